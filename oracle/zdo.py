@@ -1,0 +1,240 @@
+"""TEST INFRASTRUCTURE ONLY: ctypes loader for oracle/_build/libzd_oracle.so (the plain-C CPU
+restatement of the reference path) and, when present, oracle/_ref/libzd_ref.so (reference headers
+compiled as they lie).  Importable only from tests/, bench.py's cpu_baseline leg and
+__graft_entry__.smoke(); the product package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "libzd_oracle.so")
+_REF = os.path.join(_HERE, "_ref", "libzd_ref.so")
+
+ICFORMATS = {"Zeldovich": 0, "RVZel": 1, "RVdoubleZel": 2, "ZelSimple": 3}
+RECORD_DTYPES = {
+    "Zeldovich": np.dtype([("ijk", "<u2", 3), ("pad", "<u2"), ("d", "<f8", 3)]),
+    "RVZel": np.dtype([("ijk", "<u2", 3), ("pad", "<u2"), ("d", "<f4", 3), ("v", "<f4", 3)]),
+    "RVdoubleZel": np.dtype([("ijk", "<u2", 3), ("pad", "<u2"), ("d", "<f8", 3), ("v", "<f8", 3)]),
+    "ZelSimple": np.dtype([("d", "<f4", 3)]),
+}
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB):
+        subprocess.check_call(["make", "-C", _HERE, "_build/libzd_oracle.so"])
+    return _LIB
+
+
+class Pcg(C.Structure):
+    _fields_ = [("hi", C.c_uint64), ("lo", C.c_uint64)]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("ppd", C.c_int64), ("numblock", C.c_int), ("cpd", C.c_int), ("boxsize", C.c_double),
+        ("separation", C.c_double), ("fundamental", C.c_double), ("nyquist", C.c_double),
+        ("k_cutoff", C.c_double), ("qdensity", C.c_int), ("qoneslab", C.c_int), ("seed", C.c_int),
+        ("f_cluster", C.c_double), ("qonemode", C.c_int), ("one_mode", C.c_int * 3),
+        ("qPLT", C.c_int), ("qPLTrescale", C.c_int), ("PLT_target_z", C.c_double),
+        ("z_initial", C.c_double), ("CornerModes", C.c_int), ("icformat", C.c_int),
+        ("nthreads", C.c_int),
+    ]
+
+
+class Pk(C.Structure):
+    _fields_ = [
+        ("n", C.c_int), ("x", C.POINTER(C.c_double)), ("y", C.POINTER(C.c_double)),
+        ("y2", C.POINTER(C.c_double)), ("normalization", C.c_double), ("Pk_smooth2", C.c_double),
+        ("fixed_power", C.c_int), ("is_powerlaw", C.c_int), ("powerlaw_index", C.c_double),
+        ("kmin", C.c_double), ("kmax", C.c_double), ("Rnorm", C.c_double),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [("max_disp", C.c_double * 3), ("density_variance", C.c_double),
+                ("t_stage1", C.c_double), ("t_store", C.c_double), ("t_load", C.c_double),
+                ("t_fft2d", C.c_double), ("t_write", C.c_double)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB)
+        L.zdo_pcg_next.restype = C.c_uint64
+        L.zdo_pcg_distance.restype = C.c_uint64
+        L.zdo_u01.restype = C.c_double
+        L.zdo_u01.argtypes = [C.c_uint64]
+        L.zdo_spline_val.restype = C.c_double
+        L.zdo_power.restype = C.c_double
+        L.zdo_power.argtypes = [C.POINTER(Pk), C.c_double]
+        L.zdo_sigmaR.restype = C.c_double
+        L.zdo_sigmaR.argtypes = [C.POINTER(Pk), C.c_double]
+        L.zdo_pk_from_file.argtypes = [C.POINTER(Pk), C.c_char_p] + [C.c_double] * 5 + [C.c_int, C.c_double]
+        L.zdo_pk_from_powerlaw.argtypes = [C.POINTER(Pk)] + [C.c_double] * 5 + [C.c_int, C.c_double]
+        L.zdo_pcg_seed.argtypes = [C.POINTER(Pcg), C.c_uint64]
+        L.zdo_pcg_next.argtypes = [C.POINTER(Pcg)]
+        L.zdo_pcg_advance.argtypes = [C.POINTER(Pcg), C.c_uint64, C.c_uint64]
+        L.zdo_pcg_distance.argtypes = [C.POINTER(Pcg), C.POINTER(Pcg)]
+        L.zdo_run.argtypes = [C.POINTER(Params), C.POINTER(Pk), C.c_void_p, C.c_int64, C.c_void_p,
+                              C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+        L.zdo_mode_cube.argtypes = [C.POINTER(Params), C.POINTER(Pk), C.c_void_p, C.c_int64, C.c_void_p]
+        L.zdo_mode_draw.argtypes = [C.POINTER(Params), C.POINTER(Pk), C.c_int, C.c_int, C.c_int,
+                                    C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+        L.zdo_get_eigenmode.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64,
+                                        C.c_int, C.POINTER(C.c_double)]
+        L.zdo_spline_build.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.zdo_spline_val.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
+        _lib = L
+    return _lib
+
+
+def have_ref():
+    return os.path.exists(_REF)
+
+
+_ref = None
+
+
+def ref():
+    """reference pcg64 / SplineFunction object code (this container only)"""
+    global _ref
+    if _ref is None:
+        R = C.CDLL(_REF)
+        R.ref_pcg_distance.restype = C.c_uint64
+        R.ref_pcg_distance.argtypes = [C.c_uint64] * 4
+        R.ref_pcg_seed.argtypes = [C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        R.ref_pcg_draw.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int, C.c_void_p]
+        R.ref_pcg_advance.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64]
+        R.ref_spline_val.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        _ref = R
+    return _ref
+
+
+def make_params(ppd, numblock=2, boxsize=720.0, seed=12346, k_cutoff=1.0, qPLT=0, qPLTrescale=0,
+                PLT_target_z=0.0, z_initial=49.0, f_cluster=1.0, icformat="RVdoubleZel", qdensity=0,
+                qoneslab=-1, qonemode=0, one_mode=(0, 0, 0), CornerModes=0, cpd=None, nthreads=0):
+    p = Params()
+    p.ppd = ppd
+    p.numblock = numblock
+    p.cpd = cpd if cpd is not None else ppd
+    p.boxsize = boxsize
+    # src/parameters.cpp:172-174
+    p.separation = boxsize / ppd
+    p.nyquist = np.pi / p.separation
+    p.fundamental = 2.0 * np.pi / boxsize
+    p.k_cutoff = k_cutoff
+    p.qdensity = qdensity
+    p.qoneslab = qoneslab
+    p.seed = seed
+    p.f_cluster = f_cluster
+    p.qonemode = qonemode
+    p.one_mode = (C.c_int * 3)(*one_mode)
+    p.qPLT = qPLT
+    p.qPLTrescale = qPLTrescale
+    p.PLT_target_z = PLT_target_z
+    p.z_initial = z_initial
+    p.CornerModes = CornerModes
+    p.icformat = ICFORMATS[icformat]
+    p.nthreads = nthreads
+    return p
+
+
+def pk_from_file(path, boxsize, Pk_scale=1.0, Pk_norm=8.0, Pk_sigma=0.0210839935761, Pk_sigma_ratio=0.0,
+                 Pk_smooth=0.0, fix_to_mean=0):
+    pk = Pk()
+    rc = lib().zdo_pk_from_file(C.byref(pk), path.encode(), Pk_scale, Pk_norm, Pk_sigma, Pk_sigma_ratio,
+                                Pk_smooth, fix_to_mean, boxsize)
+    if rc:
+        raise RuntimeError("zdo_pk_from_file failed")
+    return pk
+
+
+def pk_from_powerlaw(index, boxsize, Pk_norm=8.0, Pk_sigma=0.02, Pk_sigma_ratio=0.0, Pk_smooth=0.0,
+                     fix_to_mean=0):
+    pk = Pk()
+    lib().zdo_pk_from_powerlaw(C.byref(pk), index, Pk_norm, Pk_sigma, Pk_sigma_ratio, Pk_smooth,
+                               fix_to_mean, boxsize)
+    return pk
+
+
+def pk_tables(pk):
+    n = pk.n
+    return (np.ctypeslib.as_array(pk.x, (n,)).copy(), np.ctypeslib.as_array(pk.y, (n,)).copy(),
+            np.ctypeslib.as_array(pk.y2, (n,)).copy())
+
+
+def run(params, pk, eig=None, eig_ppd=0, want_planes=False, want_density=False):
+    """returns dict(records=structured array [z,y,x], planes=[z,a,y,x] complex, stats)"""
+    L = lib()
+    n = int(params.ppd)
+    fmt = [k for k, v in ICFORMATS.items() if v == params.icformat][0]
+    dt = RECORD_DTYPES[fmt]
+    na = L.zdo_narray(C.byref(params))
+    rec = np.zeros(n * n * n, dtype=dt) if params.qdensity != 2 else None
+    planes = np.zeros((n, na, n, n), dtype=np.complex128) if want_planes else None
+    dens = np.zeros(n * n * n, dtype=np.float32) if want_density else None
+    st = Stats()
+    eigp = eig.ctypes.data if eig is not None else None
+    rc = L.zdo_run(C.byref(params), C.byref(pk), eigp, eig_ppd,
+                   rec.ctypes.data if rec is not None else None,
+                   dens.ctypes.data if dens is not None else None,
+                   planes.ctypes.data if planes is not None else None, C.byref(st))
+    if rc:
+        raise RuntimeError("zdo_run failed rc=%d" % rc)
+    return dict(records=None if rec is None else rec.reshape(n, n, n), planes=planes,
+                density=None if dens is None else dens.reshape(n, n, n),
+                max_disp=np.array(list(st.max_disp)), density_variance=st.density_variance, stats=st)
+
+
+def mode_cube(params, pk, eig=None, eig_ppd=0):
+    L = lib()
+    n = int(params.ppd)
+    na = L.zdo_narray(C.byref(params))
+    cube = np.zeros((na, n, n, n), dtype=np.complex128)  # [a][ky][kz][kx]
+    rc = L.zdo_mode_cube(C.byref(params), C.byref(pk), eig.ctypes.data if eig is not None else None,
+                         eig_ppd, cube.ctypes.data)
+    if rc:
+        raise RuntimeError("zdo_mode_cube failed")
+    return cube
+
+
+def synthetic_eigenmodes(ppd_e, seed=7, amp=0.15):
+    """Synthetic PLT eigenmode table in the reference's file layout (src/zeldovich.cpp:796-797,815,
+    155-159): float64 [ppd_e][ppd_e][ppd_e/2+1][4] = (e_x,e_y,e_z,lambda), FFT order, |e|=1.
+    eigmodes128 is absent from the reference mount, so PLT paths are exercised with this table:
+    e = normalised(k_hat + smooth perturbation ~ (k/k_Ny)^2), lambda = 1 - 0.2 (k/k_Ny)^2."""
+    h = ppd_e // 2 + 1
+    idx = np.arange(ppd_e)
+    kfull = np.where(idx > ppd_e // 2, idx - ppd_e, idx).astype(np.float64)
+    kx = kfull[:, None, None]
+    ky = kfull[None, :, None]
+    kz = np.arange(h, dtype=np.float64)[None, None, :]
+    kn = ppd_e / 2.0
+    k2 = kx * kx + ky * ky + kz * kz
+    kk = np.sqrt(np.where(k2 > 0, k2, 1.0))
+    q2 = k2 / (kn * kn)
+    rng = np.random.RandomState(seed)
+    c = rng.uniform(-1, 1, size=(3, 3))
+    # smooth, odd-in-k perturbation so that e(-k) = -e(k) like k_hat itself
+    px = (c[0, 0] * kx + c[0, 1] * ky + c[0, 2] * kz) / kn
+    py = (c[1, 0] * kx + c[1, 1] * ky + c[1, 2] * kz) / kn
+    pz = (c[2, 0] * kx + c[2, 1] * ky + c[2, 2] * kz) / kn
+    ex = kx / kk + amp * q2 * px
+    ey = ky / kk + amp * q2 * py
+    ez = kz / kk + amp * q2 * pz
+    mag = np.sqrt(ex * ex + ey * ey + ez * ez)
+    mag = np.where(mag > 0, mag, 1.0)
+    out = np.empty((ppd_e, ppd_e, h, 4), dtype=np.float64)
+    out[..., 0] = ex / mag
+    out[..., 1] = ey / mag
+    out[..., 2] = ez / mag
+    out[..., 3] = 1.0 - 0.2 * q2
+    out[0, 0, 0, :3] = 0.0
+    return np.ascontiguousarray(out)
