@@ -1,0 +1,180 @@
+/* zeldovich_hip.h — C ABI of the MI355X-native grid->displacements path.
+ *
+ * The reference (abacusorg/zeldovich-PLT, mounted at /root/reference; citations are relative to it)
+ * has no plugin / FFI interface: the path sits behind three C++ call sites in main()
+ * (src/zeldovich.cpp:938 Setup_FFTW, :962-971 BlockArray + ZeldovichZ, :982 ZeldovichXY, which calls
+ * back WriteParticlesSlab once per z plane, :667-681).  This header is the C-ABI a maintainer binds
+ * in their place — plain pointers and sizes, no C++ / torch types.  INTEGRATION.md shows the binding.
+ *
+ * Library: zeldovich_plt_amd/csrc/build/libzeldovich_hip.so (HIP, gfx950 only).  All entry points
+ * return 0 on success and non-zero on failure after printing a message to stderr (the reference's
+ * convention is message + exit(1); the CLI wrapper turns a non-zero return into exit(1)).
+ */
+#ifndef ZELDOVICH_HIP_H
+#define ZELDOVICH_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZD_MAX_PPD 65536 /* include/zeldovich.h:34 — fixes the RNG addressing */
+
+/* ICFormat -> record layout (include/output.h:19-49) */
+enum { ZD_FMT_ZEL = 0, ZD_FMT_RVZEL = 1, ZD_FMT_RVDOUBLEZEL = 2, ZD_FMT_ZELSIMPLE = 3 };
+
+/* The subset of `Parameters` (include/parameters.h:9-86) that the path reads, with the derived
+ * quantities of Parameters::setup (src/parameters.cpp:172-174) already filled in. */
+typedef struct zd_params {
+    int64_t ppd;        /* cbrt(NP) */
+    int32_t numblock;   /* ZD_NumBlock: accepted for compatibility; v2 output does not depend on it */
+    int32_t cpd;        /* CPD: only used by the writer for ic_{z*cpd/ppd} */
+    double boxsize;     /* BoxSize */
+    double fundamental; /* 2 pi / boxsize */
+    double nyquist;     /* pi / (boxsize/ppd) */
+    double k_cutoff;    /* ZD_k_cutoff */
+    double f_cluster;   /* ZD_f_cluster */
+    double z_initial;   /* InitialRedshift */
+    double PLT_target_z;
+    int64_t seed;        /* ZD_Seed widened int -> unsigned long as src/power_spectrum.cpp:14 does */
+    int32_t corner_modes;/* ZD_CornerModes */
+    int32_t qdensity;    /* ZD_qdensity: 0 none, 1 also density plane, 2 density only */
+    int32_t qoneslab;    /* ZD_qoneslab: -1 all, else only this z is delivered */
+    int32_t qonemode;    /* ZD_qonemode */
+    int32_t one_mode[3]; /* ZD_one_mode */
+    int32_t qPLT;        /* ZD_qPLT */
+    int32_t qPLTrescale; /* ZD_qPLT_rescale */
+    int32_t icformat;    /* ZD_FMT_* */
+    /* --- optional MI355X knobs (0 = let the library decide); not present in the reference --- */
+    int32_t stream_factor; /* R: number of z-residue passes (power of two) */
+    int32_t profile;       /* 1: bracket every kernel with hipEvents and report per-kernel ms */
+} zd_params;
+
+/* PowerSpectrum state after InitFromFile/InitFromPowerLaw + Normalize (src/power_spectrum.cpp:130-223).
+ * Tables are the (ln k, ln P, y'') arrays of SplineFunction (include/spline_function.h). */
+typedef struct zd_pk {
+    int32_t n;
+    const double *x, *y, *y2;
+    double normalization;
+    double Pk_smooth2;
+    int32_t fixed_power; /* ZD_qPk_fix_to_mean */
+    int32_t is_powerlaw;
+    double powerlaw_index;
+    double kmax; /* largest tabulated k (extrapolation warning only) */
+} zd_pk;
+
+/* Names of the kernels in timing arrays */
+enum { ZD_K_GEN = 0, ZD_K_ZFFT = 1, ZD_K_YFFT = 2, ZD_K_XFFT = 3, ZD_K_COUNT = 4 };
+
+typedef struct zd_stats {
+    double max_disp[3];      /* output.cpp:28: signed value of the largest |displacement| per axis (x,y,z) */
+    double density_variance; /* output.cpp:30: sum of dens^2 over delivered planes */
+    double seconds_total;    /* wall time of the grid->displacements interval (host clock, synced) */
+    double kernel_ms[ZD_K_COUNT];      /* summed hipEvent time per kernel (profile=1) */
+    int64_t kernel_launches[ZD_K_COUNT];
+    int64_t bytes_intermediate; /* size of the z-FFT'd block store held in HBM per residue pass */
+    int32_t stream_factor;      /* R actually used */
+    int32_t modes_cached;       /* 1 if the Gaussian mode amplitudes were kept in HBM across passes */
+} zd_stats;
+
+/* Replacement for the per-plane callback WriteParticlesSlab (src/output.cpp:41-234).
+ *   z          plane index (reference calls in increasing z; with stream_factor R > 1 planes arrive in
+ *              residue order r, r+R, ... and `z` tells the consumer where they belong)
+ *   n_records  ppd*ppd
+ *   records    HOST pointer to n_records packed records (ICFormat layout), valid during the call only
+ *   density    HOST pointer to n_records float32 densities, or NULL unless qdensity != 0
+ * Return non-zero to abort. */
+typedef int (*zd_slab_cb)(void *user, int64_t z, int64_t n_records, const void *records,
+                          const float *density);
+
+/* One call = ZeldovichZ + ZeldovichXY (src/zeldovich.cpp:517-695) on one GPU.
+ *   eig / eig_ppd: PLT eigenmode table as loaded by load_eigmodes (src/zeldovich.cpp:794-830),
+ *                  [eig_ppd][eig_ppd][eig_ppd/2+1][4] doubles; NULL/0 unless qPLT.
+ *   cb may be NULL: planes are then produced in HBM and dropped (benchmark sink). */
+int zd_generate(const zd_params *p, const zd_pk *pk, const double *eig, int64_t eig_ppd, zd_slab_cb cb,
+                void *user, zd_stats *out);
+
+/* Smallest power-of-two stream factor R whose block store (ppd^3*16*narray/R/nranks bytes, doubled for
+ * nranks > 1: send + receive) fits in budget_bytes; -1 if none. */
+int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes);
+
+/* ---- staged API (device pointers) for one-process-per-GPU drivers and for tests ---------------
+ * Rank `rank` of `nranks` owns half-space rows ky in [rank*H, (rank+1)*H), H = ppd/2/nranks, plus
+ * their Hermitian twins, during the Z stage, and z planes [rank*Zq, (rank+1)*Zq) of every residue
+ * pass (Zq = ppd/R/nranks) during the XY stage.  Between the two, the caller exchanges equal
+ * chunks (all-to-all): chunk d of the send buffer goes to rank d and is received as chunk `rank`…
+ * of the receive buffer (exactly torch.distributed.all_to_all_single / ncclAllToAll semantics).
+ * With nranks == 1 the send buffer IS the receive buffer. */
+typedef struct zd_plan zd_plan;
+
+int zd_plan_create(const zd_params *p, const zd_pk *pk, const double *eig, int64_t eig_ppd, int rank,
+                   int nranks, zd_plan **out);
+void zd_plan_destroy(zd_plan *plan);
+
+int32_t zd_plan_narray(const zd_plan *plan);       /* 1, 2 or 4 (src/zeldovich.cpp:871-876) */
+int32_t zd_plan_stream_factor(const zd_plan *plan);/* R */
+int32_t zd_plan_record_size(const zd_plan *plan);  /* bytes per particle record */
+int64_t zd_plan_exchange_bytes(const zd_plan *plan); /* bytes of the send (= receive) buffer per pass */
+int64_t zd_plan_local_planes(const zd_plan *plan);   /* Zq: z planes this rank finishes per pass */
+int64_t zd_plan_plane_z(const zd_plan *plan, int residue, int64_t local_plane); /* global z */
+
+/* Z stage for residue pass `residue`: mode generation (or cache reuse) + folded z FFT for the rows
+ * this rank owns, written into `d_send` (device pointer, zd_plan_exchange_bytes). */
+int zd_plan_stage_z(zd_plan *plan, int residue, void *d_send, void *hip_stream);
+
+/* XY stage: in-place y FFT on `d_recv`, then x FFT + particle epilogue for local planes
+ * [plane0, plane0+nplanes).  d_records: nplanes*ppd*ppd records; d_density: float32 or NULL. */
+int zd_plan_stage_y(zd_plan *plan, void *d_recv, void *hip_stream);
+int zd_plan_stage_x(zd_plan *plan, int residue, const void *d_recv, int64_t plane0, int64_t nplanes,
+                    void *d_records, float *d_density, void *hip_stream);
+
+/* Fetch + reset the device-side reductions (max_disp, density_variance) and kernel timers. Syncs. */
+int zd_plan_stats(zd_plan *plan, zd_stats *out);
+
+/* ---- host-side helpers mirroring the reference's setup code (no GPU needed) -------------------- */
+/* Parameters(file) + setup(): src/parameters.cpp:11-197.  Fills zd_params; strings via out buffers. */
+typedef struct zd_param_strings {
+    char Pk_filename[1024];
+    char output_dir[1024];
+    char density_filename[1024];
+    char PLT_filename[1024];
+    char ICFormat[64];
+    double Pk_scale, Pk_norm, Pk_sigma, Pk_sigma_ratio, Pk_smooth, Pk_powerlaw_index;
+    int32_t qPk_fix_to_mean;
+    int32_t version;
+    double f_NL, n_s, Omega_M;
+    int64_t np;
+} zd_param_strings;
+int zd_params_from_file(const char *path, zd_params *p, zd_param_strings *s);
+
+/* PowerSpectrum: InitFromFile / InitFromPowerLaw + Normalize.  The handle owns the tables that
+ * zd_pk points into. */
+typedef struct zd_pk_handle zd_pk_handle;
+int zd_pk_create_from_file(const char *path, double Pk_scale, double Pk_norm, double Pk_sigma,
+                           double Pk_sigma_ratio, double Pk_smooth, int fix_to_mean, double boxsize,
+                           zd_pk_handle **h, zd_pk *pk);
+int zd_pk_create_powerlaw(double index, double Pk_norm, double Pk_sigma, double Pk_sigma_ratio,
+                          double Pk_smooth, int fix_to_mean, double boxsize, zd_pk_handle **h, zd_pk *pk);
+double zd_pk_power(const zd_pk *pk, double k);  /* PowerSpectrum::power, src/power_spectrum.cpp:225 */
+double zd_pk_sigmaR(const zd_pk *pk, double R); /* PowerSpectrum::sigmaR, src/power_spectrum.cpp:60 */
+void zd_pk_destroy(zd_pk_handle *h);
+
+/* load_eigmodes: src/zeldovich.cpp:794-830.  Caller frees with zd_free. */
+int zd_load_eigmodes(const char *path, double **eig, int64_t *eig_ppd);
+void zd_free(void *p);
+
+/* ---- device test hooks (used by tests/ and bench.py only; each needs a GPU) -------------------- */
+/* n counter-addressed draws: out[2*i], out[2*i+1] = the two uint64 of mode (kx,ky,kz)[i] */
+int zd_test_draws(int64_t seed, int64_t n, const int32_t *kxyz, uint64_t *out);
+/* Gaussian amplitudes D(k) for the same mode list (cgauss<2>, src/power_spectrum.cpp:338-359) */
+int zd_test_modes(const zd_params *p, const zd_pk *pk, int64_t n, const int32_t *kxyz, double *D);
+/* batch of `lines` independent length-n inverse FFTs, host in/out [lines][n] complex double;
+ * axis_kind 0: the contiguous-line kernel path (x pass), 1: the strided-line path (y/z passes) */
+int zd_test_fft(int32_t n, int64_t lines, int32_t axis_kind, const double *in, double *out);
+/* device copy bandwidth probe: bytes moved per second by a 16 B/lane streaming copy of `bytes` */
+int zd_test_copy_bw(int64_t bytes, int32_t reps, double *gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,363 @@
+"""ctypes binding of include/zeldovich_hip.h — the host-side mirror of the reference's call sites
+(Parameters / PowerSpectrum / ZeldovichZ + ZeldovichXY, src/zeldovich.cpp:848-1032).
+
+This module is plumbing only: every number is produced by libzeldovich_hip.so (HIP, gfx950).  There is
+no CPU fallback — if the library is missing, or no GPU is present when a compute entry point is
+called, it fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "build", "libzeldovich_hip.so")
+
+ICFORMATS = {"Zeldovich": 0, "RVZel": 1, "RVdoubleZel": 2, "ZelSimple": 3}
+RECORD_DTYPES = {
+    "Zeldovich": np.dtype([("ijk", "<u2", 3), ("pad", "<u2"), ("d", "<f8", 3)]),
+    "RVZel": np.dtype([("ijk", "<u2", 3), ("pad", "<u2"), ("d", "<f4", 3), ("v", "<f4", 3)]),
+    "RVdoubleZel": np.dtype([("ijk", "<u2", 3), ("pad", "<u2"), ("d", "<f8", 3), ("v", "<f8", 3)]),
+    "ZelSimple": np.dtype([("d", "<f4", 3)]),
+}
+KERNEL_NAMES = ("k_gen", "k_zfft", "k_yfft", "k_xfft")
+
+
+class ZdParams(C.Structure):
+    _fields_ = [
+        ("ppd", C.c_int64), ("numblock", C.c_int32), ("cpd", C.c_int32), ("boxsize", C.c_double),
+        ("fundamental", C.c_double), ("nyquist", C.c_double), ("k_cutoff", C.c_double),
+        ("f_cluster", C.c_double), ("z_initial", C.c_double), ("PLT_target_z", C.c_double),
+        ("seed", C.c_int64), ("corner_modes", C.c_int32), ("qdensity", C.c_int32),
+        ("qoneslab", C.c_int32), ("qonemode", C.c_int32), ("one_mode", C.c_int32 * 3),
+        ("qPLT", C.c_int32), ("qPLTrescale", C.c_int32), ("icformat", C.c_int32),
+        ("stream_factor", C.c_int32), ("profile", C.c_int32),
+    ]
+
+
+class ZdPk(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("x", C.POINTER(C.c_double)), ("y", C.POINTER(C.c_double)),
+        ("y2", C.POINTER(C.c_double)), ("normalization", C.c_double), ("Pk_smooth2", C.c_double),
+        ("fixed_power", C.c_int32), ("is_powerlaw", C.c_int32), ("powerlaw_index", C.c_double),
+        ("kmax", C.c_double),
+    ]
+
+
+class ZdStats(C.Structure):
+    _fields_ = [
+        ("max_disp", C.c_double * 3), ("density_variance", C.c_double), ("seconds_total", C.c_double),
+        ("kernel_ms", C.c_double * 4), ("kernel_launches", C.c_int64 * 4),
+        ("bytes_intermediate", C.c_int64), ("stream_factor", C.c_int32), ("modes_cached", C.c_int32),
+    ]
+
+
+class ZdParamStrings(C.Structure):
+    _fields_ = [
+        ("Pk_filename", C.c_char * 1024), ("output_dir", C.c_char * 1024),
+        ("density_filename", C.c_char * 1024), ("PLT_filename", C.c_char * 1024),
+        ("ICFormat", C.c_char * 64),
+        ("Pk_scale", C.c_double), ("Pk_norm", C.c_double), ("Pk_sigma", C.c_double),
+        ("Pk_sigma_ratio", C.c_double), ("Pk_smooth", C.c_double), ("Pk_powerlaw_index", C.c_double),
+        ("qPk_fix_to_mean", C.c_int32), ("version", C.c_int32),
+        ("f_NL", C.c_double), ("n_s", C.c_double), ("Omega_M", C.c_double), ("np", C.c_int64),
+    ]
+
+
+SLAB_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p)
+
+# every symbol include/zeldovich_hip.h declares (checked by tests/test_capi_symbols.py)
+EXPORTED_SYMBOLS = [
+    "zd_generate", "zd_choose_stream_factor", "zd_plan_create", "zd_plan_destroy", "zd_plan_narray",
+    "zd_plan_stream_factor", "zd_plan_record_size", "zd_plan_exchange_bytes", "zd_plan_local_planes",
+    "zd_plan_plane_z", "zd_plan_stage_z", "zd_plan_stage_y", "zd_plan_stage_x", "zd_plan_stats",
+    "zd_params_from_file", "zd_pk_create_from_file", "zd_pk_create_powerlaw", "zd_pk_power",
+    "zd_pk_sigmaR", "zd_pk_destroy", "zd_load_eigmodes", "zd_free", "zd_test_draws", "zd_test_modes",
+    "zd_test_fft", "zd_test_copy_bw",
+]
+
+_lib = None
+
+
+def load_library():
+    """Load libzeldovich_hip.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "zeldovich_plt_amd: %s is missing — run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C zeldovich_plt_amd/csrc`; there is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    L.zd_generate.argtypes = [C.POINTER(ZdParams), C.POINTER(ZdPk), vp, i64, SLAB_CB, vp, C.POINTER(ZdStats)]
+    L.zd_choose_stream_factor.argtypes = [C.POINTER(ZdParams), C.c_int, i64]
+    L.zd_plan_create.argtypes = [C.POINTER(ZdParams), C.POINTER(ZdPk), vp, i64, C.c_int, C.c_int, C.POINTER(vp)]
+    L.zd_plan_destroy.argtypes = [vp]
+    L.zd_plan_destroy.restype = None
+    for name in ("zd_plan_narray", "zd_plan_stream_factor", "zd_plan_record_size"):
+        getattr(L, name).argtypes = [vp]
+        getattr(L, name).restype = i32
+    for name in ("zd_plan_exchange_bytes", "zd_plan_local_planes"):
+        getattr(L, name).argtypes = [vp]
+        getattr(L, name).restype = i64
+    L.zd_plan_plane_z.argtypes = [vp, C.c_int, i64]
+    L.zd_plan_plane_z.restype = i64
+    L.zd_plan_stage_z.argtypes = [vp, C.c_int, vp, vp]
+    L.zd_plan_stage_y.argtypes = [vp, vp, vp]
+    L.zd_plan_stage_x.argtypes = [vp, C.c_int, vp, i64, i64, vp, vp, vp]
+    L.zd_plan_stats.argtypes = [vp, C.POINTER(ZdStats)]
+    L.zd_params_from_file.argtypes = [C.c_char_p, C.POINTER(ZdParams), C.POINTER(ZdParamStrings)]
+    L.zd_pk_create_from_file.argtypes = [C.c_char_p, dbl, dbl, dbl, dbl, dbl, C.c_int, dbl, C.POINTER(vp), C.POINTER(ZdPk)]
+    L.zd_pk_create_powerlaw.argtypes = [dbl, dbl, dbl, dbl, dbl, C.c_int, dbl, C.POINTER(vp), C.POINTER(ZdPk)]
+    L.zd_pk_power.argtypes = [C.POINTER(ZdPk), dbl]
+    L.zd_pk_power.restype = dbl
+    L.zd_pk_sigmaR.argtypes = [C.POINTER(ZdPk), dbl]
+    L.zd_pk_sigmaR.restype = dbl
+    L.zd_pk_destroy.argtypes = [vp]
+    L.zd_pk_destroy.restype = None
+    L.zd_load_eigmodes.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(i64)]
+    L.zd_free.argtypes = [vp]
+    L.zd_free.restype = None
+    L.zd_test_draws.argtypes = [i64, i64, vp, vp]
+    L.zd_test_modes.argtypes = [C.POINTER(ZdParams), C.POINTER(ZdPk), i64, vp, vp]
+    L.zd_test_fft.argtypes = [i32, i64, i32, vp, vp]
+    L.zd_test_copy_bw.argtypes = [i64, i32, C.POINTER(dbl)]
+    _lib = L
+    return L
+
+
+def make_params(ppd, numblock=2, boxsize=720.0, seed=12346, k_cutoff=1.0, qPLT=0, qPLTrescale=0,
+                PLT_target_z=0.0, z_initial=49.0, f_cluster=1.0, icformat="RVdoubleZel", qdensity=0,
+                qoneslab=-1, qonemode=0, one_mode=(0, 0, 0), corner_modes=0, cpd=None, stream_factor=0,
+                profile=0):
+    """Parameters with the derived quantities of Parameters::setup (src/parameters.cpp:172-174)."""
+    p = ZdParams()
+    p.ppd = ppd
+    p.numblock = numblock
+    p.cpd = cpd if cpd is not None else ppd
+    p.boxsize = boxsize
+    p.fundamental = 2.0 * np.pi / boxsize
+    p.nyquist = np.pi / (boxsize / ppd)
+    p.k_cutoff = k_cutoff
+    p.f_cluster = f_cluster
+    p.z_initial = z_initial
+    p.PLT_target_z = PLT_target_z
+    p.seed = int(seed)
+    p.corner_modes = corner_modes
+    p.qdensity = qdensity
+    p.qoneslab = qoneslab
+    p.qonemode = qonemode
+    p.one_mode = (C.c_int32 * 3)(*one_mode)
+    p.qPLT = qPLT
+    p.qPLTrescale = qPLTrescale
+    p.icformat = ICFORMATS[icformat]
+    p.stream_factor = stream_factor
+    p.profile = profile
+    return p
+
+
+def params_from_file(path):
+    """Parameters(file): returns (ZdParams, ZdParamStrings); raises on invalid input."""
+    L = load_library()
+    p, s = ZdParams(), ZdParamStrings()
+    if L.zd_params_from_file(os.fsencode(path), C.byref(p), C.byref(s)):
+        raise ValueError("Invalid Parameters given: %s" % path)
+    return p, s
+
+
+class PowerSpectrum:
+    """PowerSpectrum after InitFromFile / InitFromPowerLaw + Normalize (src/power_spectrum.cpp:130-223)."""
+
+    def __init__(self, pk, handle):
+        self.pk = pk
+        self._h = handle
+
+    @classmethod
+    def from_file(cls, path, boxsize, Pk_scale=1.0, Pk_norm=8.0, Pk_sigma=0.0210839935761,
+                  Pk_sigma_ratio=0.0, Pk_smooth=0.0, fix_to_mean=0):
+        L = load_library()
+        pk, h = ZdPk(), C.c_void_p()
+        if L.zd_pk_create_from_file(os.fsencode(path), Pk_scale, Pk_norm, Pk_sigma, Pk_sigma_ratio, Pk_smooth,
+                                    fix_to_mean, boxsize, C.byref(h), C.byref(pk)):
+            raise RuntimeError("power spectrum file %r could not be loaded" % path)
+        return cls(pk, h)
+
+    @classmethod
+    def from_powerlaw(cls, index, boxsize, Pk_norm=8.0, Pk_sigma=0.02, Pk_sigma_ratio=0.0, Pk_smooth=0.0,
+                      fix_to_mean=0):
+        L = load_library()
+        pk, h = ZdPk(), C.c_void_p()
+        if L.zd_pk_create_powerlaw(index, Pk_norm, Pk_sigma, Pk_sigma_ratio, Pk_smooth, fix_to_mean, boxsize,
+                                   C.byref(h), C.byref(pk)):
+            raise RuntimeError("power law spectrum could not be initialised")
+        return cls(pk, h)
+
+    def power(self, k):
+        return load_library().zd_pk_power(C.byref(self.pk), float(k))
+
+    def sigmaR(self, R):
+        return load_library().zd_pk_sigmaR(C.byref(self.pk), float(R))
+
+    def tables(self):
+        n = self.pk.n
+        return tuple(np.ctypeslib.as_array(a, (n,)).copy() for a in (self.pk.x, self.pk.y, self.pk.y2))
+
+    def __del__(self):
+        try:
+            if self._h:
+                load_library().zd_pk_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def _fmt_name(icformat):
+    return [k for k, v in ICFORMATS.items() if v == icformat][0]
+
+
+def _stats_dict(st):
+    return dict(max_disp=np.array(list(st.max_disp)), density_variance=st.density_variance,
+                seconds_total=st.seconds_total, kernel_ms=dict(zip(KERNEL_NAMES, list(st.kernel_ms))),
+                kernel_launches=dict(zip(KERNEL_NAMES, list(st.kernel_launches))),
+                bytes_intermediate=st.bytes_intermediate, stream_factor=st.stream_factor,
+                modes_cached=bool(st.modes_cached))
+
+
+def generate(params, ps, eig=None, collect=True):
+    """ZeldovichZ + ZeldovichXY on cuda:0 through zd_generate.
+
+    collect=True gathers every delivered plane (host callback, like WriteParticlesSlab) into
+    records[z, y, x] (and density[z, y, x] when qdensity); collect=False uses the NULL sink."""
+    L = load_library()
+    n = int(params.ppd)
+    st = ZdStats()
+    eigp, eig_ppd = (None, 0)
+    if eig is not None:
+        eig = np.ascontiguousarray(eig, dtype=np.float64)
+        eigp, eig_ppd = eig.ctypes.data, eig.shape[0]
+    out = {}
+    if collect:
+        dt = RECORD_DTYPES[_fmt_name(params.icformat)]
+        rec = np.zeros((n, n * n), dtype=dt) if params.qdensity != 2 else None
+        dens = np.zeros((n, n * n), dtype=np.float32) if params.qdensity else None
+        seen = []
+
+        def _cb(user, z, nrec, recp, densp):
+            seen.append(int(z))
+            if recp and rec is not None:
+                C.memmove(rec[z].ctypes.data, recp, nrec * dt.itemsize)
+            if densp and dens is not None:
+                C.memmove(dens[z].ctypes.data, densp, nrec * 4)
+            return 0
+
+        cb = SLAB_CB(_cb)
+        rc = L.zd_generate(C.byref(params), C.byref(ps.pk), eigp, eig_ppd, cb, None, C.byref(st))
+        out["records"] = None if rec is None else rec.reshape(n, n, n)
+        out["density"] = None if dens is None else dens.reshape(n, n, n)
+        out["planes_seen"] = seen
+    else:
+        rc = L.zd_generate(C.byref(params), C.byref(ps.pk), eigp, eig_ppd, SLAB_CB(), None, C.byref(st))
+    if rc:
+        raise RuntimeError("zd_generate failed (rc=%d); see stderr" % rc)
+    out.update(_stats_dict(st))
+    return out
+
+
+class Plan:
+    """Staged API: one rank's share of the Z and XY stages on device pointers (see the header)."""
+
+    def __init__(self, params, ps, eig=None, rank=0, nranks=1):
+        self.L = load_library()
+        self.params = params
+        self._eig = None if eig is None else np.ascontiguousarray(eig, dtype=np.float64)
+        h = C.c_void_p()
+        rc = self.L.zd_plan_create(C.byref(params), C.byref(ps.pk),
+                                   None if self._eig is None else self._eig.ctypes.data,
+                                   0 if self._eig is None else self._eig.shape[0], rank, nranks, C.byref(h))
+        if rc:
+            raise RuntimeError("zd_plan_create failed")
+        self.h = h
+        self.rank, self.nranks = rank, nranks
+        self.narray = self.L.zd_plan_narray(h)
+        self.R = self.L.zd_plan_stream_factor(h)
+        self.record_size = self.L.zd_plan_record_size(h)
+        self.exchange_bytes = self.L.zd_plan_exchange_bytes(h)
+        self.local_planes = self.L.zd_plan_local_planes(h)
+
+    def plane_z(self, residue, local_plane):
+        return self.L.zd_plan_plane_z(self.h, residue, local_plane)
+
+    def stage_z(self, residue, d_send, stream=0):
+        if self.L.zd_plan_stage_z(self.h, residue, d_send, stream):
+            raise RuntimeError("zd_plan_stage_z failed")
+
+    def stage_y(self, d_recv, stream=0):
+        if self.L.zd_plan_stage_y(self.h, d_recv, stream):
+            raise RuntimeError("zd_plan_stage_y failed")
+
+    def stage_x(self, residue, d_recv, plane0, nplanes, d_records, d_density=None, stream=0):
+        if self.L.zd_plan_stage_x(self.h, residue, d_recv, plane0, nplanes, d_records, d_density, stream):
+            raise RuntimeError("zd_plan_stage_x failed")
+
+    def stats(self):
+        st = ZdStats()
+        if self.L.zd_plan_stats(self.h, C.byref(st)):
+            raise RuntimeError("zd_plan_stats failed")
+        return _stats_dict(st)
+
+    def close(self):
+        if self.h:
+            self.L.zd_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- device test hooks ---------------------------------------------------------------------------
+def test_draws(seed, kxyz):
+    L = load_library()
+    k = np.ascontiguousarray(kxyz, dtype=np.int32).reshape(-1, 3)
+    out = np.zeros((k.shape[0], 2), dtype=np.uint64)
+    if L.zd_test_draws(int(seed), k.shape[0], k.ctypes.data, out.ctypes.data):
+        raise RuntimeError("zd_test_draws failed")
+    return out
+
+
+def test_modes(params, ps, kxyz):
+    L = load_library()
+    k = np.ascontiguousarray(kxyz, dtype=np.int32).reshape(-1, 3)
+    out = np.zeros((k.shape[0], 2), dtype=np.float64)
+    if L.zd_test_modes(C.byref(params), C.byref(ps.pk), k.shape[0], k.ctypes.data, out.ctypes.data):
+        raise RuntimeError("zd_test_modes failed")
+    return out[:, 0] + 1j * out[:, 1]
+
+
+def test_fft(x, axis_kind):
+    """x: complex128 [lines, n]; returns the unnormalised inverse DFT of every line computed on the GPU."""
+    L = load_library()
+    x = np.ascontiguousarray(x, dtype=np.complex128)
+    lines, n = x.shape
+    if axis_kind == 1:  # strided situation: device layout [n][lines]
+        xin = np.ascontiguousarray(x.T)
+        out = np.zeros_like(xin)
+        rc = L.zd_test_fft(n, lines, 1, xin.ctypes.data, out.ctypes.data)
+        out = np.ascontiguousarray(out.T)
+    else:
+        out = np.zeros_like(x)
+        rc = L.zd_test_fft(n, lines, 0, x.ctypes.data, out.ctypes.data)
+    if rc:
+        raise RuntimeError("zd_test_fft failed")
+    return out
+
+
+def copy_bandwidth(nbytes=1 << 30, reps=10):
+    L = load_library()
+    g = C.c_double()
+    if L.zd_test_copy_bw(nbytes, reps, C.byref(g)):
+        raise RuntimeError("zd_test_copy_bw failed")
+    return g.value

@@ -1,0 +1,632 @@
+// zd_capi.cpp — C ABI (include/zeldovich_hip.h): plan management, the single-GPU driver
+// zd_generate (= ZeldovichZ + ZeldovichXY, src/zeldovich.cpp:517-695) and the device test hooks.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/zeldovich_hip.h"
+#include "zd_device.h"
+#include "zd_launch.h"
+
+using zdfft::cplx;
+using zdpcg::u128;
+
+#define HIPCHECK(call)                                                                               \
+    do {                                                                                             \
+        hipError_t e__ = (call);                                                                     \
+        if (e__ != hipSuccess) {                                                                     \
+            fprintf(stderr, "zeldovich_hip: %s failed at %s:%d: %s\n", #call, __FILE__, __LINE__,    \
+                    hipGetErrorString(e__));                                                         \
+            return 1;                                                                                \
+        }                                                                                            \
+    } while (0)
+
+namespace {
+
+struct EventPair {
+    hipEvent_t a, b;
+    int kind;
+};
+
+bool is_pow2(int64_t n) { return n > 0 && (n & (n - 1)) == 0; }
+
+std::vector<cplx> make_twiddles(int n) {
+    std::vector<cplx> tw(n);
+    for (int k = 0; k < n; k++) {
+        const long double a = 2.0L * 3.14159265358979323846264338327950288L * (long double) k / (long double) n;
+        tw[k].x = (double) cosl(a);
+        tw[k].y = (double) sinl(a);
+    }
+    return tw;
+}
+
+int record_size(int icformat) {  // include/output.h:19-42
+    switch (icformat) {
+        case ZD_FMT_ZEL: return 32;
+        case ZD_FMT_RVZEL: return 32;
+        case ZD_FMT_RVDOUBLEZEL: return 56;
+        case ZD_FMT_ZELSIMPLE: return 12;
+    }
+    return 0;
+}
+
+}  // namespace
+
+struct zd_plan {
+    zd_params p;
+    int rank = 0, nranks = 1;
+    int N = 0, half = 0, narray = 0, R = 1, L = 0, Hq = 0, Zq = 0;
+    zd::GenConst g;
+    zd::GenJumps J;
+    zd::JobList jobs;
+    zd::StoreLayout S;
+    zd::EpiConst ec;
+    // device tables
+    double *d_pk = nullptr;  // x | y | y2
+    double *d_eig = nullptr;
+    u128 *d_rowstate = nullptr;
+    cplx *d_twN = nullptr, *d_twL = nullptr;
+    zd::Reduce *d_red = nullptr;
+    // mode buffers
+    cplx *d_D = nullptr;
+    double *d_P = nullptr;
+    int slab_rows = 0;       // rows generated per k_gen launch
+    bool cache_all = false;  // D (and P) kept for all owned rows across residue passes
+    bool cache_valid = false;
+    // timing
+    std::vector<EventPair> events;
+    std::vector<hipEvent_t> pool;
+    double kernel_ms[ZD_K_COUNT] = {0, 0, 0, 0};
+    int64_t launches[ZD_K_COUNT] = {0, 0, 0, 0};
+};
+
+namespace {
+
+void tick(zd_plan *pl, int kind, hipStream_t st, bool begin) {
+    if (!pl->p.profile) return;
+    if (begin) {
+        EventPair ep;
+        hipEventCreate(&ep.a);
+        hipEventCreate(&ep.b);
+        ep.kind = kind;
+        hipEventRecord(ep.a, st);
+        pl->events.push_back(ep);
+    } else {
+        hipEventRecord(pl->events.back().b, st);
+    }
+}
+
+void collect_events(zd_plan *pl) {
+    for (auto &ep : pl->events) {
+        float ms = 0;
+        hipEventSynchronize(ep.b);
+        hipEventElapsedTime(&ms, ep.a, ep.b);
+        pl->kernel_ms[ep.kind] += ms;
+        pl->launches[ep.kind]++;
+        hipEventDestroy(ep.a);
+        hipEventDestroy(ep.b);
+    }
+    pl->events.clear();
+}
+
+int64_t mode_bytes_per_row(const zd_plan *pl) {
+    return (int64_t) pl->N * pl->N * (16 + (pl->p.qPLT ? 32 : 0));
+}
+
+}  // namespace
+
+extern "C" {
+
+int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes) {
+    const int64_t N  = p->ppd;
+    const int narray = p->qdensity == 2 ? 1 : (p->qPLT ? 4 : 2);
+    for (int R = 1; N / R >= 32; R *= 2) {
+        if ((N / R) % nranks) break;
+        int64_t store = N * N * (N / R) / nranks * 16 * narray;
+        if (nranks > 1) store *= 2;  // separate send and receive buffers
+        if (store <= budget_bytes) return R;
+    }
+    return -1;
+}
+
+int zd_plan_create(const zd_params *p, const zd_pk *pk, const double *eig, int64_t eig_ppd, int rank, int nranks,
+                   zd_plan **out) {
+    const int64_t N = p->ppd;
+    if (!is_pow2(N) || N < 32 || N > 4096) {
+        fprintf(stderr, "zeldovich_hip: PPD = %lld unsupported (power of two in [32, 4096] required)\n", (long long) N);
+        return 1;
+    }
+    if (p->qPLT && (eig == NULL || eig_ppd <= 0)) {
+        fprintf(stderr, "zeldovich_hip: ZD_qPLT set but no eigenmode table given\n");
+        return 1;
+    }
+    int R = p->stream_factor > 0 ? p->stream_factor : 1;
+    if (!is_pow2(R) || N / R < 32) {
+        fprintf(stderr, "zeldovich_hip: stream factor %d invalid for PPD %lld\n", R, (long long) N);
+        return 1;
+    }
+    if (nranks < 1 || rank < 0 || rank >= nranks || (N / 2) % nranks || (N / R) % nranks) {
+        fprintf(stderr, "zeldovich_hip: cannot split PPD %lld (R=%d) over %d ranks\n", (long long) N, R, nranks);
+        return 1;
+    }
+    zd_plan *pl = new zd_plan;
+    pl->p       = *p;
+    pl->rank    = rank;
+    pl->nranks  = nranks;
+    pl->N       = (int) N;
+    pl->half    = (int) (N / 2);
+    pl->narray  = p->qdensity == 2 ? 1 : (p->qPLT ? 4 : 2);  // zeldovich.cpp:871-876
+    pl->R       = R;
+    pl->L       = (int) (N / R);
+    pl->Hq      = pl->half / nranks;
+    pl->Zq      = pl->L / nranks;
+
+    // ---- generator constants (zeldovich.cpp:299-320, 350) ----
+    zd::GenConst &g = pl->g;
+    memset(&g, 0, sizeof(g));
+    g.N            = pl->N;
+    g.half         = pl->half;
+    g.kmax         = (int) ((double) pl->half * (1.0 / p->k_cutoff) + .5);
+    g.corner_modes = p->corner_modes;
+    g.qonemode     = p->qonemode;
+    for (int i = 0; i < 3; i++) g.one_mode[i] = p->one_mode[i];
+    g.fundamental  = p->fundamental;
+    g.fundamental2 = p->fundamental * p->fundamental;
+    g.k2_cutoff    = p->nyquist * p->nyquist / (p->k_cutoff * p->k_cutoff);
+    g.pk_n         = pk->n;
+    g.fixed_power  = pk->fixed_power;
+    g.is_powerlaw  = pk->is_powerlaw;
+    g.pk_norm      = pk->normalization;
+    g.pk_smooth2   = pk->Pk_smooth2;
+    g.powerlaw_index = pk->powerlaw_index;
+    g.qPLT         = p->qPLT;
+    g.qPLTrescale  = p->qPLTrescale;
+    g.f_cluster    = p->f_cluster;
+    g.target_f     = (sqrt(1. + 24 * p->f_cluster) - 1) / 4.;
+    {
+        double a_NL = 1.0, a0 = 1.0;
+        if (p->qPLTrescale) {
+            a_NL = 1. / (1 + p->PLT_target_z);
+            a0   = 1. / (1 + p->z_initial);
+        }
+        g.ln_growth_ratio = log(a_NL / a0);
+    }
+    g.eig_ppd = eig_ppd;
+
+#define PLCHECK(call)                                                                             \
+    do {                                                                                          \
+        hipError_t e__ = (call);                                                                  \
+        if (e__ != hipSuccess) {                                                                  \
+            fprintf(stderr, "zeldovich_hip: %s failed at %s:%d: %s\n", #call, __FILE__, __LINE__, \
+                    hipGetErrorString(e__));                                                      \
+            zd_plan_destroy(pl);                                                                  \
+            return 1;                                                                             \
+        }                                                                                         \
+    } while (0)
+
+    if (!pk->is_powerlaw) {
+        PLCHECK(hipMalloc((void **) &pl->d_pk, sizeof(double) * 3 * (size_t) pk->n));
+        PLCHECK(hipMemcpy(pl->d_pk, pk->x, sizeof(double) * pk->n, hipMemcpyHostToDevice));
+        PLCHECK(hipMemcpy(pl->d_pk + pk->n, pk->y, sizeof(double) * pk->n, hipMemcpyHostToDevice));
+        PLCHECK(hipMemcpy(pl->d_pk + 2 * pk->n, pk->y2, sizeof(double) * pk->n, hipMemcpyHostToDevice));
+        g.pk_x  = pl->d_pk;
+        g.pk_y  = pl->d_pk + pk->n;
+        g.pk_y2 = pl->d_pk + 2 * pk->n;
+    }
+    if (p->qPLT) {
+        const size_t nb = sizeof(double) * (size_t) eig_ppd * eig_ppd * (eig_ppd / 2 + 1) * 4;
+        PLCHECK(hipMalloc((void **) &pl->d_eig, nb));
+        PLCHECK(hipMemcpy(pl->d_eig, eig, nb, hipMemcpyHostToDevice));
+        g.eig = pl->d_eig;
+    }
+    // per-plane stream heads == v2rng[] of the reference (power_spectrum.cpp:26-37)
+    {
+        std::vector<u128> rows(pl->half);
+        const zdpcg::Affine plane = zdpcg::jump_map((u128) 2 * ZD_MAX_PPD * ZD_MAX_PPD);
+        rows[0] = zdpcg::seed_state((uint64_t) p->seed);
+        for (int i = 1; i < pl->half; i++) rows[i] = zdpcg::apply(plane, rows[i - 1]);
+        PLCHECK(hipMalloc((void **) &pl->d_rowstate, sizeof(u128) * rows.size()));
+        PLCHECK(hipMemcpy(pl->d_rowstate, rows.data(), sizeof(u128) * rows.size(), hipMemcpyHostToDevice));
+        g.row_state = pl->d_rowstate;
+        static zdpcg::BitTable bt;
+        static bool bt_ready = false;
+        if (!bt_ready) {
+            zdpcg::make_bit_table(bt);
+            bt_ready = true;
+        }
+        if (zdk_upload_bit_table(&bt) != 0) {
+            fprintf(stderr, "zeldovich_hip: uploading the RNG jump table failed\n");
+            zd_plan_destroy(pl);
+            return 1;
+        }
+        // state is kept one draw ahead of the mode's counter, two draws are consumed per mode:
+        // next row = +2*65536 draws, minus the one step already taken inside the loop
+        pl->J.jz  = zdpcg::jump_map((u128) 2 * 65536 - 1);
+        pl->J.jzw = zdpcg::jump_map((u128) 2 * 65536 * (u128) (1 + 65536 - N) - 1);
+    }
+    {
+        std::vector<cplx> twN = make_twiddles(pl->N), twL = make_twiddles(pl->L);
+        PLCHECK(hipMalloc((void **) &pl->d_twN, sizeof(cplx) * twN.size()));
+        PLCHECK(hipMemcpy(pl->d_twN, twN.data(), sizeof(cplx) * twN.size(), hipMemcpyHostToDevice));
+        PLCHECK(hipMalloc((void **) &pl->d_twL, sizeof(cplx) * twL.size()));
+        PLCHECK(hipMemcpy(pl->d_twL, twL.data(), sizeof(cplx) * twL.size(), hipMemcpyHostToDevice));
+    }
+    PLCHECK(hipMalloc((void **) &pl->d_red, sizeof(zd::Reduce)));
+    PLCHECK(hipMemset(pl->d_red, 0, sizeof(zd::Reduce)));
+
+    // ---- jobs of the z stage ----
+    pl->jobs.n = 0;
+    if (pl->narray == 1) {
+        pl->jobs.kind[pl->jobs.n++] = zd::JOB_DENS;
+    } else {
+        pl->jobs.kind[pl->jobs.n++] = zd::JOB_A_SELF;
+        pl->jobs.kind[pl->jobs.n++] = zd::JOB_A_TWIN;
+        pl->jobs.kind[pl->jobs.n++] = zd::JOB_B_SELF;
+        pl->jobs.kind[pl->jobs.n++] = zd::JOB_B_TWIN;
+        if (pl->narray == 4) {
+            pl->jobs.kind[pl->jobs.n++] = zd::JOB_C_BOTH;
+            pl->jobs.kind[pl->jobs.n++] = zd::JOB_D_SELF;
+            pl->jobs.kind[pl->jobs.n++] = zd::JOB_D_TWIN;
+        }
+    }
+    // ---- block store layout: [chunk = peer rank][plane][array][2*Hq rows][N] ----
+    zd::StoreLayout &S = pl->S;
+    S.N            = pl->N;
+    S.half         = pl->half;
+    S.Hq           = pl->Hq;
+    S.narray       = pl->narray;
+    S.a_stride     = (long long) 2 * pl->Hq * pl->N;
+    S.z_stride     = S.a_stride * pl->narray;
+    S.chunk_stride = S.z_stride * pl->Zq;
+
+    pl->ec.N        = pl->N;
+    pl->ec.narray   = pl->narray;
+    pl->ec.icformat = p->icformat;
+    pl->ec.recsize  = record_size(p->icformat);
+    pl->ec.qPLT     = p->qPLT;
+    pl->ec.qdensity = p->qdensity;
+    pl->ec.vnorm    = p->qPLT ? 1.0 : (sqrt(1. + 24 * p->f_cluster) - 1) * .25;  // output.cpp:78-82
+
+    // ---- mode buffers: cache everything when streaming (R > 1) and it fits, else slabs ----
+    {
+        const int64_t row_b = mode_bytes_per_row(pl);
+        size_t free_b = 0, total_b = 0;
+        PLCHECK(hipMemGetInfo(&free_b, &total_b));
+        const int64_t store_b = zd_plan_exchange_bytes(pl) * (nranks > 1 ? 2 : 1);
+        const int64_t all_b   = row_b * pl->Hq;
+        const int64_t avail   = (int64_t) free_b - store_b - ((int64_t) 3 << 30);
+        int rows = (int) std::max<int64_t>(1, ((int64_t) 256 << 20) / row_b);
+        rows     = std::min(rows, pl->Hq);
+        while (pl->Hq % rows) rows--;
+        pl->slab_rows = rows;
+        pl->cache_all = (pl->R > 1) && all_b <= avail;
+        if (pl->R == 1 && all_b <= ((int64_t) 256 << 20)) pl->slab_rows = pl->Hq;
+        const int64_t nb = pl->cache_all ? all_b : row_b * pl->slab_rows;
+        const int64_t nrows = pl->cache_all ? pl->Hq : pl->slab_rows;
+        PLCHECK(hipMalloc((void **) &pl->d_D, (size_t) nrows * pl->N * pl->N * 16));
+        if (p->qPLT) PLCHECK(hipMalloc((void **) &pl->d_P, (size_t) nrows * pl->N * pl->N * 32));
+        (void) nb;
+    }
+#undef PLCHECK
+    *out = pl;
+    return 0;
+}
+
+void zd_plan_destroy(zd_plan *pl) {
+    if (!pl) return;
+    collect_events(pl);
+    hipFree(pl->d_pk);
+    hipFree(pl->d_eig);
+    hipFree(pl->d_rowstate);
+    hipFree(pl->d_twN);
+    hipFree(pl->d_twL);
+    hipFree(pl->d_red);
+    hipFree(pl->d_D);
+    hipFree(pl->d_P);
+    delete pl;
+}
+
+int32_t zd_plan_narray(const zd_plan *pl) { return pl->narray; }
+int32_t zd_plan_stream_factor(const zd_plan *pl) { return pl->R; }
+int32_t zd_plan_record_size(const zd_plan *pl) { return pl->ec.recsize; }
+int64_t zd_plan_exchange_bytes(const zd_plan *pl) { return (int64_t) pl->S.chunk_stride * pl->nranks * 16; }
+int64_t zd_plan_local_planes(const zd_plan *pl) { return pl->Zq; }
+int64_t zd_plan_plane_z(const zd_plan *pl, int residue, int64_t local_plane) {
+    return residue + (int64_t) pl->R * ((int64_t) pl->rank * pl->Zq + local_plane);
+}
+
+int zd_plan_stage_z(zd_plan *pl, int residue, void *d_send, void *hip_stream) {
+    hipStream_t st = (hipStream_t) hip_stream;
+    if (residue < 0 || residue >= pl->R) return 1;
+    const int ky_first = pl->rank * pl->Hq;
+    for (int r0 = 0; r0 < pl->Hq; r0 += pl->slab_rows) {
+        const int nky   = std::min(pl->slab_rows, pl->Hq - r0);
+        const size_t mo = pl->cache_all ? (size_t) r0 * pl->N * pl->N : 0;
+        cplx *D   = pl->d_D + mo;
+        double *P = pl->d_P ? pl->d_P + 4 * mo : nullptr;
+        if (!(pl->cache_all && pl->cache_valid)) {
+            tick(pl, ZD_K_GEN, st, true);
+            if (zd::launch_gen(pl->g, pl->J, ky_first + r0, nky, D, P, st)) return 1;
+            tick(pl, ZD_K_GEN, st, false);
+        }
+        tick(pl, ZD_K_ZFFT, st, true);
+        if (zd::launch_zfft(pl->L, pl->g, pl->jobs, pl->S, ky_first + r0, r0, nky, residue, pl->Zq, D, P, pl->d_twN,
+                            pl->d_twL, d_send, st))
+            return 1;
+        tick(pl, ZD_K_ZFFT, st, false);
+    }
+    if (pl->cache_all) pl->cache_valid = true;
+    return 0;
+}
+
+int zd_plan_stage_y(zd_plan *pl, void *d_recv, void *hip_stream) {
+    hipStream_t st = (hipStream_t) hip_stream;
+    tick(pl, ZD_K_YFFT, st, true);
+    if (zd::launch_yfft(pl->S, pl->Zq, pl->d_twN, d_recv, st)) return 1;
+    tick(pl, ZD_K_YFFT, st, false);
+    return 0;
+}
+
+int zd_plan_stage_x(zd_plan *pl, int residue, const void *d_recv, int64_t plane0, int64_t nplanes, void *d_records,
+                    float *d_density, void *hip_stream) {
+    hipStream_t st = (hipStream_t) hip_stream;
+    if (plane0 < 0 || nplanes < 1 || plane0 + nplanes > pl->Zq) return 1;
+    const int z_first = (int) zd_plan_plane_z(pl, residue, plane0);
+    tick(pl, ZD_K_XFFT, st, true);
+    if (zd::launch_xfft(pl->S, pl->ec, pl->d_twN, d_recv, (int) plane0, (int) nplanes, z_first, pl->R, d_records,
+                        d_density, pl->d_red, st))
+        return 1;
+    tick(pl, ZD_K_XFFT, st, false);
+    return 0;
+}
+
+int zd_plan_stats(zd_plan *pl, zd_stats *out) {
+    HIPCHECK(hipDeviceSynchronize());
+    collect_events(pl);
+    zd::Reduce h;
+    HIPCHECK(hipMemcpy(&h, pl->d_red, sizeof(h), hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemset(pl->d_red, 0, sizeof(zd::Reduce)));
+    memset(out, 0, sizeof(*out));
+    double ss = 0;
+    for (int i = 0; i < zd::NSLOT; i++) ss += h.sumsq[i];
+    out->density_variance = ss;
+    for (int j = 0; j < 3; j++) {
+        double mp = 0, mn = 0;
+        for (int i = 0; i < zd::NSLOT; i++) {
+            double a, b;
+            memcpy(&a, &h.maxpos[j][i], 8);
+            memcpy(&b, &h.maxneg[j][i], 8);
+            mp = std::max(mp, a);
+            mn = std::max(mn, b);
+        }
+        // output.cpp:190-193 keeps the signed value of the largest |pos|
+        out->max_disp[j] = (mp >= mn) ? mp : -mn;
+    }
+    for (int k = 0; k < ZD_K_COUNT; k++) {
+        out->kernel_ms[k]       = pl->kernel_ms[k];
+        out->kernel_launches[k] = pl->launches[k];
+        pl->kernel_ms[k]        = 0;
+        pl->launches[k]         = 0;
+    }
+    out->bytes_intermediate = zd_plan_exchange_bytes(pl);
+    out->stream_factor      = pl->R;
+    out->modes_cached       = pl->cache_all ? 1 : 0;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+int zd_generate(const zd_params *p_in, const zd_pk *pk, const double *eig, int64_t eig_ppd, zd_slab_cb cb,
+                void *user, zd_stats *out) {
+    zd_params p = *p_in;
+    const int64_t N = p.ppd;
+    size_t free_b = 0, total_b = 0;
+    HIPCHECK(hipMemGetInfo(&free_b, &total_b));
+    if (p.stream_factor <= 0) {
+        // keep ~12% of HBM + 6 GB for tables, mode slabs, the record ring and the runtime
+        const int64_t budget = (int64_t) ((double) free_b * 0.88) - ((int64_t) 6 << 30);
+        const int R = zd_choose_stream_factor(&p, 1, budget);
+        if (R < 0) {
+            fprintf(stderr, "zeldovich_hip: PPD %lld does not fit in %.1f GB of free HBM at any stream factor\n",
+                    (long long) N, free_b / 1e9);
+            return 1;
+        }
+        p.stream_factor = R;
+    }
+    zd_plan *pl = nullptr;
+    if (zd_plan_create(&p, pk, eig, eig_ppd, 0, 1, &pl)) return 1;
+    const int R = pl->R, Zq = pl->Zq, recsize = pl->ec.recsize;
+    const bool want_rec = pl->narray >= 2, want_dens = p.qdensity != 0;
+
+    void *d_store = nullptr, *d_rec = nullptr;
+    float *d_dens = nullptr;
+    char *h_rec = nullptr;
+    float *h_dens = nullptr;
+    int rc = 1;
+    hipStream_t st = 0;
+    // planes handed over per x-stage launch
+    const int64_t plane_b = N * N * (int64_t) (want_rec ? recsize : 0) + (want_dens ? N * N * 4 : 0);
+    int chunk = (int) std::max<int64_t>(1, std::min<int64_t>(Zq, ((int64_t) 512 << 20) / std::max<int64_t>(plane_b, 1)));
+    std::chrono::steady_clock::time_point t0;
+    do {
+        if (hipMalloc(&d_store, (size_t) zd_plan_exchange_bytes(pl)) != hipSuccess) {
+            fprintf(stderr, "zeldovich_hip: cannot allocate the %.2f GB block store\n", zd_plan_exchange_bytes(pl) / 1e9);
+            break;
+        }
+        if (want_rec && hipMalloc(&d_rec, (size_t) chunk * N * N * recsize) != hipSuccess) break;
+        if (want_dens && hipMalloc((void **) &d_dens, (size_t) chunk * N * N * 4) != hipSuccess) break;
+        if (cb) {
+            if (want_rec && hipHostMalloc((void **) &h_rec, (size_t) chunk * N * N * recsize) != hipSuccess) break;
+            if (want_dens && hipHostMalloc((void **) &h_dens, (size_t) chunk * N * N * 4) != hipSuccess) break;
+        }
+        if (hipDeviceSynchronize() != hipSuccess) break;
+        t0 = std::chrono::steady_clock::now();
+        bool fail = false;
+        for (int r = 0; r < R && !fail; r++) {
+            if (p.qoneslab >= 0 && (p.qoneslab % R) != r) continue;  // zeldovich.cpp:669: only that slab is wanted
+            if (zd_plan_stage_z(pl, r, d_store, st) || zd_plan_stage_y(pl, d_store, st)) {
+                fail = true;
+                break;
+            }
+            for (int64_t pl0 = 0; pl0 < Zq && !fail; pl0 += chunk) {
+                int64_t first = pl0, n = std::min<int64_t>(chunk, Zq - pl0);
+                if (p.qoneslab >= 0) {
+                    const int64_t want = (p.qoneslab - r) / R;
+                    if (want < pl0 || want >= pl0 + n) continue;
+                    first = want;
+                    n     = 1;
+                }
+                if (zd_plan_stage_x(pl, r, d_store, first, n, d_rec, d_dens, st)) {
+                    fail = true;
+                    break;
+                }
+                if (cb) {
+                    if (want_rec && hipMemcpyAsync(h_rec, d_rec, (size_t) n * N * N * recsize, hipMemcpyDeviceToHost, st) != hipSuccess) fail = true;
+                    if (want_dens && hipMemcpyAsync(h_dens, d_dens, (size_t) n * N * N * 4, hipMemcpyDeviceToHost, st) != hipSuccess) fail = true;
+                    if (hipStreamSynchronize(st) != hipSuccess) fail = true;
+                    for (int64_t i = 0; i < n && !fail; i++) {
+                        const int64_t z = zd_plan_plane_z(pl, r, first + i);
+                        if (cb(user, z, N * N, want_rec ? h_rec + (size_t) i * N * N * recsize : nullptr,
+                               want_dens ? h_dens + (size_t) i * N * N : nullptr))
+                            fail = true;
+                    }
+                }
+            }
+        }
+        if (fail) break;
+        if (zd_plan_stats(pl, out)) break;
+        out->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        rc = 0;
+    } while (0);
+    hipFree(d_store);
+    hipFree(d_rec);
+    hipFree(d_dens);
+    if (h_rec) hipHostFree(h_rec);
+    if (h_dens) hipHostFree(h_dens);
+    zd_plan_destroy(pl);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// device test hooks
+
+static int make_test_gen(const zd_params *p, const zd_pk *pk, zd_plan **pl) {
+    zd_params q = *p;
+    q.qPLT      = 0;
+    q.stream_factor = 1;
+    return zd_plan_create(&q, pk, nullptr, 0, 0, 1, pl);
+}
+
+int zd_test_draws(int64_t seed, int64_t n, const int32_t *kxyz, uint64_t *out) {
+    // only the RNG members of GenConst are used by the draw path
+    zd_params p;
+    memset(&p, 0, sizeof(p));
+    p.ppd = 4096;  // row table covers ky < 2048
+    p.seed = seed;
+    p.boxsize = 1;
+    p.fundamental = 1;
+    p.nyquist = 1;
+    p.k_cutoff = 1;
+    p.f_cluster = 1;
+    zd_pk pk;
+    memset(&pk, 0, sizeof(pk));
+    pk.is_powerlaw = 1;
+    pk.powerlaw_index = -1;
+    pk.normalization = 1;
+    zd_plan *pl = nullptr;
+    if (make_test_gen(&p, &pk, &pl)) return 1;
+    int *d_k = nullptr;
+    uint64_t *d_o = nullptr;
+    int rc = 1;
+    do {
+        if (hipMalloc((void **) &d_k, sizeof(int) * 3 * n) != hipSuccess) break;
+        if (hipMalloc((void **) &d_o, sizeof(uint64_t) * 2 * n) != hipSuccess) break;
+        if (hipMemcpy(d_k, kxyz, sizeof(int) * 3 * n, hipMemcpyHostToDevice) != hipSuccess) break;
+        if (zd::launch_test_modes(pl->g, n, d_k, d_o, nullptr, 0)) break;
+        if (hipMemcpy(out, d_o, sizeof(uint64_t) * 2 * n, hipMemcpyDeviceToHost) != hipSuccess) break;
+        rc = 0;
+    } while (0);
+    hipFree(d_k);
+    hipFree(d_o);
+    zd_plan_destroy(pl);
+    return rc;
+}
+
+int zd_test_modes(const zd_params *p, const zd_pk *pk, int64_t n, const int32_t *kxyz, double *D) {
+    zd_plan *pl = nullptr;
+    if (make_test_gen(p, pk, &pl)) return 1;
+    int *d_k = nullptr;
+    double *d_o = nullptr;
+    int rc = 1;
+    do {
+        if (hipMalloc((void **) &d_k, sizeof(int) * 3 * n) != hipSuccess) break;
+        if (hipMalloc((void **) &d_o, sizeof(double) * 2 * n) != hipSuccess) break;
+        if (hipMemcpy(d_k, kxyz, sizeof(int) * 3 * n, hipMemcpyHostToDevice) != hipSuccess) break;
+        if (zd::launch_test_modes(pl->g, n, d_k, nullptr, d_o, 0)) break;
+        if (hipMemcpy(D, d_o, sizeof(double) * 2 * n, hipMemcpyDeviceToHost) != hipSuccess) break;
+        rc = 0;
+    } while (0);
+    hipFree(d_k);
+    hipFree(d_o);
+    zd_plan_destroy(pl);
+    return rc;
+}
+
+int zd_test_fft(int32_t n, int64_t lines, int32_t axis_kind, const double *in, double *out) {
+    const int W = zd::test_fft_tile_width(n);
+    if (W == 0 || lines % W) {
+        fprintf(stderr, "zd_test_fft: n=%d needs lines %% %d == 0\n", n, W);
+        return 1;
+    }
+    std::vector<cplx> tw = make_twiddles(n);
+    cplx *d_tw = nullptr, *d_in = nullptr, *d_out = nullptr;
+    const size_t nb = sizeof(cplx) * (size_t) n * lines;
+    int rc = 1;
+    do {
+        if (hipMalloc((void **) &d_tw, sizeof(cplx) * n) != hipSuccess) break;
+        if (hipMalloc((void **) &d_in, nb) != hipSuccess) break;
+        if (hipMalloc((void **) &d_out, nb) != hipSuccess) break;
+        if (hipMemcpy(d_tw, tw.data(), sizeof(cplx) * n, hipMemcpyHostToDevice) != hipSuccess) break;
+        if (hipMemcpy(d_in, in, nb, hipMemcpyHostToDevice) != hipSuccess) break;
+        if (zd::launch_test_fft(n, axis_kind, d_tw, d_in, d_out, lines, 0)) break;
+        if (hipDeviceSynchronize() != hipSuccess) break;
+        if (hipMemcpy(out, d_out, nb, hipMemcpyDeviceToHost) != hipSuccess) break;
+        rc = 0;
+    } while (0);
+    hipFree(d_tw);
+    hipFree(d_in);
+    hipFree(d_out);
+    return rc;
+}
+
+int zd_test_copy_bw(int64_t bytes, int32_t reps, double *gbps) {
+    void *a = nullptr, *b = nullptr;
+    int rc = 1;
+    do {
+        if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess) break;
+        hipMemset(a, 1, bytes);
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        zd::launch_copy16(a, b, bytes / 16, 0);
+        hipEventRecord(e0, 0);
+        for (int i = 0; i < reps; i++) zd::launch_copy16(a, b, bytes / 16, 0);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        *gbps = 2.0 * bytes * reps / (ms * 1e-3) / 1e9;
+        hipEventDestroy(e0);
+        hipEventDestroy(e1);
+        rc = 0;
+    } while (0);
+    hipFree(a);
+    hipFree(b);
+    return rc;
+}
+
+}  // extern "C"

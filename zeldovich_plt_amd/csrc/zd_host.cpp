@@ -1,0 +1,498 @@
+// zd_host.cpp — host-side setup that stays on the CPU, behind the C ABI of include/zeldovich_hip.h:
+//   * the parameter file reader + Parameters::setup      (src/parameters.cpp:11-197; the reference
+//     parses with the flex/bison ParseHeader library — this is a plain `key = value` reader that
+//     covers every construct used by the shipped .par files: comments, quoted strings, ints, floats
+//     with Fortran D exponents, integer vectors)
+//   * PowerSpectrum tables and normalisation             (src/power_spectrum.cpp:50-223,
+//     include/spline_function.h:77-163)
+//   * the PLT eigenmode file loader                      (src/zeldovich.cpp:794-830)
+// No GPU code here; the amplitudes produced on the device depend on these numbers to ~1e-16, so
+// the arithmetic order of the reference is kept.
+#include <algorithm>
+#include <cassert>
+#include <cctype>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <limits>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/zeldovich_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// spline (include/spline_function.h)
+
+struct Spline {
+    std::vector<double> x, y, y2;
+
+    void sort_arrays() {  // shell sort, spline_function.h:77-104 (same comparison as the source)
+        const int n = (int) x.size();
+        double *a = x.data() - 1, *b = y.data() - 1;
+        int inc = 1;
+        do {
+            inc *= 3;
+            inc++;
+        } while (inc <= n);
+        do {
+            inc /= 3;
+            for (int i = inc + 1; i <= n; i++) {
+                const double v = a[i], w = b[i];
+                int j = i;
+                while (x[j - inc] > v) {
+                    a[j] = a[j - inc];
+                    b[j] = b[j - inc];
+                    j -= inc;
+                    if (j <= inc) break;
+                }
+                a[j] = v;
+                b[j] = w;
+            }
+        } while (inc > 1);
+    }
+    void build() {  // natural cubic spline, spline_function.h:106-139
+        const int n = (int) x.size();
+        y2.assign(n, 0.0);
+        std::vector<double> u(n, 0.0);
+        sort_arrays();
+        for (int i = 1; i <= n - 2; i++) {
+            const double sig = (x[i] - x[i - 1]) / (x[i + 1] - x[i - 1]);
+            const double p   = sig * y2[i - 1] + 2.0;
+            y2[i]            = (sig - 1.0) / p;
+            u[i] = (y[i + 1] - y[i]) / (x[i + 1] - x[i]) - (y[i] - y[i - 1]) / (x[i] - x[i - 1]);
+            u[i] = (6.0 * u[i] / (x[i + 1] - x[i - 1]) - sig * u[i - 1]) / p;
+        }
+        const double qn = 0.0, un = 0.0;
+        y2[n - 1] = (un - qn * u[n - 2]) / (qn * y2[n - 2] + 1.0);
+        for (int k = n - 2; k >= 0; k--) y2[k] = y2[k] * y2[k + 1] + u[k];
+    }
+};
+
+double spline_val(int n, const double *x, const double *y, const double *y2, double v) {
+    int klo = 0, khi = n - 1;
+    while (khi - klo > 1) {
+        const int k = (khi + klo) >> 1;
+        if (x[k] > v)
+            khi = k;
+        else
+            klo = k;
+    }
+    const double h = x[khi] - x[klo];
+    const double a = (x[khi] - v) / h, b = (v - x[klo]) / h;
+    return a * y[klo] + b * y[khi] + ((a * a * a - a) * y2[klo] + (b * b * b - b) * y2[khi]) * (h * h) / 6.0;
+}
+
+double pk_power(const zd_pk *pk, double k) {  // power_spectrum.cpp:225-261
+    if (k <= 0.0) return 0.0;
+    if (pk->is_powerlaw) return std::pow(k, pk->powerlaw_index) * std::exp(-k * k * pk->Pk_smooth2) * pk->normalization;
+    static bool already_warned = false;
+    if (k > pk->kmax && !already_warned) {
+        fprintf(stderr,
+                "\n*** WARNING: power spectrum spline interpolation was requested\n"
+                "past the maximum k (%f) that was provided in the input power\n"
+                "spectrum file.  The extrapolation should be well-behaved, but\n"
+                "make sure that this was expected.  Provide a power spectrum\n"
+                "that goes to at least k=10 (or higher if your k_Nyquist demands\n"
+                "it) to get rid of this warning.\n\n",
+                pk->kmax);
+        already_warned = true;
+    }
+    return std::exp(spline_val(pk->n, pk->x, pk->y, pk->y2, std::log(k)) - k * k * pk->Pk_smooth2) * pk->normalization;
+}
+
+double sigmaR_integrand(const zd_pk *pk, double Rnorm, double k) {  // power_spectrum.cpp:50-58
+    const double x = k * Rnorm;
+    double w;
+    if (x <= 1e-3)
+        w = 1 - x * x / 10.0;
+    else
+        w = 3.0 * (std::sin(x) - x * std::cos(x)) / x / x / x;
+    return 0.5 / M_PI / M_PI * k * k * w * w * pk_power(pk, k);
+}
+
+// Romberg with up to 32 bisections (power_spectrum.cpp:93-128); midpoint sums in k order
+double romberg(const zd_pk *pk, double Rnorm, double a, double b, double prec, double *obtprec) {
+    constexpr int MAXITER = 32;
+    static thread_local double TT[MAXITER + 1][MAXITER + 1];
+    double h = 0.5 * (b - a);
+    TT[0][1] = h * (sigmaR_integrand(pk, Rnorm, a) + sigmaR_integrand(pk, Rnorm, b));
+    int jj   = 0;
+    do {
+        jj++;
+        double s = 0;
+        for (uint64_t k = 1; k <= (1ULL << (jj - 1)); k++) s += sigmaR_integrand(pk, Rnorm, a + (2 * k - 1) * h);
+        TT[jj][1] = 0.5 * TT[jj - 1][1] + h * s;
+        double fourtokm1 = 1;
+        for (int k = 2; k <= jj; k++) {
+            fourtokm1 *= 4;
+            TT[jj][k] = TT[jj][k - 1] + (TT[jj][k - 1] - TT[jj - 1][k - 1]) / (fourtokm1 - 1);
+        }
+        h *= 0.5;
+        if (jj > 1 && std::fabs(TT[jj][jj] - TT[jj - 1][jj - 1]) < prec * std::fabs(TT[jj][jj])) break;
+    } while (jj < MAXITER);
+    *obtprec = (TT[jj][jj] - TT[jj - 1][jj - 1]) / TT[jj][jj];
+    return TT[jj][jj];
+}
+
+double pk_sigmaR(const zd_pk *pk, double R) {  // power_spectrum.cpp:60-89
+    if (!pk->is_powerlaw) {
+        const double target_prec = 1e-6;
+        double precision         = 1.0;
+        const double retval      = std::sqrt(romberg(pk, R, 0, 10.0, target_prec, &precision));
+        if (precision > target_prec) {
+            fprintf(stderr,
+                    "Error: actual Romberg integration precision (%g) is greater than the target precision (%g); halting.\n",
+                    precision, target_prec);
+            exit(1);
+        }
+        return retval;
+    }
+    const double n = pk->powerlaw_index;
+    double retval  = 9 * std::pow(R, -n - 3) / (2 * M_PI * std::sqrt(M_PI)) * std::tgamma((3 + n) / 2.)
+                    / (std::tgamma((2 - n) / 2.) * (n - 3) * (n - 1));
+    return std::sqrt(retval * pk->normalization);
+}
+
+}  // namespace
+
+struct zd_pk_handle {
+    Spline sp;
+};
+
+static void normalize(zd_pk *pk, double Pk_norm, double Pk_sigma, double Pk_sigma_ratio, double Pk_smooth,
+                      int fix_to_mean, double boxsize) {  // power_spectrum.cpp:186-223
+    pk->Pk_smooth2    = 0.0;
+    pk->normalization = 1.0;
+    if (Pk_norm > 0.0) {
+        fprintf(stderr, "Input sigma(%f) = %.6g\n", Pk_norm, pk_sigmaR(pk, Pk_norm));
+        if (Pk_sigma > 0) {
+            pk->normalization = Pk_sigma / pk_sigmaR(pk, Pk_norm);
+            pk->normalization *= pk->normalization;
+        } else if (Pk_sigma_ratio > 0) {
+            pk->normalization = Pk_sigma_ratio * Pk_sigma_ratio;
+        } else {
+            assert(Pk_sigma > 0 || Pk_sigma_ratio > 0);
+        }
+        fprintf(stderr, "Final sigma(%f) = %.6g\n", Pk_norm, pk_sigmaR(pk, Pk_norm));
+    }
+    pk->normalization /= boxsize * boxsize * boxsize;
+    pk->Pk_smooth2  = Pk_smooth * Pk_smooth;
+    pk->fixed_power = fix_to_mean;
+    if (pk->fixed_power) fprintf(stderr, "Fixing density mode amplitudes to sqrt(P(k))\n");
+}
+
+extern "C" {
+
+int zd_pk_create_from_file(const char *path, double Pk_scale, double Pk_norm, double Pk_sigma,
+                           double Pk_sigma_ratio, double Pk_smooth, int fix_to_mean, double boxsize,
+                           zd_pk_handle **hout, zd_pk *pk) {  // power_spectrum.cpp:130-171
+    fprintf(stderr, "Loading power spectrum from file \"%s\"\n", path);
+    FILE *fp = fopen(path, "r");
+    if (fp == NULL) {
+        fprintf(stderr, "Power spectrum file \"%s\" not found; exiting.\n", path);
+        return 1;
+    }
+    zd_pk_handle *h = new zd_pk_handle;
+    double kmin = std::numeric_limits<double>::max(), kmax = std::numeric_limits<double>::min();
+    char line[200];
+    double k = 0, P = 0;
+    while (fgets(line, 200, fp) != NULL) {
+        if (line[0] == '#') continue;
+        sscanf(line, "%lf %lf", &k, &P);
+        if (k < 0.0) continue;
+        if (P < 0.0) continue;
+        double ks = k * Pk_scale;
+        if (ks > 0.0) {
+            h->sp.x.push_back(std::log(ks));
+            h->sp.y.push_back(std::log(P));
+            kmin = std::min(ks, kmin);
+        } else {
+            h->sp.x.push_back(-1e3);
+            h->sp.y.push_back(std::log(P));
+        }
+        kmax = std::max(ks, kmax);
+    }
+    fclose(fp);
+    if (h->sp.x.size() < 3) {
+        fprintf(stderr, "Power spectrum file \"%s\" has fewer than 3 usable rows.\n", path);
+        delete h;
+        return 1;
+    }
+    h->sp.build();
+    memset(pk, 0, sizeof(*pk));
+    pk->n  = (int) h->sp.x.size();
+    pk->x  = h->sp.x.data();
+    pk->y  = h->sp.y.data();
+    pk->y2 = h->sp.y2.data();
+    pk->kmax           = kmax;
+    pk->powerlaw_index = 1000;
+    normalize(pk, Pk_norm, Pk_sigma, Pk_sigma_ratio, Pk_smooth, fix_to_mean, boxsize);
+    *hout = h;
+    return 0;
+}
+
+int zd_pk_create_powerlaw(double index, double Pk_norm, double Pk_sigma, double Pk_sigma_ratio, double Pk_smooth,
+                          int fix_to_mean, double boxsize, zd_pk_handle **hout, zd_pk *pk) {  // :173-184
+    if (index == 1000) return 1;
+    fprintf(stderr, "Initializing power spectrum with power law index %g\n", index);
+    zd_pk_handle *h = new zd_pk_handle;
+    memset(pk, 0, sizeof(*pk));
+    pk->powerlaw_index = index;
+    pk->is_powerlaw    = 1;
+    pk->kmax           = std::numeric_limits<double>::min();
+    normalize(pk, Pk_norm, Pk_sigma, Pk_sigma_ratio, Pk_smooth, fix_to_mean, boxsize);
+    *hout = h;
+    return 0;
+}
+
+double zd_pk_power(const zd_pk *pk, double k) { return pk_power(pk, k); }
+double zd_pk_sigmaR(const zd_pk *pk, double R) { return pk_sigmaR(pk, R); }
+void zd_pk_destroy(zd_pk_handle *h) { delete h; }
+
+// load_eigmodes: int32 ppd + ppd*ppd*(ppd/2+1)*4 doubles  (zeldovich.cpp:794-830)
+int zd_load_eigmodes(const char *path, double **eig, int64_t *eig_ppd) {
+    fprintf(stderr, "Using PLT eigenmodes.\n");
+    std::ifstream f(path, std::ios::in | std::ios::binary | std::ios::ate);
+    if (!f) {
+        fprintf(stderr, "[Error] Could not open eigenmode file \"%s\".\n", path);
+        return 1;
+    }
+    const std::streampos size = f.tellg();
+    f.seekg(0, std::ios::beg);
+    int32_t ppd32 = 0;
+    f.read((char *) &ppd32, sizeof(ppd32));
+    const int64_t ep    = ppd32;
+    const size_t nelem  = (size_t) ep * ep * (ep / 2 + 1) * 4;
+    const size_t nbytes = nelem * sizeof(double);
+    if ((size_t) size != nbytes + sizeof(ppd32)) {
+        fprintf(stderr, "[Error] Eigenmode file \"%s\" of size %lld did not match expected size %zu from eig_vecs_ppd %lld.\n",
+                path, (long long) size, nbytes, (long long) ep);
+        return 1;
+    }
+    double *buf = NULL;
+    if (posix_memalign((void **) &buf, 4096, nbytes) != 0) return 1;
+    f.read((char *) buf, nbytes);
+    *eig     = buf;
+    *eig_ppd = ep;
+    return 0;
+}
+void zd_free(void *p) { free(p); }
+
+// ---------------------------------------------------------------------------------------------
+// parameter file
+
+static std::string trim(const std::string &s) {
+    size_t a = 0, b = s.size();
+    while (a < b && isspace((unsigned char) s[a])) a++;
+    while (b > a && isspace((unsigned char) s[b - 1])) b--;
+    return s.substr(a, b - a);
+}
+static std::string unquote(const std::string &s) {
+    std::string t = trim(s);
+    if (t.size() >= 2 && ((t.front() == '"' && t.back() == '"') || (t.front() == '\'' && t.back() == '\'')))
+        return t.substr(1, t.size() - 2);
+    return t;
+}
+static double to_double(std::string s) {
+    for (auto &c : s)
+        if (c == 'D' || c == 'd') c = 'e';  // Fortran exponents (phScanner.ll)
+    return strtod(s.c_str(), NULL);
+}
+
+int zd_params_from_file(const char *path, zd_params *p, zd_param_strings *s) {
+    std::ifstream in(path);
+    if (!in) {
+        fprintf(stderr, "Could not open parameter file \"%s\"\n", path);
+        return 1;
+    }
+    std::map<std::string, std::string> kv;
+    std::string line;
+    bool in_block_comment = false;
+    while (std::getline(in, line)) {
+        if (!line.empty() && line[0] == '\x02') break;  // ^B ends the header (ParseHeader convention)
+        std::string t = trim(line);
+        if (t.rfind("##", 0) == 0) {  // `##` toggles a block comment
+            in_block_comment = !in_block_comment;
+            continue;
+        }
+        if (in_block_comment) continue;
+        // strip `#` comments outside quotes
+        bool q = false;
+        size_t cut = std::string::npos;
+        for (size_t i = 0; i < line.size(); i++) {
+            if (line[i] == '"') q = !q;
+            if (line[i] == '#' && !q) {
+                cut = i;
+                break;
+            }
+        }
+        if (cut != std::string::npos) line = line.substr(0, cut);
+        const size_t eq = line.find('=');
+        if (eq == std::string::npos) continue;
+        const std::string key = trim(line.substr(0, eq));
+        if (key.empty()) continue;
+        kv[key] = trim(line.substr(eq + 1));
+    }
+
+    // defaults: src/parameters.cpp:13-44
+    memset(p, 0, sizeof(*p));
+    memset(s, 0, sizeof(*s));
+    p->numblock = 2;
+    p->qoneslab = -1;
+    p->f_cluster = 1;
+    p->k_cutoff  = 1.;
+    s->Pk_scale  = 1;
+    s->Pk_powerlaw_index = 1000;
+    strcpy(s->density_filename, "density{:d}");
+    s->version = -1;
+    s->n_s     = 1;
+    s->Omega_M = 1.0;
+    int cpd = 0;
+    bool have_cpd = false;
+
+    auto has = [&](const char *k) { return kv.find(k) != kv.end(); };
+    auto must = [&](const char *k) {
+        if (!has(k)) {
+            fprintf(stderr, "Parameter \"%s\" must be defined in \"%s\"\n", k, path);
+            return false;
+        }
+        return true;
+    };
+    // MUST_DEFINE keys: src/parameters.cpp:61-95
+    const char *required[] = {"BoxSize", "ZD_Pk_scale", "NP", "ZD_NumBlock", "CPD", "ZD_Seed", "ZD_Pk_norm",
+                              "ZD_Pk_smooth", "InitialConditionsDirectory", "InitialRedshift", "ICFormat"};
+    for (const char *k : required)
+        if (!must(k)) return 1;
+
+    auto D = [&](const char *k, double &v) { if (has(k)) v = to_double(kv[k]); };
+    auto I = [&](const char *k, int32_t &v) { if (has(k)) v = (int32_t) strtol(kv[k].c_str(), NULL, 0); };
+    auto S = [&](const char *k, char *dst, size_t cap) {
+        if (has(k)) {
+            std::string v = unquote(kv[k]);
+            strncpy(dst, v.c_str(), cap - 1);
+        }
+    };
+    D("BoxSize", p->boxsize);
+    D("ZD_Pk_scale", s->Pk_scale);
+    if (has("NP")) s->np = (int64_t) llround(to_double(kv["NP"]));
+    I("ZD_NumBlock", p->numblock);
+    if (has("CPD")) {
+        cpd      = (int) strtol(kv["CPD"].c_str(), NULL, 0);
+        have_cpd = true;
+    }
+    I("ZD_qdensity", p->qdensity);
+    I("ZD_qoneslab", p->qoneslab);
+    int32_t seed32 = 0;
+    I("ZD_Seed", seed32);
+    D("ZD_Pk_norm", s->Pk_norm);
+    D("ZD_Pk_sigma", s->Pk_sigma);
+    D("ZD_Pk_sigma_ratio", s->Pk_sigma_ratio);
+    D("ZD_f_cluster", p->f_cluster);
+    D("ZD_Pk_smooth", s->Pk_smooth);
+    I("ZD_qPk_fix_to_mean", s->qPk_fix_to_mean);
+    S("ZD_Pk_filename", s->Pk_filename, sizeof(s->Pk_filename));
+    D("ZD_Pk_powerlaw_index", s->Pk_powerlaw_index);
+    S("InitialConditionsDirectory", s->output_dir, sizeof(s->output_dir));
+    S("ZD_density_filename", s->density_filename, sizeof(s->density_filename));
+    D("InitialRedshift", p->z_initial);
+    I("ZD_qonemode", p->qonemode);
+    if (has("ZD_one_mode")) {
+        std::stringstream ss(kv["ZD_one_mode"]);
+        std::string tok;
+        int i = 0;
+        while (i < 3 && ss >> tok) {
+            while (!tok.empty() && (tok.back() == ',')) tok.pop_back();
+            p->one_mode[i++] = (int32_t) strtol(tok.c_str(), NULL, 0);
+        }
+    }
+    I("ZD_qPLT", p->qPLT);
+    S("ZD_PLT_filename", s->PLT_filename, sizeof(s->PLT_filename));
+    I("ZD_qPLT_rescale", p->qPLTrescale);
+    D("ZD_PLT_target_z", p->PLT_target_z);
+    D("ZD_k_cutoff", p->k_cutoff);
+    D("ZD_f_NL", s->f_NL);
+    D("ZD_n_s", s->n_s);
+    D("Omega_M", s->Omega_M);
+    S("ICFormat", s->ICFormat, sizeof(s->ICFormat));
+    I("ZD_Version", s->version);
+    I("ZD_CornerModes", p->corner_modes);
+    // optional MI355X knobs (not in the reference; reference .par files run unchanged)
+    I("ZD_StreamFactor", p->stream_factor);
+    (void) have_cpd;
+    p->cpd = cpd;
+
+    // ---- Parameters::setup: src/parameters.cpp:97-197 ----
+    if (s->version == -1) {
+        fprintf(stderr,
+                "\n*** ERROR: ZD_Version was not specified for zeldovich-PLT.  New ICs should\n"
+                "    specify ZD_Version = 2; legacy ICs (pre-November 2019) should use\n"
+                "    ZD_Version = 1 to reproduce the old phases.  Please specify one of\n"
+                "    these in the parameter file.\n");
+        return 1;
+    }
+    if (s->version != 2) {
+        fprintf(stderr, "zeldovich (MI355X): only ZD_Version = 2 is supported (ZD_Version = 1 needs GSL mt19937 streams).\n");
+        return 1;
+    }
+    p->ppd = (int64_t) llround(cbrt((double) s->np));
+    fprintf(stderr, "Generating ICs for ppd = %lld\n", (long long) p->ppd);
+#define ZD_REQUIRE(cond)                                                             \
+    if (!(cond)) {                                                                   \
+        fprintf(stderr, "Invalid Parameters given: assertion `%s' failed\n", #cond); \
+        return 1;                                                                    \
+    }
+    ZD_REQUIRE(p->ppd * p->ppd * p->ppd == s->np);
+    ZD_REQUIRE(p->ppd <= ZD_MAX_PPD);
+    ZD_REQUIRE(!(p->boxsize <= 0.0));
+    ZD_REQUIRE(!(p->ppd <= 0));
+    ZD_REQUIRE(!(p->numblock <= 0));
+    ZD_REQUIRE(!(s->Pk_scale <= 0.0));
+    ZD_REQUIRE(!(s->Pk_norm < 0.0));
+    if ((bool) (s->Pk_sigma > 0) == (bool) (s->Pk_sigma_ratio > 0)) {
+        fprintf(stderr, "Must specify exactly one of Pk_sigma or Pk_sigma_ratio!\n");
+        return 1;
+    }
+    ZD_REQUIRE(p->f_cluster > 0. && p->f_cluster <= 1.);
+    ZD_REQUIRE((s->Pk_filename[0] != 0) != (bool) (s->Pk_powerlaw_index != 1000));
+    if (s->Pk_powerlaw_index != 1000) ZD_REQUIRE(s->Pk_powerlaw_index <= 0);
+    if (p->qPLT) ZD_REQUIRE(s->PLT_filename[0] != 0);
+    ZD_REQUIRE(p->k_cutoff >= 1);
+    if (p->qPLT) ZD_REQUIRE(strncmp(s->ICFormat, "RV", 2) == 0);
+    if (s->f_NL != 0.) {
+        fprintf(stderr, "zeldovich (MI355X): ZD_f_NL != 0 (local primordial non-Gaussianity) is not supported yet.\n");
+        return 1;
+    }
+    // block geometry asserts of BlockArray (src/block_array.cpp:38-40) — kept so that reference
+    // parameter files are rejected in the same situations
+    ZD_REQUIRE(p->ppd % 2 == 0);
+    ZD_REQUIRE(p->numblock % 2 == 0);
+    ZD_REQUIRE(p->ppd % p->numblock == 0);
+#undef ZD_REQUIRE
+    const double separation = p->boxsize / p->ppd;
+    p->nyquist     = M_PI / separation;
+    p->fundamental = 2.0 * M_PI / p->boxsize;
+    p->seed        = (int64_t) seed32;  // int -> unsigned long sign-extends (power_spectrum.cpp:14)
+    if (p->qonemode) fprintf(stderr, "one_mode: %d, %d, %d\n", p->one_mode[0], p->one_mode[1], p->one_mode[2]);
+
+    if (!strcmp(s->ICFormat, "RVdoubleZel"))
+        p->icformat = ZD_FMT_RVDOUBLEZEL;
+    else if (!strcmp(s->ICFormat, "RVZel"))
+        p->icformat = ZD_FMT_RVZEL;
+    else if (!strcmp(s->ICFormat, "Zeldovich"))
+        p->icformat = ZD_FMT_ZEL;
+    else if (!strcmp(s->ICFormat, "ZelSimple"))
+        p->icformat = ZD_FMT_ZELSIMPLE;
+    else if (p->qdensity != 2) {
+        fprintf(stderr, "Error: unknown ICFormat \"%s\". Aborting.\n", s->ICFormat);  // output.cpp:272-277
+        return 1;
+    }
+    return 0;
+}
+
+}  // extern "C"

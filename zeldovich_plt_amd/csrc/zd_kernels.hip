@@ -1,0 +1,808 @@
+// zd_kernels.hip — the four gfx950 kernels of the grid->displacements path and their launchers.
+//
+//   k_gen    : Gaussian modes  D(k) = sqrt(-P(k) ln R) e^{2 pi i theta}  (+ PLT factors)
+//              replaces the (z,x) loop of LoadPlane, src/zeldovich.cpp:333-438, cgauss<2>
+//              (src/power_spectrum.cpp:338-359) and get_eigenmode (src/zeldovich.cpp:229-276)
+//   k_zfft   : Hermitian packing + (folded) z FFT, replaces zeldovich.cpp:447-511 and StoreBlock
+//   k_yfft   : y FFT in place on the block store, replaces LoadBlock + half of Inverse2dFFT
+//   k_xfft   : x FFT + particle epilogue, replaces the rest of Inverse2dFFT + WriteParticlesSlab
+//              (src/output.cpp:86-203)
+// HBM-bound design notes are in DESIGN.md; LDS/register structure of the FFT in zd_fft.h.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "zd_device.h"
+#include "zd_launch.h"
+
+using namespace zd;
+using zdfft::cplx;
+using zdpcg::u128;
+
+__constant__ zdpcg::BitTable c_bits;
+
+extern "C" int zdk_upload_bit_table(const zdpcg::BitTable *host) {
+    return (int) hipMemcpyToSymbol(HIP_SYMBOL(c_bits), host, sizeof(zdpcg::BitTable));
+}
+
+// ------------------------------------------------------------------------------------------------
+// device math for one mode
+
+__device__ __forceinline__ u128 advance_bits(u128 s, uint64_t delta) {
+    for (int i = 0; i < zdpcg::NBITS; i++) {
+        if ((delta >> i) == 0) break;
+        if ((delta >> i) & 1ULL) s = zdpcg::apply(c_bits.m[i], s);
+    }
+    return s;
+}
+
+// PowerSpectrum::power (src/power_spectrum.cpp:225-261) with SplineFunction::val
+// (include/spline_function.h:141-163)
+__device__ __forceinline__ double pk_power(const GenConst &g, double k) {
+    if (k <= 0.0) return 0.0;
+    if (g.is_powerlaw) return pow(k, g.powerlaw_index) * exp(-k * k * g.pk_smooth2) * g.pk_norm;
+    const double v = log(k);
+    int klo = 0, khi = g.pk_n - 1;
+    while (khi - klo > 1) {
+        const int m = (khi + klo) >> 1;
+        if (g.pk_x[m] > v)
+            khi = m;
+        else
+            klo = m;
+    }
+    const double xl = g.pk_x[klo], xh = g.pk_x[khi];
+    const double h = xh - xl;
+    const double a = (xh - v) / h, b = (v - xl) / h;
+    const double val = a * g.pk_y[klo] + b * g.pk_y[khi]
+                       + ((a * a * a - a) * g.pk_y2[klo] + (b * b * b - b) * g.pk_y2[khi]) * (h * h) / 6.0;
+    return exp(val - k * k * g.pk_smooth2) * g.pk_norm;
+}
+
+// zero rule of LoadPlane (src/zeldovich.cpp:350-356)
+__device__ __forceinline__ bool mode_is_zero(const GenConst &g, int kx, int ky, int kz, double k2) {
+    const int ax = kx < 0 ? -kx : kx, ay = ky < 0 ? -ky : ky, az = kz < 0 ? -kz : kz;
+    if (ax == g.kmax || az == g.kmax || ay == g.kmax) return true;
+    if (!g.corner_modes && k2 >= g.k2_cutoff) return true;
+    if (g.qonemode && !(kx == g.one_mode[0] && ky == g.one_mode[1] && kz == g.one_mode[2])) return true;
+    return false;
+}
+
+// cgauss<2> given the two raw draws
+__device__ __forceinline__ void gauss_mode(const GenConst &g, double kmag, uint64_t r1, uint64_t r2,
+                                           double &dr, double &di) {
+    const double Pk = pk_power(g, kmag);
+    double R        = zdpcg::u01(r1);
+    double theta    = zdpcg::u01(r2);
+    if (!g.fixed_power)
+        R = sqrt(-Pk * log(R));
+    else
+        R = sqrt(Pk);
+    theta = (2 * 3.14159265358979323846) * theta;
+    double s, c;
+    sincos(theta, &s, &c);
+    dr = R * c;
+    di = R * s;
+}
+
+// interp_eigmode + get_eigenmode (src/zeldovich.cpp:154-276); out = e_x,e_y,e_z (weighted), lambda
+__device__ void get_eigenmode_dev(const GenConst &g, int kx, int ky, int kz, double (&out)[4]) {
+    const long long N = g.N, ep = g.eig_ppd;
+    const long long halfppd = ep / 2 + 1, ppdhalf = ep / 2;
+    const int ikx = kx < 0 ? (int) N + kx : kx;
+    const int iky = ky < 0 ? (int) N + ky : ky;
+    int ikz       = kz < 0 ? (int) N + kz : kz;
+    ikz           = ikz > N / 2 ? (int) N - ikz : ikz;
+    const double k2 = (double) (kx * kx + ky * ky + kz * kz);
+    double eh[4];
+    const double *E = g.eig;
+#define ZD_EIG(_x, _y, _z, _i) E[((long long) (_x) * ep + (_y)) * halfppd * 4 + (long long) (_z) * 4 + (_i)]
+    if (ep % N == 0) {
+        const long long sx = ikx * ep / N, sy = iky * ep / N, sz = ikz * ep / N;
+#pragma unroll
+        for (int i = 0; i < 4; i++) eh[i] = ZD_EIG(sx, sy, sz, i);
+    } else {
+        double fx = ((double) ep) / N * ikx, fy = ((double) ep) / N * iky, fz = ((double) ep) / N * ikz;
+        if (fx > ppdhalf && fx < halfppd) fx = floor(fx + 1);
+        if (fy > ppdhalf && fy < halfppd) fy = floor(fy + 1);
+        if (fz > ppdhalf && fz < halfppd) fz = floor(fz + 1);
+        int xl = (int) fx, xh = xl + 1, yl = (int) fy, yh = yl + 1, zl = (int) fz, zh = zl + 1;
+        if (xh == ep) xh = 0;
+        if (yh == ep) yh = 0;
+        if (zh == ep) zh = 0;
+        fx -= xl;
+        fy -= yl;
+        fz -= zl;
+        double f[8];
+        f[0] = (1 - fx) * (1 - fy) * (1 - fz);
+        f[1] = (1 - fx) * (1 - fy) * (fz);
+        f[2] = (1 - fx) * (fy) * (1 - fz);
+        f[3] = (1 - fx) * (fy) * (fz);
+        f[4] = (fx) * (1 - fy) * (1 - fz);
+        f[5] = (fx) * (1 - fy) * (fz);
+        f[6] = (fx) * (fy) * (1 - fz);
+        f[7] = (fx) * (fy) * (fz);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            double acc = f[0] * ZD_EIG(xl, yl, zl, i);
+            acc += f[1] * (f[1] != 0 ? ZD_EIG(xl, yl, zh, i) : 0.0);
+            acc += f[2] * (f[2] != 0 ? ZD_EIG(xl, yh, zl, i) : 0.0);
+            acc += f[3] * (f[3] != 0 ? ZD_EIG(xl, yh, zh, i) : 0.0);
+            acc += f[4] * (f[4] != 0 ? ZD_EIG(xh, yl, zl, i) : 0.0);
+            acc += f[5] * (f[5] != 0 ? ZD_EIG(xh, yl, zh, i) : 0.0);
+            acc += f[6] * (f[6] != 0 ? ZD_EIG(xh, yh, zl, i) : 0.0);
+            acc += f[7] * (f[7] != 0 ? ZD_EIG(xh, yh, zh, i) : 0.0);
+            eh[i] = acc;
+        }
+    }
+#undef ZD_EIG
+    eh[2] *= (kz < 0 ? -1.0 : 1.0);  // copysign(1, kz) for an int: kz = 0 -> +1
+    const double mag = sqrt(eh[0] * eh[0] + eh[1] * eh[1] + eh[2] * eh[2]);
+    eh[0] /= mag;
+    eh[1] /= mag;
+    eh[2] /= mag;
+    double norm = k2 / (kx * eh[0] + ky * eh[1] + kz * eh[2]);
+    if (k2 == 0.0 || !isfinite(norm)) norm = 0.0;
+    out[0] = norm * eh[0];
+    out[1] = norm * eh[1];
+    out[2] = norm * eh[2];
+    out[3] = eh[3];
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_gen: one thread owns one x and walks ZR consecutive z rows (RNG stride = one affine map).
+//   Dbuf[(kyl*N + z)*N + x]      complex amplitude D(k)          (kyl = ky - ky0)
+//   Pbuf[((kyl*N + z)*N + x)*4]  PLT only: s_x, s_y, s_z, f   with F_j = i s_j D
+// grid: (N/GEN_BX, N/ZR, nky)  block: GEN_BX
+template <int ZR>
+__global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, int ky0, cplx *__restrict__ Dbuf,
+                                                double *__restrict__ Pbuf) {
+    const int N = g.N, half = g.half;
+    const int x  = blockIdx.x * GEN_BX + threadIdx.x;
+    const int z0 = blockIdx.y * ZR;
+    const int ky = ky0 + blockIdx.z;
+    if (x >= N) return;
+    const int kx = x > half ? x - N : x;
+    // state one step ahead of the first mode's counter
+    u128 s;
+    {
+        const int kz0 = z0 > half ? z0 - N : z0;
+        const uint64_t off = 2ULL * ((uint64_t) (kz0 & 65535) * 65536ULL + (uint64_t) (kx & 65535)) + 1ULL;
+        s = advance_bits(g.row_state[ky], off);
+    }
+    const long long rowbase = ((long long) blockIdx.z * N) * N;
+#pragma unroll 1
+    for (int zi = 0; zi < ZR; zi++) {
+        const int z  = z0 + zi;
+        const int kz = z > half ? z - N : z;
+        const uint64_t r1 = zdpcg::output(s);
+        const u128 s2     = zdpcg::step(s);
+        const uint64_t r2 = zdpcg::output(s2);
+        s = zdpcg::apply(z == half ? J.jzw : J.jz, s2);
+
+        const int k2i = kx * kx + ky * ky + kz * kz;
+        double k2     = (double) k2i * g.fundamental2;
+        double dr = 0.0, di = 0.0;
+        if (!mode_is_zero(g, kx, ky, kz, k2)) gauss_mode(g, sqrt(k2), r1, r2, dr, di);
+        const long long idx = rowbase + (long long) z * N + x;
+        Dbuf[idx] = cplx{dr, di};
+        if (g.qPLT) {
+            double sx = 0, sy = 0, sz = 0, f = 0;
+            if (dr != 0.0 || di != 0.0) {
+                double e[4];
+                get_eigenmode_dev(g, kx, ky, kz, e);
+                if (k2 == 0.0) k2 = 1.0;
+                const double ik2 = 1.0 / k2;
+                f = (sqrt(1. + 24 * e[3] * g.f_cluster) - 1) * .25;
+                double rescale = 1.0;
+                if (g.qPLTrescale) rescale = exp(g.ln_growth_ratio * (g.target_f - f));
+                sx = rescale * e[0] * g.fundamental * ik2;
+                sy = rescale * e[1] * g.fundamental * ik2;
+                sz = rescale * e[2] * g.fundamental * ik2;
+            }
+            double4 pv;
+            pv.x = sx;
+            pv.y = sy;
+            pv.z = sz;
+            pv.w = f;
+            reinterpret_cast<double4 *>(Pbuf)[idx] = pv;
+        }
+    }
+}
+
+// test hook: raw draws / amplitudes for an explicit mode list (counter addressing, no walk)
+__global__ void k_test_modes(GenConst g, long long n, const int *__restrict__ kxyz, uint64_t *__restrict__ draws,
+                             double *__restrict__ D) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int kx = kxyz[3 * i], ky = kxyz[3 * i + 1], kz = kxyz[3 * i + 2];
+    const uint64_t off = 2ULL * ((uint64_t) (kz & 65535) * 65536ULL + (uint64_t) (kx & 65535));
+    u128 s = advance_bits(g.row_state[ky], off);
+    s = zdpcg::step(s);
+    const uint64_t r1 = zdpcg::output(s);
+    s = zdpcg::step(s);
+    const uint64_t r2 = zdpcg::output(s);
+    if (draws) {
+        draws[2 * i]     = r1;
+        draws[2 * i + 1] = r2;
+    }
+    if (D) {
+        const double k2 = (double) (kx * kx + ky * ky + kz * kz) * g.fundamental2;
+        double dr = 0, di = 0;
+        if (!mode_is_zero(g, kx, ky, kz, k2)) gauss_mode(g, sqrt(k2), r1, r2, dr, di);
+        D[2 * i]     = dr;
+        D[2 * i + 1] = di;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_zfft: for half-space row ky and a W-wide column tile, build the FFT input of one job from the
+// mode amplitudes (Hermitian bookkeeping done algebraically: each output column of each packed
+// array is ONE complex FFT of c(k)*D(k)), fold the R = N/L residues, transform, store.
+//   grid: (N/W, nky, njobs)   block: W*L/E
+template <int L, int E, int W>
+__global__ __launch_bounds__(W *L / E) void k_zfft(GenConst g, JobList jobs, StoreLayout S, int ky0, int kyloc0,
+                                                  int residue, int Zq, const cplx *__restrict__ Dbuf,
+                                                  const double *__restrict__ Pbuf,
+                                                  const cplx *__restrict__ twN, const cplx *__restrict__ twL,
+                                                  cplx *__restrict__ out) {
+    using PL  = zdfft::Plan<L, E>;
+    using LDS = zdfft::ColsInner<L, W>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int T = PL::T;
+    const int N = g.N, half = g.half, R = N / L;
+    const int w = threadIdx.x % W, t = threadIdx.x / W;
+    const int x   = blockIdx.x * W + w;
+    const int kyl = blockIdx.y;  // row inside the generated slab
+    const int ky  = ky0 + kyl;
+    const int kind = jobs.kind[blockIdx.z];
+    const bool twin_only = (kind == JOB_A_TWIN || kind == JOB_B_TWIN || kind == JOB_D_TWIN);
+    if (ky == 0 && twin_only) return;  // ky = 0 is its own twin plane: every column written as "self"
+
+    const int kx = x > half ? x - N : x;
+    double re[E], im[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) re[e] = im[e] = 0.0;
+
+    for (int k1 = 0; k1 < R; k1++) {
+        double fr = 1.0, fi = 0.0;  // W_R^{k1 * residue}
+        if (R > 1) {
+            const cplx f = twN[(int) (((long long) k1 * residue * L) & (N - 1))];
+            fr = f.x;
+            fi = f.y;
+        }
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int z = t + T * e + L * k1;
+            // which generated mode feeds (ky, z, x)?  For ky = 0 the reference copies the conjugate
+            // half-plane back (zeldovich.cpp:485-503): losers take conj of the mode at -k.
+            int zs = z, xs = x;
+            bool cj = false, zero = false;
+            if (ky == 0) {
+                if (z > half) {
+                    zs = N - z;
+                    xs = (N - x) & (N - 1);
+                    cj = true;
+                } else if (z == 0) {
+                    if (x == 0)
+                        zero = true;
+                    else if (x > half) {
+                        xs = N - x;
+                        cj = true;
+                    }
+                }
+            }
+            const long long idx = ((long long) kyl * N + zs) * N + xs;
+            cplx D = Dbuf[idx];
+            if (zero) D.x = D.y = 0.0;
+            if (cj) D.y = -D.y;
+            double sx, sy, sz, f = 1.0;
+            if (g.qPLT) {
+                const double4 pv = reinterpret_cast<const double4 *>(Pbuf)[idx];
+                const double sg  = cj ? -1.0 : 1.0;  // s(k) = -s(-k) for the conjugated copy
+                sx = sg * pv.x;
+                sy = sg * pv.y;
+                sz = sg * pv.z;
+                f  = pv.w;
+            } else {
+                const int kz = z > half ? z - N : z;
+                double k2    = (double) (kx * kx + ky * ky + kz * kz) * g.fundamental2;
+                if (k2 == 0.0) k2 = 1.0;
+                const double ik2 = 1.0 / k2;
+                sx = (double) kx * g.fundamental * ik2;
+                sy = (double) ky * g.fundamental * ik2;
+                sz = (double) kz * g.fundamental * ik2;
+            }
+            double cr, ci;
+            switch (kind) {
+                case JOB_A_SELF: cr = 1.0 - sx; ci = 0.0; break;
+                case JOB_A_TWIN: cr = 1.0 + sx; ci = 0.0; break;
+                case JOB_B_SELF: cr = -sz; ci = sy; break;
+                case JOB_B_TWIN: cr = sz; ci = sy; break;
+                case JOB_C_BOTH: cr = -f * sx; ci = 0.0; break;
+                case JOB_D_SELF: cr = -f * sz; ci = f * sy; break;
+                case JOB_D_TWIN: cr = f * sz; ci = f * sy; break;
+                default: cr = 1.0; ci = 0.0; break;
+            }
+            double vr = cr * D.x - ci * D.y, vi = cr * D.y + ci * D.x;
+            if (R > 1) {
+                const double a = vr * fr - vi * fi, b = vr * fi + vi * fr;
+                vr = a;
+                vi = b;
+            }
+            re[e] += vr;
+            im[e] += vi;
+        }
+    }
+    if (R > 1) {  // W_N^{k2 * residue}
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int k2 = t + T * e;
+            const cplx f = twN[(int) (((long long) k2 * residue) & (N - 1))];
+            const double a = re[e] * f.x - im[e] * f.y, b = re[e] * f.y + im[e] * f.x;
+            re[e] = a;
+            im[e] = b;
+        }
+    }
+
+    zdfft::fft_line<PL, LDS>(re, im, t, w, lds, twL);
+
+    // store: plane index z2 = t + T*e of this residue pass; destination chunk = owner of that plane
+    const int arr = (kind == JOB_A_SELF || kind == JOB_A_TWIN || kind == JOB_DENS) ? 0
+                    : (kind == JOB_B_SELF || kind == JOB_B_TWIN)                    ? 1
+                    : (kind == JOB_C_BOTH)                                          ? 2
+                                                                                    : 3;
+    const bool st_self = !twin_only;
+    const bool st_twin = (ky != 0) && (twin_only || kind == JOB_C_BOTH || kind == JOB_DENS);
+    const int loc_self = kyloc0 + kyl, loc_twin = S.Hq + kyloc0 + kyl;
+    const int xt = (N - x) & (N - 1);
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int z2 = t + T * e;
+        const int dst = z2 / Zq, zl = z2 - dst * Zq;
+        const long long base = (long long) dst * S.chunk_stride + (long long) zl * S.z_stride + (long long) arr * S.a_stride;
+        if (st_self) out[base + (long long) loc_self * N + x] = cplx{re[e], im[e]};
+        if (st_twin) {
+            cplx v;
+            if (kind == JOB_C_BOTH) {
+                v.x = -re[e];
+                v.y = im[e];
+            } else {
+                v.x = re[e];
+                v.y = -im[e];
+            }
+            out[base + (long long) loc_twin * N + xt] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_yfft: in-place y FFT of the block store.  grid: (N/W, narray, nplanes)  block: W*N/E
+template <int N, int E, int W>
+__global__ __launch_bounds__(W *N / E) void k_yfft(StoreLayout S, const cplx *__restrict__ tw, cplx *__restrict__ data) {
+    using PL  = zdfft::Plan<N, E>;
+    using LDS = zdfft::ColsInner<N, W>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int T = PL::T;
+    const int w = threadIdx.x % W, t = threadIdx.x / W;
+    const int x = blockIdx.x * W + w;
+    cplx *base = data + (long long) blockIdx.z * S.z_stride + (long long) blockIdx.y * S.a_stride + x;
+    double re[E], im[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int ky = t + T * e;
+        if (ky == N / 2) {  // Nyquist row is identically zero (zeldovich.cpp:644-650)
+            re[e] = im[e] = 0.0;
+        } else {
+            const cplx v = base[row_offset(S, ky)];
+            re[e] = v.x;
+            im[e] = v.y;
+        }
+    }
+    zdfft::fft_line<PL, LDS>(re, im, t, w, lds, tw);
+#pragma unroll
+    for (int e = 0; e < E; e++) base[row_offset(S, t + T * e)] = cplx{re[e], im[e]};
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_xfft: x FFT of ROWS rows x NA arrays per workgroup, then the WriteParticlesSlab epilogue.
+//   grid: (N/ROWS, nplanes)   block: ROWS*NA*N/E
+__device__ __forceinline__ unsigned long long dbits(double v) { return (unsigned long long) __double_as_longlong(v); }
+
+template <int N, int E, int NA, int ROWS>
+__global__ __launch_bounds__(ROWS *NA *N / E) void k_xfft(StoreLayout S, EpiConst ec, const cplx *__restrict__ tw,
+                                                         const cplx *__restrict__ data, int plane0,
+                                                         int z_first, int z_step, char *__restrict__ records,
+                                                         float *__restrict__ density, Reduce *__restrict__ red) {
+    using PL = zdfft::Plan<N, E>;
+    constexpr int WL = ROWS * NA;  // lines per workgroup
+    using LDS = zdfft::LineInner<N, WL>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int T = PL::T, NT = WL * T;
+    const int t = threadIdx.x % T, line = threadIdx.x / T;
+    const int row = line / NA, a = line % NA;
+    const int y  = blockIdx.x * ROWS + row;
+    const int pl = plane0 + blockIdx.y;  // local plane index inside the store
+    const cplx *src = data + (long long) pl * S.z_stride + (long long) a * S.a_stride + row_offset(S, y);
+    double re[E], im[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const cplx v = src[t + T * e];
+        re[e] = v.x;
+        im[e] = v.y;
+    }
+    zdfft::fft_line<PL, LDS>(re, im, t, line, lds, tw);
+    __syncthreads();
+    // fields of this line into LDS: fld[(row*2*NA + 2a + {0,1})*N + x]
+    double *fld = lds;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int xx = t + T * e;
+        fld[(row * 2 * NA + 2 * a) * N + xx]     = re[e];
+        fld[(row * 2 * NA + 2 * a + 1) * N + xx] = im[e];
+    }
+    __syncthreads();
+
+    // ---- WriteParticlesSlab (src/output.cpp:86-203) ----
+    const int z = z_first + z_step * (int) blockIdx.y;
+    double ssq = 0.0, mp[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
+    const long long plane_rec0 = (long long) blockIdx.y * N * N;
+    for (int i = threadIdx.x; i < ROWS * N; i += NT) {
+        const int r = i / N, xx = i - r * N;
+        const int yy = blockIdx.x * ROWS + r;
+        const double *f = fld + (r * 2 * NA) * N + xx;
+        const double dens = f[0];
+        ssq += dens * dens;
+        const long long pidx = plane_rec0 + (long long) yy * N + xx;
+        if (density) density[pidx] = (float) dens;
+        if (NA >= 2) {
+            double pos[3], vel[3];
+            pos[0] = f[1 * N];
+            pos[1] = f[2 * N];
+            pos[2] = f[3 * N];
+            if (NA == 4) {
+                vel[0] = f[5 * N] * ec.vnorm;
+                vel[1] = f[6 * N] * ec.vnorm;
+                vel[2] = f[7 * N] * ec.vnorm;
+            } else {
+                vel[0] = pos[0] * ec.vnorm;
+                vel[1] = pos[1] * ec.vnorm;
+                vel[2] = pos[2] * ec.vnorm;
+            }
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                mp[j] = fmax(mp[j], pos[j]);
+                mn[j] = fmax(mn[j], -pos[j]);
+            }
+            if (records) {
+                char *rec = records + pidx * ec.recsize;
+                const unsigned int ij = ((unsigned int) z & 0xffffu) | (((unsigned int) yy & 0xffffu) << 16);
+                const unsigned int k0 = ((unsigned int) xx & 0xffffu);
+                if (ec.icformat == 1) {  // RVZel: u16 i,j,k + pad, float displ[3], vel[3]
+                    uint4 q0, q1;
+                    q0.x = ij;
+                    q0.y = k0;
+                    q0.z = __float_as_uint((float) pos[2]);
+                    q0.w = __float_as_uint((float) pos[1]);
+                    q1.x = __float_as_uint((float) pos[0]);
+                    q1.y = __float_as_uint((float) vel[2]);
+                    q1.z = __float_as_uint((float) vel[1]);
+                    q1.w = __float_as_uint((float) vel[0]);
+                    reinterpret_cast<uint4 *>(rec)[0] = q0;
+                    reinterpret_cast<uint4 *>(rec)[1] = q1;
+                } else if (ec.icformat == 2) {  // RVdoubleZel: 56 B
+                    unsigned long long *r8 = reinterpret_cast<unsigned long long *>(rec);
+                    r8[0] = (unsigned long long) ij | ((unsigned long long) k0 << 32);
+                    double *d = reinterpret_cast<double *>(rec + 8);
+                    d[0] = pos[2];
+                    d[1] = pos[1];
+                    d[2] = pos[0];
+                    d[3] = vel[2];
+                    d[4] = vel[1];
+                    d[5] = vel[0];
+                } else if (ec.icformat == 0) {  // Zeldovich: u16 i,j,k + pad, double displ[3]
+                    double2 q0, q1;
+                    q0.x = __longlong_as_double((long long) ((unsigned long long) ij | ((unsigned long long) k0 << 32)));
+                    q0.y = pos[2];
+                    q1.x = pos[1];
+                    q1.y = pos[0];
+                    reinterpret_cast<double2 *>(rec)[0] = q0;
+                    reinterpret_cast<double2 *>(rec)[1] = q1;
+                } else {  // ZelSimple: float displ[3]
+                    float *d = reinterpret_cast<float *>(rec);
+                    d[0] = (float) pos[2];
+                    d[1] = (float) pos[1];
+                    d[2] = (float) pos[0];
+                }
+            }
+        }
+    }
+    // workgroup reduction -> one atomic per quantity into a replicated slot
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        ssq += __shfl_down(ssq, off);
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            mp[j] = fmax(mp[j], __shfl_down(mp[j], off));
+            mn[j] = fmax(mn[j], __shfl_down(mn[j], off));
+        }
+    }
+    __syncthreads();
+    double *scr = lds;  // 7 doubles per wave
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        scr[wave * 7 + 0] = ssq;
+        for (int j = 0; j < 3; j++) {
+            scr[wave * 7 + 1 + j] = mp[j];
+            scr[wave * 7 + 4 + j] = mn[j];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        constexpr int NW = (NT + 63) / 64;
+        double tot = 0, a3[3] = {0, 0, 0}, b3[3] = {0, 0, 0};
+        for (int i = 0; i < NW; i++) {
+            tot += scr[i * 7];
+            for (int j = 0; j < 3; j++) {
+                a3[j] = fmax(a3[j], scr[i * 7 + 1 + j]);
+                b3[j] = fmax(b3[j], scr[i * 7 + 4 + j]);
+            }
+        }
+        const int slot = (blockIdx.x + blockIdx.y * 7) % NSLOT;
+        atomicAdd(&red->sumsq[slot], tot);
+        if (NA >= 2) {
+            for (int j = 0; j < 3; j++) {
+                atomicMax(&red->maxpos[j][slot], dbits(fabs(a3[j])));
+                atomicMax(&red->maxneg[j][slot], dbits(fabs(b3[j])));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// test kernels: batches of independent lines through the two LDS layouts
+template <int N, int E, int W>
+__global__ __launch_bounds__(W *N / E) void k_test_fft_cols(const cplx *__restrict__ tw, const cplx *__restrict__ in,
+                                                           cplx *__restrict__ out, long long lines) {
+    // data layout [n][lines] (line index contiguous): the strided-axis situation of the y/z passes
+    using PL  = zdfft::Plan<N, E>;
+    using LDS = zdfft::ColsInner<N, W>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int T = PL::T;
+    const int w = threadIdx.x % W, t = threadIdx.x / W;
+    const long long col = (long long) blockIdx.x * W + w;
+    double re[E], im[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const cplx v = in[(long long) (t + T * e) * lines + col];
+        re[e] = v.x;
+        im[e] = v.y;
+    }
+    zdfft::fft_line<PL, LDS>(re, im, t, w, lds, tw);
+#pragma unroll
+    for (int e = 0; e < E; e++) out[(long long) (t + T * e) * lines + col] = cplx{re[e], im[e]};
+}
+template <int N, int E, int W>
+__global__ __launch_bounds__(W *N / E) void k_test_fft_lines(const cplx *__restrict__ tw, const cplx *__restrict__ in,
+                                                            cplx *__restrict__ out, long long lines) {
+    // data layout [lines][n]: contiguous lines (x pass)
+    using PL  = zdfft::Plan<N, E>;
+    using LDS = zdfft::LineInner<N, W>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int T = PL::T;
+    const int t = threadIdx.x % T, w = threadIdx.x / T;
+    const long long line = (long long) blockIdx.x * W + w;
+    double re[E], im[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const cplx v = in[line * N + t + T * e];
+        re[e] = v.x;
+        im[e] = v.y;
+    }
+    zdfft::fft_line<PL, LDS>(re, im, t, w, lds, tw);
+#pragma unroll
+    for (int e = 0; e < E; e++) out[line * N + t + T * e] = cplx{re[e], im[e]};
+}
+
+__global__ void k_copy16(const uint4 *__restrict__ in, uint4 *__restrict__ out, long long n) {
+    long long i      = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    const long long s = (long long) gridDim.x * blockDim.x;
+    for (; i < n; i += s) out[i] = in[i];
+}
+
+// ================================================================================================
+// launchers (C++ linkage inside the library; the C ABI lives in zd_capi.cpp)
+
+#define ZD_LAUNCH_CHECK()                                                                       \
+    do {                                                                                        \
+        hipError_t e__ = hipGetLastError();                                                     \
+        if (e__ != hipSuccess) {                                                                \
+            fprintf(stderr, "zeldovich_hip: launch failed at %s:%d: %s\n", __FILE__, __LINE__,  \
+                    hipGetErrorString(e__));                                                    \
+            return 1;                                                                           \
+        }                                                                                       \
+    } while (0)
+
+namespace zd {
+
+int launch_gen(const GenConst &g, const GenJumps &J, int ky0, int nky, void *Dbuf, void *Pbuf, hipStream_t st) {
+    const int N = g.N;
+    const int bx = (N + GEN_BX - 1) / GEN_BX;
+    if (N % GEN_ZR != 0) return 2;
+    dim3 grid(bx, N / GEN_ZR, nky), block(GEN_BX);
+    hipLaunchKernelGGL(k_gen<GEN_ZR>, grid, block, 0, st, g, J, ky0, (cplx *) Dbuf, (double *) Pbuf);
+    ZD_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_test_modes(const GenConst &g, long long n, const int *kxyz, uint64_t *draws, double *D, hipStream_t st) {
+    dim3 grid((unsigned) ((n + 255) / 256)), block(256);
+    hipLaunchKernelGGL(k_test_modes, grid, block, 0, st, g, n, kxyz, draws, D);
+    ZD_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int L, int E, int W>
+static int launch_zfft_t(const GenConst &g, const JobList &jobs, const StoreLayout &S, int ky0, int kyloc0, int nky,
+                         int residue, int Zq, const void *Dbuf, const void *Pbuf, const void *twN, const void *twL,
+                         void *out, hipStream_t st) {
+    constexpr int threads = W * L / E;
+    const size_t shmem = sizeof(double) * zdfft::ColsInner<L, W>::SIZE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void *) k_zfft<L, E, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+        attr_set = true;
+    }
+    dim3 grid(g.N / W, nky, jobs.n), block(threads);
+    hipLaunchKernelGGL((k_zfft<L, E, W>), grid, block, shmem, st, g, jobs, S, ky0, kyloc0, residue, Zq,
+                       (const cplx *) Dbuf, (const double *) Pbuf, (const cplx *) twN, (const cplx *) twL, (cplx *) out);
+    ZD_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_zfft(int L, const GenConst &g, const JobList &jobs, const StoreLayout &S, int ky0, int kyloc0, int nky,
+                int residue, int Zq, const void *Dbuf, const void *Pbuf, const void *twN, const void *twL, void *out,
+                hipStream_t st) {
+#define ZCASE(l, e, w) \
+    case l: return launch_zfft_t<l, e, w>(g, jobs, S, ky0, kyloc0, nky, residue, Zq, Dbuf, Pbuf, twN, twL, out, st);
+    switch (L) {
+        ZCASE(32, 16, 32)
+        ZCASE(64, 16, 32)
+        ZCASE(128, 16, 32)
+        ZCASE(256, 16, 16)
+        ZCASE(512, 16, 16)
+        ZCASE(1024, 16, 8)
+        ZCASE(2048, 16, 4)
+        ZCASE(4096, 16, 4)
+    }
+#undef ZCASE
+    fprintf(stderr, "zeldovich_hip: unsupported z-FFT length %d (power of two in [32,4096] required)\n", L);
+    return 2;
+}
+int zfft_tile_width(int L) {
+    switch (L) {
+        case 32: case 64: case 128: return 32;
+        case 256: case 512: return 16;
+        case 1024: return 8;
+        case 2048: case 4096: return 4;
+    }
+    return 0;
+}
+
+template <int N, int E, int W>
+static int launch_yfft_t(const StoreLayout &S, int nplanes, const void *tw, void *data, hipStream_t st) {
+    constexpr int threads = W * N / E;
+    const size_t shmem = sizeof(double) * zdfft::ColsInner<N, W>::SIZE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void *) k_yfft<N, E, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+        attr_set = true;
+    }
+    dim3 grid(N / W, S.narray, nplanes), block(threads);
+    hipLaunchKernelGGL((k_yfft<N, E, W>), grid, block, shmem, st, S, (const cplx *) tw, (cplx *) data);
+    ZD_LAUNCH_CHECK();
+    return 0;
+}
+int launch_yfft(const StoreLayout &S, int nplanes, const void *tw, void *data, hipStream_t st) {
+#define YCASE(n, e, w) \
+    case n: return launch_yfft_t<n, e, w>(S, nplanes, tw, data, st);
+    switch (S.N) {
+        YCASE(32, 16, 32)
+        YCASE(64, 16, 32)
+        YCASE(128, 16, 32)
+        YCASE(256, 16, 16)
+        YCASE(512, 16, 16)
+        YCASE(1024, 16, 8)
+        YCASE(2048, 16, 4)
+        YCASE(4096, 16, 4)
+    }
+#undef YCASE
+    fprintf(stderr, "zeldovich_hip: unsupported PPD %d (power of two in [32,4096] required)\n", S.N);
+    return 2;
+}
+
+template <int N, int E, int NA, int ROWS>
+static int launch_xfft_t(const StoreLayout &S, const EpiConst &ec, const void *tw, const void *data, int plane0,
+                         int nplanes, int z_first, int z_step, void *records, float *density, Reduce *red, hipStream_t st) {
+    constexpr int WL = ROWS * NA, threads = WL * N / E;
+    constexpr size_t fft_dbl = zdfft::LineInner<N, WL>::SIZE, fld_dbl = (size_t) ROWS * 2 * NA * N;
+    const size_t shmem = sizeof(double) * (fft_dbl > fld_dbl ? fft_dbl : fld_dbl);
+    if (shmem > 160 * 1024) {
+        fprintf(stderr, "zeldovich_hip: x pass for PPD %d with %d arrays needs %zu B of LDS (> 160 KB): unsupported\n", N, NA, shmem);
+        return 2;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void *) k_xfft<N, E, NA, ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+        attr_set = true;
+    }
+    dim3 grid(N / ROWS, nplanes), block(threads);
+    hipLaunchKernelGGL((k_xfft<N, E, NA, ROWS>), grid, block, shmem, st, S, ec, (const cplx *) tw, (const cplx *) data,
+                       plane0, z_first, z_step, (char *) records, density, red);
+    ZD_LAUNCH_CHECK();
+    return 0;
+}
+int launch_xfft(const StoreLayout &S, const EpiConst &ec, const void *tw, const void *data, int plane0, int nplanes,
+                int z_first, int z_step, void *records, float *density, Reduce *red, hipStream_t st) {
+#define XCASE(n, e, rows1, rows2, rows4)                                                                              \
+    case n:                                                                                                           \
+        if (S.narray == 1) return launch_xfft_t<n, e, 1, rows1>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, density, red, st); \
+        if (S.narray == 2) return launch_xfft_t<n, e, 2, rows2>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, density, red, st); \
+        return launch_xfft_t<n, e, 4, rows4>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, density, red, st);
+    switch (S.N) {
+        XCASE(32, 16, 32, 32, 16)
+        XCASE(64, 16, 32, 32, 16)
+        XCASE(128, 16, 32, 16, 8)
+        XCASE(256, 16, 16, 8, 4)
+        XCASE(512, 16, 8, 4, 2)
+        XCASE(1024, 16, 4, 2, 1)
+        XCASE(2048, 16, 2, 1, 1)
+        XCASE(4096, 16, 1, 1, 1)
+    }
+#undef XCASE
+    fprintf(stderr, "zeldovich_hip: unsupported PPD %d\n", S.N);
+    return 2;
+}
+
+template <int N, int E, int W>
+static int launch_test_fft_t(int kind, const void *tw, const void *in, void *out, long long lines, hipStream_t st) {
+    constexpr int threads = W * N / E;
+    if (lines % W) return 3;
+    if (kind == 1) {
+        const size_t shmem = sizeof(double) * zdfft::ColsInner<N, W>::SIZE;
+        hipFuncSetAttribute((const void *) k_test_fft_cols<N, E, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+        hipLaunchKernelGGL((k_test_fft_cols<N, E, W>), dim3((unsigned) (lines / W)), dim3(threads), shmem, st,
+                           (const cplx *) tw, (const cplx *) in, (cplx *) out, lines);
+    } else {
+        const size_t shmem = sizeof(double) * zdfft::LineInner<N, W>::SIZE;
+        hipFuncSetAttribute((const void *) k_test_fft_lines<N, E, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+        hipLaunchKernelGGL((k_test_fft_lines<N, E, W>), dim3((unsigned) (lines / W)), dim3(threads), shmem, st,
+                           (const cplx *) tw, (const cplx *) in, (cplx *) out, lines);
+    }
+    ZD_LAUNCH_CHECK();
+    return 0;
+}
+int launch_test_fft(int n, int kind, const void *tw, const void *in, void *out, long long lines, hipStream_t st) {
+#define TCASE(nn, e, w) \
+    case nn: return launch_test_fft_t<nn, e, w>(kind, tw, in, out, lines, st);
+    switch (n) {
+        TCASE(32, 16, 32)
+        TCASE(64, 16, 32)
+        TCASE(128, 16, 32)
+        TCASE(256, 16, 16)
+        TCASE(512, 16, 16)
+        TCASE(1024, 16, 8)
+        TCASE(2048, 16, 4)
+        TCASE(4096, 16, 4)
+    }
+#undef TCASE
+    return 2;
+}
+int test_fft_tile_width(int n) { return zfft_tile_width(n); }
+
+int launch_copy16(const void *in, void *out, long long n16, hipStream_t st) {
+    hipLaunchKernelGGL(k_copy16, dim3(256 * 8), dim3(256), 0, st, (const uint4 *) in, (uint4 *) out, n16);
+    ZD_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace zd
