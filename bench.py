@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py — grid->displacements throughput of the MI355X path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--ppd P] [--plt 0|1] [--format RVZel] [--stream R]
+
+One "step" = one complete pass of the hot path over the workload: mode generation, Hermitian
+packing + z FFT, (all-to-all between ranks), y FFT, x FFT + particle epilogue for all ppd^3
+particles.  Inputs (P(k) spline, eigenmode table, RNG jump tables) are resident in HBM before
+the timed region; finished planes are produced into an HBM ring and dropped (no PCIe in `value`).
+For N > 1 the driver launches this file under torch.distributed.run (one rank per GPU, RCCL);
+the fixed workload is sharded over the ranks ("strong" scaling) with ONE all-to-all per residue
+pass between the Z and XY stages.
+
+Prints ONE JSON line on rank 0 (see the contract in the task statement) with `roofline`
+(dominant kernel, hipEvent-timed on the launch stream inside the timed region) and
+`cpu_baseline` (the oracle — CPU port of the reference — timed on the host cores, rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+WMAP = os.path.join(ROOT, "tests", "golden", "wmap1new.pow")
+
+
+def synthetic_eigenmodes(ppd_e=128, seed=7, amp=0.15):
+    """Synthetic PLT eigenmode table in the reference's file layout (src/zeldovich.cpp:796-797,815):
+    eigmodes128 is not part of the reference mount, so the benchmark input is generated: a smooth
+    odd perturbation of k_hat (~(k/k_Ny)^2) and lambda = 1 - 0.2 (k/k_Ny)^2."""
+    h = ppd_e // 2 + 1
+    idx = np.arange(ppd_e)
+    kfull = np.where(idx > ppd_e // 2, idx - ppd_e, idx).astype(np.float64)
+    kx, ky, kz = kfull[:, None, None], kfull[None, :, None], np.arange(h, dtype=np.float64)[None, None, :]
+    kn = ppd_e / 2.0
+    k2 = kx * kx + ky * ky + kz * kz
+    kk = np.sqrt(np.where(k2 > 0, k2, 1.0))
+    q2 = k2 / (kn * kn)
+    c = np.random.RandomState(seed).uniform(-1, 1, size=(3, 3))
+    e = [kx / kk + amp * q2 * (c[i, 0] * kx + c[i, 1] * ky + c[i, 2] * kz) / kn for i in range(3)]
+    e[2] = kz / kk + amp * q2 * (c[2, 0] * kx + c[2, 1] * ky + c[2, 2] * kz) / kn
+    mag = np.sqrt(e[0] ** 2 + e[1] ** 2 + e[2] ** 2)
+    mag = np.where(mag > 0, mag, 1.0)
+    out = np.empty((ppd_e, ppd_e, h, 4), dtype=np.float64)
+    for i in range(3):
+        out[..., i] = e[i] / mag
+    out[..., 3] = 1.0 - 0.2 * q2
+    out[0, 0, 0, :3] = 0.0
+    return np.ascontiguousarray(out)
+
+
+def cpu_baseline(ppd, plt, fmt, eig):
+    """oracle (CPU port of the reference path) on the host cores, bounded sample of the workload"""
+    from oracle import zdo
+    zdo.build()
+    cores = os.cpu_count() or 1
+    n = min(ppd, 256)
+    while n > 64 and n ** 3 * (64 if plt else 32) * 2.2 > 24e9:
+        n //= 2
+    pk = zdo.pk_from_file(WMAP, 720.0)
+    kw = dict(numblock=4, icformat=fmt, nthreads=cores)
+    if plt:
+        kw.update(qPLT=1, qPLTrescale=1, PLT_target_z=5.0, z_initial=49.0)
+    p = zdo.make_params(n, **kw)
+    t0 = time.time()
+    out = zdo.run(p, pk, eig=eig if plt else None, eig_ppd=eig.shape[0] if plt else 0)
+    st = out["stats"]
+    t = st.t_stage1 + st.t_store + st.t_load + st.t_fft2d + st.t_write
+    return {"value": n ** 3 / t, "unit": "particles/s", "cores": cores, "kind": "port",
+            "sample": "PPD=%d %s %s, full grid->displacements (ZeldovichZ+ZeldovichXY timers), OpenMP on %d threads, "
+                      "radix-2 CPU FFT (FFTW3 absent); wall %.1fs" % (n, "PLT+rescale" if plt else "ZA", fmt, cores,
+                                                                     time.time() - t0)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--ppd", type=int, default=int(os.environ.get("ZD_BENCH_PPD", "2048")))
+    ap.add_argument("--plt", type=int, default=int(os.environ.get("ZD_BENCH_PLT", "1")))
+    ap.add_argument("--format", default="RVZel")
+    ap.add_argument("--stream", type=int, default=0, help="z-residue stream factor R (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import zeldovich_plt_amd.api as zd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    N, plt, fmt = args.ppd, bool(args.plt), args.format
+    zd.load_library()
+    ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
+    eig = synthetic_eigenmodes(128) if plt else None
+    kw = dict(numblock=64 if N >= 4096 else 4, icformat=fmt, profile=1)
+    if plt:
+        kw.update(qPLT=1, qPLTrescale=1, PLT_target_z=5.0, z_initial=49.0)
+    p = zd.make_params(N, **kw)
+    narray = 4 if plt else 2
+    recsize = zd.RECORD_DTYPES[fmt].itemsize
+
+    free_b, total_b = torch.cuda.mem_get_info()
+    R = args.stream
+    if R <= 0:
+        budget = int(free_b * 0.86) - (8 << 30)
+        import ctypes
+        R = zd.load_library().zd_choose_stream_factor(ctypes.byref(p), world, budget)
+        if R < 0:
+            raise SystemExit("PPD=%d does not fit %d GPU(s)" % (N, world))
+    p.stream_factor = R
+    plan = zd.Plan(p, ps, eig=eig, rank=rank, nranks=world)
+    from zeldovich_plt_amd.parallel import HipEngine, SlabPipeline
+    pipe = SlabPipeline(HipEngine(plan, N), N, world=world, dist=dist, device="cuda")
+
+    def step():
+        pipe.run()  # R residue passes: Z stage -> all-to-all (xGMI) -> y FFT -> x FFT + epilogue
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    plan.stats()  # drop warm-up kernel timers
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    st = plan.stats()
+
+    if rank == 0:
+        particles = float(N) ** 3
+        value = particles * args.steps / dt
+        # per-kernel algorithmic bytes per particle (64*a + S_out split over the passes)
+        alg = {"k_zfft": 16.0 * narray, "k_yfft": 32.0 * narray, "k_xfft": 16.0 * narray + recsize}
+        kms, kl = st["kernel_ms"], st["kernel_launches"]
+        dom = max(alg, key=lambda k: kms[k])
+        launches = max(1, kl[dom])
+        per_launch_particles = particles * args.steps / world / launches
+        avg_ms = kms[dom] / launches
+        achieved = alg[dom] * per_launch_particles / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(dom)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "particles/sec (grid->displacements)", "value": value, "unit": "particles/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic (seeded pcg64 Gaussian modes, wmap1new P(k)%s)" % (
+                ", synthetic ppd_e=128 PLT eigenmodes" if plt else ""),
+            "config": {"workload": "PPD=%d %s ICFormat=%s seed=12346 BoxSize=720" % (
+                N, "ZD_qPLT=1 ZD_qPLT_rescale=1" if plt else "ZA (ZD_qPLT=0)", fmt),
+                "stream_factor": R, "modes_cached": st["modes_cached"], "narray": narray,
+                "block_store_GB": plan.exchange_bytes / 1e9, "parallelism": "ky/z slabs x%d" % world},
+            "hbm_GBps_path": (64.0 * narray + recsize) * value / 1e9,
+            "roofline_path_frac": (64.0 * narray + recsize) * value / 1e9 / (HBM_PEAK_GBS * world),
+            "kernel_ms_per_step": {k: v / args.steps for k, v in kms.items()},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "avg_launch_ms": avg_ms, "launches": launches,
+                         "alg_bytes_per_particle": alg[dom]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(N, plt, fmt, eig)
+            except Exception as e:  # the baseline is a reported number, never the product path
+                out["cpu_baseline"] = {"value": None, "unit": "particles/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        print(json.dumps(out))
+    plan.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

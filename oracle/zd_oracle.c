@@ -755,6 +755,10 @@ static void load_block(const geom *g, double *arr, int yblock, int zblock, doubl
             }
 }
 
+typedef struct { unsigned short i, j, k, pad; double displ[3]; } zel_rec;               /* ZelParticle */
+typedef struct { unsigned short i, j, k, pad; float displ[3]; float vel[3]; } rv_rec;   /* RVZelParticle */
+typedef struct { unsigned short i, j, k, pad; double displ[3]; double vel[3]; } rvdouble_rec; /* RVdoubleZelParticle */
+
 /* WriteParticlesSlab into memory: src/output.cpp:41-234 */
 static void write_particles_slab(const geom *g, const zdo_params *param, int z, const double *s1,
                                  const double *s2, const double *s3, const double *s4, char *rec_out,
@@ -787,32 +791,32 @@ static void write_particles_slab(const geom *g, const zdo_params *param, int z, 
                     vel[2] = s2[2 * yx + 1] * vnorm;
                 }
                 if (rec_out) {
-                    char *r = rec_out + (size_t) i * recsize;
-                    memset(r, 0, (size_t) recsize); /* padding bytes are indeterminate in the reference */
-                    unsigned short ijk[3] = {(unsigned short) z, (unsigned short) y, (unsigned short) x};
+                    /* record structs: include/output.h:19-42 (padding bytes, indeterminate in the
+                     * reference, are written as zero) */
                     switch (param->icformat) {
-                        case 2: { /* RVdoubleZel */
-                            double d[6] = {pos[2], pos[1], pos[0], vel[2], vel[1], vel[0]};
-                            memcpy(r, ijk, 6);
-                            memcpy(r + 8, d, 48);
+                        case 2: {
+                            rvdouble_rec *o = (rvdouble_rec *) rec_out + i;
+                            o->i = (unsigned short) z; o->j = (unsigned short) y; o->k = (unsigned short) x; o->pad = 0;
+                            o->displ[0] = pos[2]; o->displ[1] = pos[1]; o->displ[2] = pos[0];
+                            o->vel[0] = vel[2]; o->vel[1] = vel[1]; o->vel[2] = vel[0];
                             break;
                         }
-                        case 1: { /* RVZel */
-                            float d[6] = {(float) pos[2], (float) pos[1], (float) pos[0],
-                                          (float) vel[2], (float) vel[1], (float) vel[0]};
-                            memcpy(r, ijk, 6);
-                            memcpy(r + 8, d, 24);
+                        case 1: {
+                            rv_rec *o = (rv_rec *) rec_out + i;
+                            o->i = (unsigned short) z; o->j = (unsigned short) y; o->k = (unsigned short) x; o->pad = 0;
+                            o->displ[0] = (float) pos[2]; o->displ[1] = (float) pos[1]; o->displ[2] = (float) pos[0];
+                            o->vel[0] = (float) vel[2]; o->vel[1] = (float) vel[1]; o->vel[2] = (float) vel[0];
                             break;
                         }
-                        case 0: { /* Zeldovich */
-                            double d[3] = {pos[2], pos[1], pos[0]};
-                            memcpy(r, ijk, 6);
-                            memcpy(r + 8, d, 24);
+                        case 0: {
+                            zel_rec *o = (zel_rec *) rec_out + i;
+                            o->i = (unsigned short) z; o->j = (unsigned short) y; o->k = (unsigned short) x; o->pad = 0;
+                            o->displ[0] = pos[2]; o->displ[1] = pos[1]; o->displ[2] = pos[0];
                             break;
                         }
-                        case 3: { /* ZelSimple */
-                            float d[3] = {(float) pos[2], (float) pos[1], (float) pos[0]};
-                            memcpy(r, d, 12);
+                        case 3: {
+                            float *o = (float *) rec_out + 3 * i;
+                            o[0] = (float) pos[2]; o[1] = (float) pos[1]; o[2] = (float) pos[0];
                             break;
                         }
                     }
@@ -853,7 +857,11 @@ int zdo_run(const zdo_params *param, const zdo_pk *Pk, const double *eig, int64_
     zdo_pcg *v2rng = make_v2rng(param);
 
     int64_t total = ppd * ppd * ppd * g->narray;
-    double *arr   = (double *) calloc((size_t) total, 2 * sizeof(double));
+    double *arr   = (double *) malloc((size_t) total * 2 * sizeof(double));
+    if (arr) { /* BlockArray constructor zeroes in parallel, outside the stage timers (block_array.cpp:63-66) */
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < 2 * total; i++) arr[i] = 0.0;
+    }
     int64_t len   = (int64_t) g->block * ppd * ppd * g->narray;
     double *slab    = (double *) calloc((size_t) len, 2 * sizeof(double));
     double *slabHer = (double *) calloc((size_t) len, 2 * sizeof(double));

@@ -1,0 +1,163 @@
+"""CPU: host-side logic of the product (no compute on a GPU): parameter file reader, PowerSpectrum
+setup vs the oracle, eigenmode loader, stream-factor chooser, FFT engine index arithmetic (host
+emulation of zd_fft.h) and the RNG jump maps."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, WMAP
+
+EXAMPLE = """# An example zeldovich parameter file (same keys as the reference's example.par)
+BoxSize = 720
+CPD = 375
+ICFormat = "RVZel"
+InitialConditionsDirectory = "%(out)s"
+InitialRedshift = 49
+NP = 2097152
+ZD_NumBlock = 4
+ZD_PLT_filename = "%(eig)s"
+ZD_PLT_target_z = 5
+ZD_Pk_filename = "%(pk)s"
+ZD_Pk_norm = 8.0
+ZD_Pk_scale = 1.0
+ZD_Pk_sigma = 0.0210839935761
+ZD_Pk_smooth = 0.0
+ZD_Seed = 12346
+ZD_k_cutoff = 1.0
+ZD_qPLT = %(plt)d
+ZD_qPLT_rescale = 0
+ZD_qPk_fix_to_mean = 0
+ZD_Version = 2
+ZD_f_NL = 0
+"""
+
+
+@pytest.fixture()
+def zd():
+    import zeldovich_plt_amd.api as api
+    api.load_library()
+    return api
+
+
+def _write(tmp_path, text):
+    f = tmp_path / "t.par"
+    f.write_text(text)
+    return str(f)
+
+
+def test_params_from_file(zd, tmp_path):
+    par = _write(tmp_path, EXAMPLE % dict(out=tmp_path / "ic", eig="./eigmodes128", pk=WMAP, plt=1))
+    p, s = zd.params_from_file(par)
+    assert p.ppd == 128 and p.numblock == 4 and p.cpd == 375 and p.seed == 12346
+    assert p.qPLT == 1 and p.qPLTrescale == 0 and p.PLT_target_z == 5 and p.z_initial == 49
+    assert p.icformat == zd.ICFORMATS["RVZel"] and s.ICFormat == b"RVZel"
+    assert s.Pk_filename.decode() == WMAP and s.version == 2 and s.np == 2097152
+    # derived quantities: src/parameters.cpp:172-174
+    assert p.fundamental == 2.0 * np.pi / 720 and p.nyquist == np.pi / (720 / 128)
+    assert p.k_cutoff == 1.0 and p.f_cluster == 1.0 and p.qoneslab == -1  # defaults :13-44
+
+
+@pytest.mark.parametrize("mutation,ok", [
+    (("ZD_Version = 2", ""), False),                    # ZD_Version must be given
+    (("ZD_Version = 2", "ZD_Version = 1"), False),      # v1 (GSL streams) is out of scope
+    (("NP = 2097152", "NP = 2097153"), False),          # ppd^3 != NP
+    (("BoxSize = 720", ""), False),                     # MUST_DEFINE
+    (("ZD_Pk_sigma = 0.0210839935761", "ZD_Pk_sigma = 0.02\nZD_Pk_sigma_ratio = 1.0"), False),
+    (("ZD_NumBlock = 4", "ZD_NumBlock = 3"), False),    # even divisor (block_array.cpp:38-40)
+    (("ICFormat = \"RVZel\"", "ICFormat = \"Zeldovich\""), False),  # PLT needs an RV format
+    (("ZD_k_cutoff = 1.0", "ZD_k_cutoff = 0.5"), False),
+    (("ZD_Seed = 12346", "ZD_Seed = -7   # negative seeds sign-extend"), True),
+    (("NP = 2097152", "NP = 2.097152D6"), True),        # Fortran exponent
+])
+def test_params_validation(zd, tmp_path, mutation, ok):
+    text = (EXAMPLE % dict(out=tmp_path / "ic", eig="./eigmodes128", pk=WMAP, plt=1)).replace(*mutation)
+    par = _write(tmp_path, text)
+    if ok:
+        p, s = zd.params_from_file(par)
+        if "Seed" in mutation[1]:
+            assert p.seed == -7
+    else:
+        with pytest.raises(ValueError):
+            zd.params_from_file(par)
+
+
+def test_power_spectrum_matches_oracle(zd, oracle):
+    ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
+    opk = oracle.pk_from_file(WMAP, 720.0)
+    x, y, y2 = ps.tables()
+    ox, oy, oy2 = oracle.pk_tables(opk)
+    assert np.array_equal(x, ox) and np.array_equal(y, oy)
+    assert np.max(np.abs(y2 - oy2)) <= 1e-15 * np.max(np.abs(oy2))
+    assert abs(ps.pk.normalization - opk.normalization) <= 1e-15 * opk.normalization
+    L = oracle.lib()
+    for k in [1e-3, 0.0123, 0.5, 3.0, 7.5]:
+        a, b = ps.power(k), L.zdo_power(C.byref(opk), k)
+        assert abs(a - b) <= 1e-15 * b
+    assert ps.power(0.0) == 0.0 and ps.power(-1.0) == 0.0
+    # sigma(R) after normalisation reproduces the target (x boxsize^1.5 undoes the 1/V)
+    assert abs(ps.sigmaR(8.0) * 720.0 ** 1.5 - 0.0210839935761) < 1e-6 * 0.0210839935761
+    pl = zd.PowerSpectrum.from_powerlaw(-1.5, 720.0)
+    opl = oracle.pk_from_powerlaw(-1.5, 720.0)
+    assert abs(pl.pk.normalization - opl.normalization) <= 1e-15 * opl.normalization
+    assert abs(pl.power(0.3) - L.zdo_power(C.byref(opl), 0.3)) <= 1e-15 * pl.power(0.3)
+
+
+def test_eigenmode_loader(zd, oracle, tmp_path):
+    eig = oracle.synthetic_eigenmodes(8)
+    f = tmp_path / "eig8"
+    with open(f, "wb") as fh:
+        fh.write(np.int32(8).tobytes())
+        fh.write(eig.tobytes())
+    L = zd.load_library()
+    ptr, ppd = C.c_void_p(), C.c_int64()
+    assert L.zd_load_eigmodes(os.fsencode(str(f)), C.byref(ptr), C.byref(ppd)) == 0
+    got = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), (eig.size,)).copy()
+    L.zd_free(ptr)
+    assert ppd.value == 8 and np.array_equal(got, eig.ravel())
+    with open(f, "ab") as fh:
+        fh.write(b"x")  # size mismatch must be rejected (zeldovich.cpp:817-822)
+    assert L.zd_load_eigmodes(os.fsencode(str(f)), C.byref(ptr), C.byref(ppd)) != 0
+    assert L.zd_load_eigmodes(b"/nonexistent/eig", C.byref(ptr), C.byref(ppd)) != 0
+
+
+def test_stream_factor_chooser(zd):
+    L = zd.load_library()
+    GB = 1 << 30
+    p = zd.make_params(2048)  # ZA: 2048^3*32 B = 256 GiB
+    assert L.zd_choose_stream_factor(C.byref(p), 1, 300 * GB) == 1
+    assert L.zd_choose_stream_factor(C.byref(p), 1, 200 * GB) == 2
+    assert L.zd_choose_stream_factor(C.byref(p), 1, 100 * GB) == 4
+    assert L.zd_choose_stream_factor(C.byref(p), 8, 100 * GB) == 1   # 32 GiB/rank x2 buffers
+    p4 = zd.make_params(4096)
+    assert L.zd_choose_stream_factor(C.byref(p4), 1, 200 * GB) == 16
+    assert L.zd_choose_stream_factor(C.byref(p4), 8, 200 * GB) == 4
+    assert L.zd_choose_stream_factor(C.byref(p4), 1, 1 * GB) == -1
+
+
+# ---- host emulation of the device FFT engine -------------------------------------------------------
+@pytest.fixture(scope="module")
+def emul():
+    src = os.path.join(ROOT, "tests", "host_emul", "emul_fft.cpp")
+    out = os.path.join(ROOT, "tests", "host_emul", "_build", "libemul_fft.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if not os.path.exists(out) or os.path.getmtime(out) < max(
+            os.path.getmtime(src), os.path.getmtime(os.path.join(ROOT, "zeldovich_plt_amd", "csrc", "zd_fft.h"))):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", src, "-o", out])
+    return C.CDLL(out)
+
+
+@pytest.mark.parametrize("n,e,w", [(16, 16, 2), (32, 16, 2), (64, 16, 4), (128, 16, 4), (256, 16, 2), (512, 16, 2),
+                                   (1024, 16, 2), (2048, 16, 2), (4096, 16, 1), (64, 8, 4), (512, 8, 2),
+                                   (128, 4, 2), (32, 2, 2), (8, 4, 3)])
+@pytest.mark.parametrize("line", [0, 1])
+def test_fft_engine_host_emulation(emul, n, e, w, line):
+    """the exact pass / exchange index arithmetic the kernels run, executed thread by thread on the CPU"""
+    rng = np.random.default_rng(n * 31 + e + line)
+    x = rng.standard_normal((w, n)) + 1j * rng.standard_normal((w, n))
+    out = np.zeros_like(x)
+    assert emul.emul_fft(n, e, w, line, x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)) == 0
+    ref = np.fft.ifft(x, axis=1) * n
+    assert np.abs(out - ref).max() / np.abs(ref).max() < 5e-15

@@ -343,13 +343,16 @@ int64_t zd_plan_plane_z(const zd_plan *pl, int residue, int64_t local_plane) {
 int zd_plan_stage_z(zd_plan *pl, int residue, void *d_send, void *hip_stream) {
     hipStream_t st = (hipStream_t) hip_stream;
     if (residue < 0 || residue >= pl->R) return 1;
+    // residue 0 starts a new realisation pass: the cached amplitudes are only reused by the later
+    // residues of the SAME pass (every pass pays for its own mode generation)
+    if (residue == 0) pl->cache_valid = false;
     const int ky_first = pl->rank * pl->Hq;
     for (int r0 = 0; r0 < pl->Hq; r0 += pl->slab_rows) {
         const int nky   = std::min(pl->slab_rows, pl->Hq - r0);
         const size_t mo = pl->cache_all ? (size_t) r0 * pl->N * pl->N : 0;
         cplx *D   = pl->d_D + mo;
         double *P = pl->d_P ? pl->d_P + 4 * mo : nullptr;
-        if (!(pl->cache_all && pl->cache_valid)) {
+        if (!(pl->cache_all && pl->cache_valid && residue != 0)) {
             tick(pl, ZD_K_GEN, st, true);
             if (zd::launch_gen(pl->g, pl->J, ky_first + r0, nky, D, P, st)) return 1;
             tick(pl, ZD_K_GEN, st, false);
@@ -360,7 +363,7 @@ int zd_plan_stage_z(zd_plan *pl, int residue, void *d_send, void *hip_stream) {
             return 1;
         tick(pl, ZD_K_ZFFT, st, false);
     }
-    if (pl->cache_all) pl->cache_valid = true;
+    if (pl->cache_all && residue == 0) pl->cache_valid = true;
     return 0;
 }
 

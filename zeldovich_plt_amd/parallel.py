@@ -1,0 +1,82 @@
+"""One-process-per-GPU driver of the grid->displacements path.
+
+The reference is single-process; its y<->z "transpose" is StoreBlock/LoadBlock on one big array
+(src/block_array.cpp:387-414,466-504).  Here rank g owns the half-space rows ky in [g*H,(g+1)*H)
+(+ Hermitian twins) during the Z stage and the planes [g*Zq,(g+1)*Zq) of each residue pass during the
+XY stage; the block exchange between the two is ONE all-to-all per pass (RCCL over xGMI through
+torch.distributed; gloo in the CPU tests).  No other collective is on the data path.
+
+`engine` is anything with the staged interface of include/zeldovich_hip.h:
+    engine.R, engine.local_planes, engine.exchange_bytes, engine.record_size
+    engine.stage_z(residue, send), engine.stage_y(recv), engine.stage_x(residue, recv, p0, n, out)
+    engine.plane_z(residue, local_plane)
+On a GPU it is `HipEngine` (zeldovich_plt_amd.api.Plan on torch device buffers).
+"""
+import torch
+
+
+class HipEngine:
+    """The product engine: libzeldovich_hip.so plan on torch-owned HBM buffers (no CPU fallback)."""
+
+    def __init__(self, plan, ppd):
+        self.plan = plan
+        self.ppd = ppd
+        self.R = plan.R
+        self.local_planes = plan.local_planes
+        self.exchange_bytes = plan.exchange_bytes
+        self.record_size = plan.record_size
+
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    def plane_z(self, residue, local_plane):
+        return self.plan.plane_z(residue, local_plane)
+
+    def stage_z(self, residue, send):
+        self.plan.stage_z(residue, send.data_ptr(), self._stream())
+
+    def stage_y(self, recv):
+        self.plan.stage_y(recv.data_ptr(), self._stream())
+
+    def stage_x(self, residue, recv, plane0, nplanes, out):
+        self.plan.stage_x(residue, recv.data_ptr(), plane0, nplanes, out.data_ptr(), None, self._stream())
+
+
+class SlabPipeline:
+    """Runs residue passes: Z stage -> all-to-all -> y FFT -> x FFT + epilogue in plane chunks."""
+
+    def __init__(self, engine, ppd, world=1, dist=None, device="cpu", chunk_bytes=512 << 20):
+        self.e = engine
+        self.ppd = ppd
+        self.world = world
+        self.dist = dist
+        if world > 1 and dist is None:
+            raise ValueError("world > 1 needs torch.distributed")
+        self.send = torch.empty(engine.exchange_bytes, dtype=torch.uint8, device=device)
+        self.recv = torch.empty(engine.exchange_bytes, dtype=torch.uint8, device=device) if world > 1 else self.send
+        plane_b = ppd * ppd * max(engine.record_size, 1)
+        self.chunk = int(max(1, min(engine.local_planes, chunk_bytes // plane_b)))
+        self.ring = torch.empty(self.chunk * plane_b, dtype=torch.uint8, device=device)
+
+    def exchange(self):
+        if self.world > 1:
+            # chunk d of `send` goes to rank d and arrives as chunk <my rank> there: exactly the
+            # y-slab-owner -> z-slab-owner block move of StoreBlock/LoadBlock
+            self.dist.all_to_all_single(self.recv, self.send)
+
+    def run_pass(self, residue, consume=None):
+        """consume(z_list, ring_tensor) is called once per plane chunk with the global z of each plane"""
+        e = self.e
+        e.stage_z(residue, self.send)
+        self.exchange()
+        e.stage_y(self.recv)
+        for p0 in range(0, e.local_planes, self.chunk):
+            n = min(self.chunk, e.local_planes - p0)
+            e.stage_x(residue, self.recv, p0, n, self.ring)
+            if consume is not None:
+                consume([e.plane_z(residue, p0 + i) for i in range(n)], self.ring)
+
+    def run(self, consume=None):
+        for r in range(self.e.R):
+            self.run_pass(r, consume)
