@@ -1,0 +1,71 @@
+"""GPU: the drop-in command line `zeldovich <param_file>` (reference src/zeldovich.cpp:848-1032):
+ic_{z*CPD/PPD} files in the reference's record formats, plane order inside a file = increasing z even
+when planes are produced in residue order, optional density file, usage/exit codes."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, WMAP
+
+pytestmark = pytest.mark.gpu
+EXE = os.path.join(ROOT, "zeldovich_plt_amd", "csrc", "build", "zeldovich")
+
+PAR = """BoxSize = 720
+CPD = %(cpd)d
+ICFormat = "%(fmt)s"
+InitialConditionsDirectory = "%(out)s"
+InitialRedshift = 49
+NP = %(np)d
+ZD_NumBlock = 2
+ZD_Pk_filename = "%(pk)s"
+ZD_Pk_norm = 8.0
+ZD_Pk_scale = 1.0
+ZD_Pk_sigma = 0.0210839935761
+ZD_Pk_smooth = 0.0
+ZD_Seed = 12346
+ZD_Version = 2
+ZD_qdensity = %(qd)d
+ZD_StreamFactor = %(R)d
+"""
+
+
+def test_usage_and_bad_file():
+    r = subprocess.run([EXE], capture_output=True, text=True)
+    assert r.returncode == 1 and "Usage:" in r.stderr
+    r = subprocess.run([EXE, "/nonexistent.par"], capture_output=True, text=True)
+    assert r.returncode == 1
+
+
+@pytest.mark.parametrize("fmt,R,qd", [("RVdoubleZel", 1, 0), ("RVZel", 2, 1), ("ZelSimple", 2, 0)])
+def test_cli_writes_reference_files(tmp_path, oracle, fmt, R, qd):
+    n, cpd = 64, 5
+    out = tmp_path / "ic"
+    out.mkdir()
+    (out / "ic_99").write_bytes(b"stale")       # SetupOutputDir removes ic_* and zeldovich.* (output.cpp:236-251)
+    (out / "keep.txt").write_text("keep")
+    par = tmp_path / "t.par"
+    par.write_text(PAR % dict(cpd=cpd, fmt=fmt, out=out, np=n ** 3, pk=WMAP, qd=qd, R=R))
+    r = subprocess.run([EXE, str(par)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Mpart/sec" in r.stderr and "maximum component-wise displacements" in r.stderr
+    assert not (out / "ic_99").exists() and (out / "keep.txt").exists()
+    pk = oracle.pk_from_file(WMAP, 720.0)
+    ref = oracle.run(oracle.make_params(n, numblock=2, icformat=fmt, cpd=cpd, qdensity=qd), pk, want_density=bool(qd))
+    dt = oracle.RECORD_DTYPES[fmt]
+    files = sorted(int(f.name[3:]) for f in out.iterdir() if f.name.startswith("ic_"))
+    assert files == sorted(set(z * cpd // n for z in range(n)))
+    for f in files:
+        zs = [z for z in range(n) if z * cpd // n == f]
+        got = np.fromfile(out / ("ic_%d" % f), dtype=dt).reshape(len(zs), n, n)
+        want = ref["records"][zs]
+        if "ijk" in dt.names:
+            assert np.array_equal(got["ijk"], want["ijk"])
+        tol = 1e-10 if dt["d"].base == np.float64 else 1e-6
+        assert np.abs(got["d"] - want["d"]).max() <= tol * np.abs(want["d"]).max()
+        if "v" in dt.names:
+            assert np.abs(got["v"] - want["v"]).max() <= tol * np.abs(want["v"]).max()
+    if qd:
+        dens = np.fromfile(out / ("density%d" % n), dtype=np.float32).reshape(n, n, n)
+        assert np.abs(dens - ref["density"]).max() <= 1e-6 * np.abs(ref["density"]).max()
