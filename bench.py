@@ -121,7 +121,7 @@ def main():
     free_b, total_b = torch.cuda.mem_get_info()
     R = args.stream
     if R <= 0:
-        budget = int(free_b * 0.86) - (8 << 30)
+        budget = int(free_b) - (12 << 30)  # tables, ~1 GB folded-input slab, record ring, runtime
         import ctypes
         R = zd.load_library().zd_choose_stream_factor(ctypes.byref(p), world, budget)
         if R < 0:

@@ -171,6 +171,9 @@ int zd_test_modes(const zd_params *p, const zd_pk *pk, int64_t n, const int32_t 
 /* batch of `lines` independent length-n inverse FFTs, host in/out [lines][n] complex double;
  * axis_kind 0: the contiguous-line kernel path (x pass), 1: the strided-line path (y/z passes) */
 int zd_test_fft(int32_t n, int64_t lines, int32_t axis_kind, const double *in, double *out);
+/* tuning harness: ms per launch of y-pass tile variant `variant` on a synthetic store of nplanes planes */
+int zd_test_yfft_variant(int32_t n, int32_t variant, int32_t narray, int32_t nplanes, int32_t tiled, int32_t reps,
+                         double *ms_per_launch);
 /* device copy bandwidth probe: bytes moved per second by a 16 B/lane streaming copy of `bytes` */
 int zd_test_copy_bw(int64_t bytes, int32_t reps, double *gbps);
 

@@ -17,9 +17,20 @@ class NumpyEngine:
         self.Zq = self.L // world
         self.local_planes = self.Zq
         self.record_size = 16 * self.na  # "records" of the stand-in = the raw complex planes
-        self.a_stride = 2 * self.Hq * N
-        self.z_stride = self.a_stride * self.na
-        self.chunk_stride = self.z_stride * self.Zq
+        # tiled block store (zd_device.h StoreLayout): blocks of Bz planes x Bk row slots x N
+        target = max(1, (2 << 20) // (N * 16))
+        lt = target.bit_length() - 1
+        lBk = (lt + 1) // 2
+        lBz = lt - lBk
+        while (1 << lBk) > self.Hq:
+            lBk -= 1
+        while (1 << lBz) > self.Zq:
+            lBz -= 1
+        self.lBk, self.lBz = lBk, lBz
+        self.a_stride = (N << lBk) << lBz
+        self.zb_stride = self.a_stride * self.na
+        self.kb_stride = self.zb_stride * (self.Zq >> lBz)
+        self.chunk_stride = self.kb_stride * ((2 * self.Hq) >> lBk)
         self.exchange_bytes = self.chunk_stride * world * 16
         # z-transformed columns for the rows this rank generates
         self.zt = np.fft.ifft(cube, axis=2) * N  # [a][ky][z][kx]
@@ -38,6 +49,11 @@ class NumpyEngine:
         src = kyh // Hq
         return src, kyh - src * Hq + tw * Hq
 
+    def _off(self, chunk, zl, a, slot):
+        Bk, Bz = 1 << self.lBk, 1 << self.lBz
+        return (chunk * self.chunk_stride + (slot >> self.lBk) * self.kb_stride + (zl >> self.lBz) * self.zb_stride
+                + a * self.a_stride + (((zl & (Bz - 1)) << self.lBk) + (slot & (Bk - 1))) * self.N)
+
     def stage_z(self, residue, send):
         buf = send.numpy().view(np.complex128)
         N, Hq, Zq = self.N, self.Hq, self.Zq
@@ -49,7 +65,7 @@ class NumpyEngine:
                 for z2 in range(self.L):
                     dst, zl = divmod(z2, Zq)
                     for a in range(self.na):
-                        o = dst * self.chunk_stride + zl * self.z_stride + a * self.a_stride + loc * N
+                        o = self._off(dst, zl, a, loc)
                         buf[o:o + N] = self.zt[a, ky, residue + self.R * z2, :]
 
     def stage_y(self, recv):
@@ -57,12 +73,11 @@ class NumpyEngine:
         N = self.N
         for zl in range(self.Zq):
             for a in range(self.na):
-                base = zl * self.z_stride + a * self.a_stride
                 offs = []
                 plane = np.zeros((N, N), dtype=np.complex128)
                 for ky in range(N):
                     src, loc = self._loc(ky)
-                    o = src * self.chunk_stride + base + loc * N
+                    o = self._off(src, zl, a, loc)
                     offs.append(o)
                     if ky != N // 2:
                         plane[ky] = buf[o:o + N]
@@ -77,10 +92,9 @@ class NumpyEngine:
         for i in range(nplanes):
             zl = plane0 + i
             for a in range(self.na):
-                base = zl * self.z_stride + a * self.a_stride
                 for y in range(N):
                     src, loc = self._loc(y)
-                    o = src * self.chunk_stride + base + loc * N
+                    o = self._off(src, zl, a, loc)
                     row = np.fft.ifft(buf[o:o + N]) * N
                     d = ((i * N + y) * self.na + a) * N  # out layout: [plane][y][a][x]
                     o_out[d:d + N] = row

@@ -73,7 +73,7 @@ EXPORTED_SYMBOLS = [
     "zd_plan_plane_z", "zd_plan_stage_z", "zd_plan_stage_y", "zd_plan_stage_x", "zd_plan_stats",
     "zd_params_from_file", "zd_pk_create_from_file", "zd_pk_create_powerlaw", "zd_pk_power",
     "zd_pk_sigmaR", "zd_pk_destroy", "zd_load_eigmodes", "zd_free", "zd_test_draws", "zd_test_modes",
-    "zd_test_fft", "zd_test_copy_bw",
+    "zd_test_fft", "zd_test_yfft_variant", "zd_test_copy_bw",
 ]
 
 _lib = None
@@ -123,6 +123,7 @@ def load_library():
     L.zd_test_modes.argtypes = [C.POINTER(ZdParams), C.POINTER(ZdPk), i64, vp, vp]
     L.zd_test_fft.argtypes = [i32, i64, i32, vp, vp]
     L.zd_test_copy_bw.argtypes = [i64, i32, C.POINTER(dbl)]
+    L.zd_test_yfft_variant.argtypes = [i32, i32, i32, i32, i32, i32, C.POINTER(dbl)]
     _lib = L
     return L
 

@@ -68,16 +68,14 @@ struct zd_plan {
     zd::EpiConst ec;
     // device tables
     double *d_pk = nullptr;  // x | y | y2
+    int *d_lut = nullptr;
     double *d_eig = nullptr;
     u128 *d_rowstate = nullptr;
     cplx *d_twN = nullptr, *d_twL = nullptr;
     zd::Reduce *d_red = nullptr;
-    // mode buffers
-    cplx *d_D = nullptr;
-    double *d_P = nullptr;
-    int slab_rows = 0;       // rows generated per k_gen launch
-    bool cache_all = false;  // D (and P) kept for all owned rows across residue passes
-    bool cache_valid = false;
+    // folded FFT inputs of one slab of half-space rows: Y[job][row][k2][x]
+    cplx *d_Y = nullptr;
+    int slab_rows = 0;  // rows generated per k_gen launch
     // timing
     std::vector<EventPair> events;
     std::vector<hipEvent_t> pool;
@@ -114,8 +112,12 @@ void collect_events(zd_plan *pl) {
     pl->events.clear();
 }
 
-int64_t mode_bytes_per_row(const zd_plan *pl) {
-    return (int64_t) pl->N * pl->N * (16 + (pl->p.qPLT ? 32 : 0));
+int64_t y_bytes_per_row(const zd_plan *pl) { return (int64_t) pl->jobs.n * pl->L * pl->N * 16; }
+
+// advance by (2*65536*drows - 1) draws, drows may be negative (period 2^128)
+zdpcg::Affine row_jump(long long drows) {
+    const __int128 d = (__int128) 2 * 65536 * (__int128) drows - 1;
+    return zdpcg::jump_map((u128) d);
 }
 
 }  // namespace
@@ -173,6 +175,7 @@ int zd_plan_create(const zd_params *p, const zd_pk *pk, const double *eig, int64
     g.half         = pl->half;
     g.kmax         = (int) ((double) pl->half * (1.0 / p->k_cutoff) + .5);
     g.corner_modes = p->corner_modes;
+    g.ablate       = getenv("ZD_ABLATE") ? atoi(getenv("ZD_ABLATE")) : 0;
     g.qonemode     = p->qonemode;
     for (int i = 0; i < 3; i++) g.one_mode[i] = p->one_mode[i];
     g.fundamental  = p->fundamental;
@@ -217,6 +220,21 @@ int zd_plan_create(const zd_params *p, const zd_pk *pk, const double *eig, int64
         g.pk_x  = pl->d_pk;
         g.pk_y  = pl->d_pk + pk->n;
         g.pk_y2 = pl->d_pk + 2 * pk->n;
+        // segment start table: cell c covers ln k in [x0 + c*dx, x0 + (c+1)*dx)
+        std::vector<int> lut(zd::PK_LUT);
+        const double x0 = pk->x[0], x1 = pk->x[pk->n - 1];
+        const double dx = (x1 - x0) / zd::PK_LUT;
+        int klo = 0;
+        for (int c2 = 0; c2 < zd::PK_LUT; c2++) {
+            const double cell_start = x0 + c2 * dx * (1.0 - 1e-12) - 1e-9;  // never past the true start
+            while (klo < pk->n - 2 && pk->x[klo + 1] <= cell_start) klo++;
+            lut[c2] = klo;
+        }
+        PLCHECK(hipMalloc((void **) &pl->d_lut, sizeof(int) * lut.size()));
+        PLCHECK(hipMemcpy(pl->d_lut, lut.data(), sizeof(int) * lut.size(), hipMemcpyHostToDevice));
+        g.pk_lut     = pl->d_lut;
+        g.lut_x0     = x0;
+        g.lut_inv_dx = 1.0 / dx;
     }
     if (p->qPLT) {
         const size_t nb = sizeof(double) * (size_t) eig_ppd * eig_ppd * (eig_ppd / 2 + 1) * 4;
@@ -244,10 +262,13 @@ int zd_plan_create(const zd_params *p, const zd_pk *pk, const double *eig, int64
             zd_plan_destroy(pl);
             return 1;
         }
-        // state is kept one draw ahead of the mode's counter, two draws are consumed per mode:
-        // next row = +2*65536 draws, minus the one step already taken inside the loop
-        pl->J.jz  = zdpcg::jump_map((u128) 2 * 65536 - 1);
-        pl->J.jzw = zdpcg::jump_map((u128) 2 * 65536 * (u128) (1 + 65536 - N) - 1);
+        // z-walk of k_gen (see zd_device.h GenJumps): forward L rows inside a fold, then back to the
+        // first term of the next k2; crossing z = N/2 shifts the counter row by +-(65536 - N)
+        const long long wrap = 65536 - N, Lr = pl->L, back = -((long long) (R - 1) * Lr - 1);
+        pl->J.fwd[0]  = row_jump(Lr);
+        pl->J.fwd[1]  = row_jump(Lr + wrap);
+        pl->J.back[0] = row_jump(back);
+        pl->J.back[1] = row_jump(back > 0 ? back + wrap : back - wrap);
     }
     {
         std::vector<cplx> twN = make_twiddles(pl->N), twL = make_twiddles(pl->L);
@@ -274,15 +295,37 @@ int zd_plan_create(const zd_params *p, const zd_pk *pk, const double *eig, int64
             pl->jobs.kind[pl->jobs.n++] = zd::JOB_D_TWIN;
         }
     }
-    // ---- block store layout: [chunk = peer rank][plane][array][2*Hq rows][N] ----
+    // ---- block store layout (zd_device.h StoreLayout): chunks per peer rank, ~2 MB tiles inside ----
     zd::StoreLayout &S = pl->S;
-    S.N            = pl->N;
-    S.half         = pl->half;
-    S.Hq           = pl->Hq;
-    S.narray       = pl->narray;
-    S.a_stride     = (long long) 2 * pl->Hq * pl->N;
-    S.z_stride     = S.a_stride * pl->narray;
-    S.chunk_stride = S.z_stride * pl->Zq;
+    S.N      = pl->N;
+    S.half   = pl->half;
+    S.Hq     = pl->Hq;
+    S.narray = pl->narray;
+    {
+        const long long target = std::max<long long>(1, ((long long) 2 << 20) / ((long long) pl->N * 16));
+        int lt = 0;
+        while ((1LL << (lt + 1)) <= target) lt++;
+        int lBk = (lt + 1) / 2, lBz = lt - lBk;
+        S.rows_outer = 0;
+        lBk = 20; lBz = 0;  // measured best on MI355X (profiles/r01_layout_sweep.txt): rows of one plane together
+        if (const char *env = getenv("ZD_LAYOUT")) {  // experimentation knob: "lBk,lBz,rows_outer"
+            int a = lBk, b = lBz, o = 0;
+            if (sscanf(env, "%d,%d,%d", &a, &b, &o) >= 2) {
+                lBk = a; lBz = b; S.rows_outer = o;
+            }
+        }
+        while ((1 << lBk) > pl->Hq) lBk--;
+        while ((1 << lBz) > pl->Zq) lBz--;
+        S.lBk = lBk;
+        S.lBz = lBz;
+        int row_pad = 0, arr_pad = 0, plane_pad = 0;  // in complex elements
+        if (const char *env = getenv("ZD_PAD")) sscanf(env, "%d,%d,%d", &row_pad, &arr_pad, &plane_pad);
+        S.pitch        = pl->N + row_pad;
+        S.a_stride     = (((long long) S.pitch << lBk) << lBz) + arr_pad;
+        S.zb_stride    = S.a_stride * pl->narray + plane_pad;
+        S.kb_stride    = S.zb_stride * (pl->Zq >> lBz);
+        S.chunk_stride = S.kb_stride * ((2 * pl->Hq) >> lBk);
+    }
 
     pl->ec.N        = pl->N;
     pl->ec.narray   = pl->narray;
@@ -292,25 +335,14 @@ int zd_plan_create(const zd_params *p, const zd_pk *pk, const double *eig, int64
     pl->ec.qdensity = p->qdensity;
     pl->ec.vnorm    = p->qPLT ? 1.0 : (sqrt(1. + 24 * p->f_cluster) - 1) * .25;  // output.cpp:78-82
 
-    // ---- mode buffers: cache everything when streaming (R > 1) and it fits, else slabs ----
+    // ---- folded-input slab: enough rows to fill the chip, bounded to ~1 GB ----
     {
-        const int64_t row_b = mode_bytes_per_row(pl);
-        size_t free_b = 0, total_b = 0;
-        PLCHECK(hipMemGetInfo(&free_b, &total_b));
-        const int64_t store_b = zd_plan_exchange_bytes(pl) * (nranks > 1 ? 2 : 1);
-        const int64_t all_b   = row_b * pl->Hq;
-        const int64_t avail   = (int64_t) free_b - store_b - ((int64_t) 3 << 30);
-        int rows = (int) std::max<int64_t>(1, ((int64_t) 256 << 20) / row_b);
+        const int64_t row_b = y_bytes_per_row(pl);
+        int rows = (int) std::max<int64_t>(1, ((int64_t) 1 << 30) / row_b);
         rows     = std::min(rows, pl->Hq);
         while (pl->Hq % rows) rows--;
         pl->slab_rows = rows;
-        pl->cache_all = (pl->R > 1) && all_b <= avail;
-        if (pl->R == 1 && all_b <= ((int64_t) 256 << 20)) pl->slab_rows = pl->Hq;
-        const int64_t nb = pl->cache_all ? all_b : row_b * pl->slab_rows;
-        const int64_t nrows = pl->cache_all ? pl->Hq : pl->slab_rows;
-        PLCHECK(hipMalloc((void **) &pl->d_D, (size_t) nrows * pl->N * pl->N * 16));
-        if (p->qPLT) PLCHECK(hipMalloc((void **) &pl->d_P, (size_t) nrows * pl->N * pl->N * 32));
-        (void) nb;
+        PLCHECK(hipMalloc((void **) &pl->d_Y, (size_t) row_b * rows));
     }
 #undef PLCHECK
     *out = pl;
@@ -321,13 +353,13 @@ void zd_plan_destroy(zd_plan *pl) {
     if (!pl) return;
     collect_events(pl);
     hipFree(pl->d_pk);
+    hipFree(pl->d_lut);
     hipFree(pl->d_eig);
     hipFree(pl->d_rowstate);
     hipFree(pl->d_twN);
     hipFree(pl->d_twL);
     hipFree(pl->d_red);
-    hipFree(pl->d_D);
-    hipFree(pl->d_P);
+    hipFree(pl->d_Y);
     delete pl;
 }
 
@@ -343,27 +375,17 @@ int64_t zd_plan_plane_z(const zd_plan *pl, int residue, int64_t local_plane) {
 int zd_plan_stage_z(zd_plan *pl, int residue, void *d_send, void *hip_stream) {
     hipStream_t st = (hipStream_t) hip_stream;
     if (residue < 0 || residue >= pl->R) return 1;
-    // residue 0 starts a new realisation pass: the cached amplitudes are only reused by the later
-    // residues of the SAME pass (every pass pays for its own mode generation)
-    if (residue == 0) pl->cache_valid = false;
     const int ky_first = pl->rank * pl->Hq;
     for (int r0 = 0; r0 < pl->Hq; r0 += pl->slab_rows) {
-        const int nky   = std::min(pl->slab_rows, pl->Hq - r0);
-        const size_t mo = pl->cache_all ? (size_t) r0 * pl->N * pl->N : 0;
-        cplx *D   = pl->d_D + mo;
-        double *P = pl->d_P ? pl->d_P + 4 * mo : nullptr;
-        if (!(pl->cache_all && pl->cache_valid && residue != 0)) {
-            tick(pl, ZD_K_GEN, st, true);
-            if (zd::launch_gen(pl->g, pl->J, ky_first + r0, nky, D, P, st)) return 1;
-            tick(pl, ZD_K_GEN, st, false);
-        }
+        const int nky = std::min(pl->slab_rows, pl->Hq - r0);
+        tick(pl, ZD_K_GEN, st, true);
+        if (zd::launch_gen(pl->g, pl->J, pl->jobs, ky_first + r0, nky, pl->L, residue, pl->d_twN, pl->d_Y, st)) return 1;
+        tick(pl, ZD_K_GEN, st, false);
         tick(pl, ZD_K_ZFFT, st, true);
-        if (zd::launch_zfft(pl->L, pl->g, pl->jobs, pl->S, ky_first + r0, r0, nky, residue, pl->Zq, D, P, pl->d_twN,
-                            pl->d_twL, d_send, st))
+        if (zd::launch_zfft(pl->L, pl->jobs, pl->S, ky_first + r0, r0, nky, pl->Zq, pl->d_Y, pl->d_twL, d_send, st))
             return 1;
         tick(pl, ZD_K_ZFFT, st, false);
     }
-    if (pl->cache_all && residue == 0) pl->cache_valid = true;
     return 0;
 }
 
@@ -418,7 +440,7 @@ int zd_plan_stats(zd_plan *pl, zd_stats *out) {
     }
     out->bytes_intermediate = zd_plan_exchange_bytes(pl);
     out->stream_factor      = pl->R;
-    out->modes_cached       = pl->cache_all ? 1 : 0;
+    out->modes_cached       = 0;  // modes are regenerated per residue pass (counter-addressed RNG)
     return 0;
 }
 
@@ -430,8 +452,8 @@ int zd_generate(const zd_params *p_in, const zd_pk *pk, const double *eig, int64
     size_t free_b = 0, total_b = 0;
     HIPCHECK(hipMemGetInfo(&free_b, &total_b));
     if (p.stream_factor <= 0) {
-        // keep ~12% of HBM + 6 GB for tables, mode slabs, the record ring and the runtime
-        const int64_t budget = (int64_t) ((double) free_b * 0.88) - ((int64_t) 6 << 30);
+        // leave 12 GB for tables, the folded-input slab (~1 GB), the record ring and the runtime
+        const int64_t budget = (int64_t) free_b - ((int64_t) 12 << 30);
         const int R = zd_choose_stream_factor(&p, 1, budget);
         if (R < 0) {
             fprintf(stderr, "zeldovich_hip: PPD %lld does not fit in %.1f GB of free HBM at any stream factor\n",
@@ -603,6 +625,50 @@ int zd_test_fft(int32_t n, int64_t lines, int32_t axis_kind, const double *in, d
     hipFree(d_tw);
     hipFree(d_in);
     hipFree(d_out);
+    return rc;
+}
+
+// tuning harness (not part of the product path): time y-pass tile variants on a synthetic store
+int zd_test_yfft_variant(int32_t n, int32_t variant, int32_t narray, int32_t nplanes, int32_t tiled, int32_t reps,
+                         double *ms_per_launch) {
+    zd::StoreLayout S;
+    S.N = n; S.half = n / 2; S.Hq = n / 2; S.narray = narray;
+    int lBk = 0, lBz = 0;
+    if (tiled) {
+        const long long target = std::max<long long>(1, ((long long) 2 << 20) / ((long long) n * 16));
+        int lt = 0;
+        while ((1LL << (lt + 1)) <= target) lt++;
+        lBk = (lt + 1) / 2; lBz = lt - lBk;
+        while ((1 << lBz) > nplanes) lBz--;
+    }
+    S.lBk = lBk; S.lBz = lBz; S.rows_outer = 0; S.pitch = n;
+    S.a_stride = ((long long) n << lBk) << lBz;
+    S.zb_stride = S.a_stride * narray;
+    S.kb_stride = S.zb_stride * (nplanes >> lBz);
+    S.chunk_stride = S.kb_stride * (n >> lBk);
+    std::vector<cplx> tw = make_twiddles(n);
+    cplx *d_tw = nullptr, *d = nullptr;
+    const size_t nb = (size_t) S.chunk_stride * 16;
+    int rc = 1;
+    do {
+        if (hipMalloc((void **) &d_tw, sizeof(cplx) * n) != hipSuccess) break;
+        if (hipMalloc((void **) &d, nb) != hipSuccess) break;
+        hipMemcpy(d_tw, tw.data(), sizeof(cplx) * n, hipMemcpyHostToDevice);
+        hipMemset(d, 0, nb);
+        if (zd::launch_yfft_variant(variant, S, nplanes, d_tw, d, 0)) break;
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0, 0);
+        for (int i = 0; i < reps; i++) zd::launch_yfft_variant(variant, S, nplanes, d_tw, d, 0);
+        hipEventRecord(e1, 0);
+        if (hipEventSynchronize(e1) != hipSuccess) break;
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        *ms_per_launch = ms / reps;
+        hipEventDestroy(e0); hipEventDestroy(e1);
+        rc = 0;
+    } while (0);
+    hipFree(d_tw); hipFree(d);
     return rc;
 }
 

@@ -6,6 +6,8 @@
 
 namespace zd {
 
+constexpr int PK_LUT = 2048;
+
 // Everything the mode generator needs (restates the per-run scalars of LoadPlane,
 // src/zeldovich.cpp:299-320, and the PowerSpectrum members used by power()/cgauss<2>).
 struct GenConst {
@@ -13,10 +15,13 @@ struct GenConst {
     int kmax;          // int(double(N/2)/k_cutoff + .5)           zeldovich.cpp:350
     int corner_modes;  //                                          zeldovich.cpp:353
     int qonemode, one_mode[3];
+    int ablate;        // debug/tuning only (ZD_ABLATE env): skip parts of the generator; 0 in production
     double fundamental, fundamental2, k2_cutoff;
     // PowerSpectrum
     int pk_n, fixed_power, is_powerlaw;
     const double *pk_x, *pk_y, *pk_y2;
+    const int *pk_lut;        // PK_LUT uniform cells over [x0, x_last] -> start segment
+    double lut_x0, lut_inv_dx;
     double pk_norm, pk_smooth2, powerlaw_index;
     // PLT
     int qPLT, qPLTrescale;
@@ -29,23 +34,34 @@ struct GenConst {
 
 // Affine maps used by the generator's z-walk (set per launch geometry)
 struct GenJumps {
-    zdpcg::Affine jz;   // next row, same x:            advance 2*65536 - 1      (state kept one ahead)
-    zdpcg::Affine jzw;  // next row across z = N/2:     advance 2*65536*(1 + 65536 - N) - 1
+    // The generator keeps its state ONE draw ahead of the mode's counter and consumes two draws per
+    // mode, so each map advances (2*65536*drows - 1) draws; index 1 = the step crosses the z = N/2
+    // wrap of the counter (rows N/2+1.. live at 65536-N+z, zeldovich.cpp:335).
+    zdpcg::Affine fwd[2];   // z -> z + L         (next residue-fold term)
+    zdpcg::Affine back[2];  // z -> z - (R-1)L + 1 (first term of the next k2; for R = 1: the next row)
 };
 
 // Addressing of the z-transformed block store ("BlockArray", include/block_array.h:26-35, re-laid
-// out for the GPU): element (plane zl, array a, row ky, column kx) of chunk `c` lives at
-//      c*chunk_stride + zl*z_stride + a*a_stride + loc(ky)*N + kx          [complex doubles]
-// where rows are grouped by the rank that generated them: rank g holds half-space rows
-// [g*Hq,(g+1)*Hq) at loc 0..Hq-1 and their Hermitian twins at loc Hq..2Hq-1 — the reference's
+// out for the GPU).  Rows are grouped by the rank that generated them: rank g holds half-space rows
+// [g*Hq,(g+1)*Hq) at slots 0..Hq-1 and their Hermitian twins at slots Hq..2Hq-1 — the reference's
 // "displaced twin" storage (zeldovich.cpp:453-466, block_array.cpp:487-491); the unused twin slot of
 // ky = 0 is the Nyquist row ky = N/2, which is never read (treated as zero, zeldovich.cpp:644-650).
+//
+// Inside a chunk (= what one peer rank sends) the store is tiled in blocks of Bz planes x Bk row
+// slots x N columns (~2 MB, one large page): the z stage writes ALL planes of a few rows and the y
+// stage reads ALL rows of a few planes, so a plain [plane][row] or [row][plane] order makes one of
+// them touch a different page (and the same HBM channel) with every access; with the tiling both
+// touch N/8-ish pages per workgroup.  Element (chunk c, local plane zl, array a, slot s, column x):
+//   c*chunk_stride + (s/Bk)*kb_stride + (zl/Bz)*zb_stride + a*a_stride + ((zl%Bz)*Bk + s%Bk)*N + x
 struct StoreLayout {
     int N, half, Hq, narray;
-    long long chunk_stride, z_stride, a_stride;
+    int lBk, lBz;  // log2 of the block edge in row slots / planes
+    int rows_outer; // order inside a block: 0 = [plane][slot][x], 1 = [slot][plane][x]
+    int pitch;      // row pitch in elements (>= N; padding de-aliases power-of-two strides)
+    long long chunk_stride, kb_stride, zb_stride, a_stride;
 };
 
-ZD_HD long long row_offset(const StoreLayout &L, int ky) {  // chunk (source rank) + loc for row ky
+ZD_HD void row_slot(const StoreLayout &L, int ky, int &chunk, int &slot) {
     int kyh, tw;
     if (ky < L.half) {
         kyh = ky;
@@ -57,8 +73,21 @@ ZD_HD long long row_offset(const StoreLayout &L, int ky) {  // chunk (source ran
         kyh = L.N - ky;
         tw  = 1;
     }
-    const int src = kyh / L.Hq, loc = kyh - src * L.Hq + tw * L.Hq;
-    return (long long) src * L.chunk_stride + (long long) loc * L.N;
+    chunk = kyh / L.Hq;
+    slot  = kyh - chunk * L.Hq + tw * L.Hq;
+}
+// offset of column 0 of (chunk, local plane zl, array a, row slot)
+ZD_HD long long store_offset(const StoreLayout &L, int chunk, int zl, int a, int slot) {
+    const int Bk = 1 << L.lBk, Bz = 1 << L.lBz;
+    return (long long) chunk * L.chunk_stride + (long long) (slot >> L.lBk) * L.kb_stride
+           + (long long) (zl >> L.lBz) * L.zb_stride + (long long) a * L.a_stride
+           + (long long) (L.rows_outer ? (((slot & (Bk - 1)) << L.lBz) + (zl & (Bz - 1)))
+                                        : (((zl & (Bz - 1)) << L.lBk) + (slot & (Bk - 1)))) * L.pitch;
+}
+ZD_HD long long row_offset(const StoreLayout &L, int zl, int a, int ky) {
+    int c, s;
+    row_slot(L, ky, c, s);
+    return store_offset(L, c, zl, a, s);
 }
 
 // Jobs of the z stage: which real-linear combination of the mode's fields is transformed and where

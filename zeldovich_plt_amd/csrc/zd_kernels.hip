@@ -37,25 +37,29 @@ __device__ __forceinline__ u128 advance_bits(u128 s, uint64_t delta) {
 }
 
 // PowerSpectrum::power (src/power_spectrum.cpp:225-261) with SplineFunction::val
-// (include/spline_function.h:141-163)
+// (include/spline_function.h:141-163).  The reference bisects for the segment; here a uniform-cell
+// table over ln k gives a start index and a short forward scan lands on exactly the segment the
+// bisection would return (largest klo with x[klo] <= v, clamped to [0, n-2]).
+template <bool PLAW>
 __device__ __forceinline__ double pk_power(const GenConst &g, double k) {
     if (k <= 0.0) return 0.0;
-    if (g.is_powerlaw) return pow(k, g.powerlaw_index) * exp(-k * k * g.pk_smooth2) * g.pk_norm;
-    const double v = log(k);
-    int klo = 0, khi = g.pk_n - 1;
-    while (khi - klo > 1) {
-        const int m = (khi + klo) >> 1;
-        if (g.pk_x[m] > v)
-            khi = m;
-        else
-            klo = m;
+    if constexpr (PLAW) {
+        return pow(k, g.powerlaw_index) * exp(-k * k * g.pk_smooth2) * g.pk_norm;
+    } else {
+        const double v = log(k);
+        int c   = (int) ((v - g.lut_x0) * g.lut_inv_dx);
+        c       = c < 0 ? 0 : (c >= PK_LUT ? PK_LUT - 1 : c);
+        int klo = g.pk_lut[c];
+        const int last = g.pk_n - 2;
+        while (klo < last && g.pk_x[klo + 1] <= v) klo++;
+        const int khi = klo + 1;
+        const double xl = g.pk_x[klo], xh = g.pk_x[khi];
+        const double h = xh - xl;
+        const double a = (xh - v) / h, b = (v - xl) / h;
+        const double val = a * g.pk_y[klo] + b * g.pk_y[khi]
+                           + ((a * a * a - a) * g.pk_y2[klo] + (b * b * b - b) * g.pk_y2[khi]) * (h * h) / 6.0;
+        return exp(val - k * k * g.pk_smooth2) * g.pk_norm;
     }
-    const double xl = g.pk_x[klo], xh = g.pk_x[khi];
-    const double h = xh - xl;
-    const double a = (xh - v) / h, b = (v - xl) / h;
-    const double val = a * g.pk_y[klo] + b * g.pk_y[khi]
-                       + ((a * a * a - a) * g.pk_y2[klo] + (b * b * b - b) * g.pk_y2[khi]) * (h * h) / 6.0;
-    return exp(val - k * k * g.pk_smooth2) * g.pk_norm;
 }
 
 // zero rule of LoadPlane (src/zeldovich.cpp:350-356)
@@ -68,11 +72,17 @@ __device__ __forceinline__ bool mode_is_zero(const GenConst &g, int kx, int ky, 
 }
 
 // cgauss<2> given the two raw draws
+template <bool PLAW>
 __device__ __forceinline__ void gauss_mode(const GenConst &g, double kmag, uint64_t r1, uint64_t r2,
                                            double &dr, double &di) {
-    const double Pk = pk_power(g, kmag);
+    const double Pk = (g.ablate & 1) ? 1e-9 * kmag : pk_power<PLAW>(g, kmag);
     double R        = zdpcg::u01(r1);
     double theta    = zdpcg::u01(r2);
+    if (g.ablate & 2) {
+        dr = R * Pk;
+        di = theta * Pk;
+        return;
+    }
     if (!g.fixed_power)
         R = sqrt(-Pk * log(R));
     else
@@ -112,26 +122,23 @@ __device__ void get_eigenmode_dev(const GenConst &g, int kx, int ky, int kz, dou
         fx -= xl;
         fy -= yl;
         fz -= zl;
-        double f[8];
-        f[0] = (1 - fx) * (1 - fy) * (1 - fz);
-        f[1] = (1 - fx) * (1 - fy) * (fz);
-        f[2] = (1 - fx) * (fy) * (1 - fz);
-        f[3] = (1 - fx) * (fy) * (fz);
-        f[4] = (fx) * (1 - fy) * (1 - fz);
-        f[5] = (fx) * (1 - fy) * (fz);
-        f[6] = (fx) * (fy) * (1 - fz);
-        f[7] = (fx) * (fy) * (fz);
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            double acc = f[0] * ZD_EIG(xl, yl, zl, i);
-            acc += f[1] * (f[1] != 0 ? ZD_EIG(xl, yl, zh, i) : 0.0);
-            acc += f[2] * (f[2] != 0 ? ZD_EIG(xl, yh, zl, i) : 0.0);
-            acc += f[3] * (f[3] != 0 ? ZD_EIG(xl, yh, zh, i) : 0.0);
-            acc += f[4] * (f[4] != 0 ? ZD_EIG(xh, yl, zl, i) : 0.0);
-            acc += f[5] * (f[5] != 0 ? ZD_EIG(xh, yl, zh, i) : 0.0);
-            acc += f[6] * (f[6] != 0 ? ZD_EIG(xh, yh, zl, i) : 0.0);
-            acc += f[7] * (f[7] != 0 ? ZD_EIG(xh, yh, zh, i) : 0.0);
-            eh[i] = acc;
+        // trilinear weights and corners in the reference's order f[0..7] = (x l/h, y l/h, z l/h) with z
+        // fastest; accumulated left to right like the single expression of zeldovich.cpp:218-225.
+        // Corners with zero weight are not read (the reference reads them: same value unless non-finite).
+        eh[0] = eh[1] = eh[2] = eh[3] = 0.0;
+#pragma unroll 1
+        for (int c = 0; c < 8; c++) {
+            const double wx = (c & 4) ? fx : 1 - fx, wy = (c & 2) ? fy : 1 - fy, wz = (c & 1) ? fz : 1 - fz;
+            const double wgt = wx * wy * wz;
+            if (wgt != 0) {
+                const int cx = (c & 4) ? xh : xl, cy = (c & 2) ? yh : yl, cz = (c & 1) ? zh : zl;
+                const double2 *q = reinterpret_cast<const double2 *>(&ZD_EIG(cx, cy, cz, 0));
+                const double2 q0 = q[0], q1 = q[1];
+                eh[0] += wgt * q0.x;
+                eh[1] += wgt * q0.y;
+                eh[2] += wgt * q1.x;
+                eh[3] += wgt * q1.y;
+            }
         }
     }
 #undef ZD_EIG
@@ -149,62 +156,145 @@ __device__ void get_eigenmode_dev(const GenConst &g, int kx, int ky, int kz, dou
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_gen: one thread owns one x and walks ZR consecutive z rows (RNG stride = one affine map).
-//   Dbuf[(kyl*N + z)*N + x]      complex amplitude D(k)          (kyl = ky - ky0)
-//   Pbuf[((kyl*N + z)*N + x)*4]  PLT only: s_x, s_y, s_z, f   with F_j = i s_j D
-// grid: (N/GEN_BX, N/ZR, nky)  block: GEN_BX
-template <int ZR>
-__global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, int ky0, cplx *__restrict__ Dbuf,
-                                                double *__restrict__ Pbuf) {
-    const int N = g.N, half = g.half;
-    const int x  = blockIdx.x * GEN_BX + threadIdx.x;
-    const int z0 = blockIdx.y * ZR;
-    const int ky = ky0 + blockIdx.z;
+// k_gen: mode generation fused with the Hermitian job algebra and the z-residue fold.
+//   One thread owns one x and ZR consecutive k2 (k2 < L = N/R).  For each k2 it visits the R modes
+//   kz-index z = k2 + L*k1, draws D(k), forms the NJ job inputs c_j(k) D(k) and accumulates
+//        Y_j[k2] = W_N^{k2 r} * sum_k1 W_R^{k1 r} c_j D            (r = residue)
+//   i.e. the decimation-in-frequency fold, so that k_zfft only has to run length-L FFTs.
+//   The RNG walk is z-major with two stride maps (forward L rows; back to the next k2), each with a
+//   variant for crossing the z = N/2 wrap of the counter (zeldovich.cpp:335).
+//   ky = 0: "loser" positions take the conjugate of the winner's mode (zeldovich.cpp:485-503); that
+//   plane uses direct counter addressing per mode (1 of N/2 planes).
+//   Y[((j*nky + kyl)*L + k2)*N + x]   complex
+// grid: (ceil(N/GEN_BX), L/ZR, nky)  block: GEN_BX
+template <int ZR, int NJ, bool PLT, bool PLAW>
+__global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, JobList jobs, int ky0, int nky, int L,
+                                                int residue, const cplx *__restrict__ twN,
+                                                cplx *__restrict__ Y) {
+    const int N = g.N, half = g.half, R = N / L;
+    const int x   = blockIdx.x * GEN_BX + threadIdx.x;
+    const int k20 = blockIdx.y * ZR;
+    const int kyl = blockIdx.z;
+    const int ky  = ky0 + kyl;
     if (x >= N) return;
     const int kx = x > half ? x - N : x;
-    // state one step ahead of the first mode's counter
-    u128 s;
-    {
-        const int kz0 = z0 > half ? z0 - N : z0;
+    u128 s = 0;
+    if (ky != 0) {  // state one step ahead of the first mode's counter
+        const int kz0 = k20 > half ? k20 - N : k20;  // k20 > N/2 only happens when R = 1
         const uint64_t off = 2ULL * ((uint64_t) (kz0 & 65535) * 65536ULL + (uint64_t) (kx & 65535)) + 1ULL;
         s = advance_bits(g.row_state[ky], off);
     }
-    const long long rowbase = ((long long) blockIdx.z * N) * N;
 #pragma unroll 1
     for (int zi = 0; zi < ZR; zi++) {
-        const int z  = z0 + zi;
-        const int kz = z > half ? z - N : z;
-        const uint64_t r1 = zdpcg::output(s);
-        const u128 s2     = zdpcg::step(s);
-        const uint64_t r2 = zdpcg::output(s2);
-        s = zdpcg::apply(z == half ? J.jzw : J.jz, s2);
-
-        const int k2i = kx * kx + ky * ky + kz * kz;
-        double k2     = (double) k2i * g.fundamental2;
-        double dr = 0.0, di = 0.0;
-        if (!mode_is_zero(g, kx, ky, kz, k2)) gauss_mode(g, sqrt(k2), r1, r2, dr, di);
-        const long long idx = rowbase + (long long) z * N + x;
-        Dbuf[idx] = cplx{dr, di};
-        if (g.qPLT) {
-            double sx = 0, sy = 0, sz = 0, f = 0;
-            if (dr != 0.0 || di != 0.0) {
+        const int k2 = k20 + zi;
+        double accr[NJ], acci[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; j++) accr[j] = acci[j] = 0.0;
+#pragma unroll 1
+        for (int k1 = 0; k1 < R; k1++) {
+            const int z = k2 + L * k1;
+            // ---- which mode feeds (ky, z, x), and its two raw draws ----
+            int zs = z, xs = x;
+            bool cj = false, zero = false;
+            uint64_t r1, r2;
+            if (ky != 0) {
+                r1 = zdpcg::output(s);
+                const u128 s2 = (g.ablate & 4) ? s + 12345 : zdpcg::step(s);
+                r2 = zdpcg::output(s2);
+                // next mode of the walk
+                int zb;
+                const zdpcg::Affine *m;
+                if (k1 + 1 < R) {
+                    zb = z + L;
+                    m  = &J.fwd[(z > half) != (zb > half)];
+                } else {
+                    zb = k2 + 1;
+                    m  = &J.back[(z > half) != (zb > half)];
+                }
+                s = (g.ablate & 4) ? s2 + m->C : zdpcg::apply(*m, s2);
+            } else {
+                if (z > half) {
+                    zs = N - z;
+                    xs = (N - x) & (N - 1);
+                    cj = true;
+                } else if (z == 0) {
+                    if (x == 0)
+                        zero = true;
+                    else if (x > half) {
+                        xs = N - x;
+                        cj = true;
+                    }
+                }
+                const int kxs = xs > half ? xs - N : xs, kzs = zs > half ? zs - N : zs;
+                u128 t = advance_bits(g.row_state[0], 2ULL * ((uint64_t) (kzs & 65535) * 65536ULL + (uint64_t) (kxs & 65535)) + 1ULL);
+                r1 = zdpcg::output(t);
+                r2 = zdpcg::output(zdpcg::step(t));
+            }
+            const int kxm = xs > half ? xs - N : xs, kzm = zs > half ? zs - N : zs;  // generated mode
+            const int k2i = kxm * kxm + ky * ky + kzm * kzm;
+            double k2v    = (double) k2i * g.fundamental2;
+            double dr = 0.0, di = 0.0;
+            if (!zero && !mode_is_zero(g, kxm, ky, kzm, k2v)) gauss_mode<PLAW>(g, sqrt(k2v), r1, r2, dr, di);
+            if (dr == 0.0 && di == 0.0) continue;  // zero modes add nothing (zeldovich.cpp:403,435-438)
+            if (k2v == 0.0) k2v = 1.0;
+            const double ik2 = 1.0 / k2v;
+            double sx, sy, sz, f = 1.0;
+            if constexpr (PLT) {
                 double e[4];
-                get_eigenmode_dev(g, kx, ky, kz, e);
-                if (k2 == 0.0) k2 = 1.0;
-                const double ik2 = 1.0 / k2;
+                if (g.ablate & 8) {
+                    e[0] = kxm; e[1] = ky; e[2] = kzm; e[3] = 1.0 - 1e-9 * k2i;
+                } else
+                    get_eigenmode_dev(g, kxm, ky, kzm, e);
                 f = (sqrt(1. + 24 * e[3] * g.f_cluster) - 1) * .25;
                 double rescale = 1.0;
                 if (g.qPLTrescale) rescale = exp(g.ln_growth_ratio * (g.target_f - f));
                 sx = rescale * e[0] * g.fundamental * ik2;
                 sy = rescale * e[1] * g.fundamental * ik2;
                 sz = rescale * e[2] * g.fundamental * ik2;
+            } else {
+                sx = (double) kxm * g.fundamental * ik2;
+                sy = (double) ky * g.fundamental * ik2;
+                sz = (double) kzm * g.fundamental * ik2;
             }
-            double4 pv;
-            pv.x = sx;
-            pv.y = sy;
-            pv.z = sz;
-            pv.w = f;
-            reinterpret_cast<double4 *>(Pbuf)[idx] = pv;
+            if (cj) {  // conjugated copy of the mode at -k: D -> conj D, s -> -s(-k)
+                di = -di;
+                sx = -sx;
+                sy = -sy;
+                sz = -sz;
+            }
+            if (R > 1) {  // W_R^{k1 r}
+                const cplx w = twN[(int) (((long long) k1 * residue * L) & (N - 1))];
+                const double a = dr * w.x - di * w.y, b = dr * w.y + di * w.x;
+                dr = a;
+                di = b;
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                double cr, ci;
+                switch (jobs.kind[j]) {
+                    case JOB_A_SELF: cr = 1.0 - sx; ci = 0.0; break;
+                    case JOB_A_TWIN: cr = 1.0 + sx; ci = 0.0; break;
+                    case JOB_B_SELF: cr = -sz; ci = sy; break;
+                    case JOB_B_TWIN: cr = sz; ci = sy; break;
+                    case JOB_C_BOTH: cr = -f * sx; ci = 0.0; break;
+                    case JOB_D_SELF: cr = -f * sz; ci = f * sy; break;
+                    case JOB_D_TWIN: cr = f * sz; ci = f * sy; break;
+                    default: cr = 1.0; ci = 0.0; break;
+                }
+                accr[j] += cr * dr - ci * di;
+                acci[j] += cr * di + ci * dr;
+            }
+        }
+        double pr = 1.0, pi = 0.0;  // W_N^{k2 r}
+        if (R > 1) {
+            const cplx w = twN[(int) (((long long) k2 * residue) & (N - 1))];
+            pr = w.x;
+            pi = w.y;
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const long long idx = (((long long) j * nky + kyl) * L + k2) * N + x;
+            Y[idx] = cplx{accr[j] * pr - acci[j] * pi, accr[j] * pi + acci[j] * pr};
         }
     }
 }
@@ -228,125 +318,50 @@ __global__ void k_test_modes(GenConst g, long long n, const int *__restrict__ kx
     if (D) {
         const double k2 = (double) (kx * kx + ky * ky + kz * kz) * g.fundamental2;
         double dr = 0, di = 0;
-        if (!mode_is_zero(g, kx, ky, kz, k2)) gauss_mode(g, sqrt(k2), r1, r2, dr, di);
+        if (!mode_is_zero(g, kx, ky, kz, k2)) {
+            if (g.is_powerlaw)
+                gauss_mode<true>(g, sqrt(k2), r1, r2, dr, di);
+            else
+                gauss_mode<false>(g, sqrt(k2), r1, r2, dr, di);
+        }
         D[2 * i]     = dr;
         D[2 * i + 1] = di;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_zfft: for half-space row ky and a W-wide column tile, build the FFT input of one job from the
-// mode amplitudes (Hermitian bookkeeping done algebraically: each output column of each packed
-// array is ONE complex FFT of c(k)*D(k)), fold the R = N/L residues, transform, store.
+// k_zfft: length-L FFT of one job's folded inputs for a W-wide column tile of row ky, then the
+// Hermitian stores: "self" columns at (row ky, column x), "twin" columns conjugated at
+// (row N-ky, column N-x) — same plane index, see DESIGN.md §2.2.  Replaces InverseFFT_Yonly +
+// StoreBlock (zeldovich.cpp:508-511, block_array.cpp:387-414).
 //   grid: (N/W, nky, njobs)   block: W*L/E
 template <int L, int E, int W>
-__global__ __launch_bounds__(W *L / E) void k_zfft(GenConst g, JobList jobs, StoreLayout S, int ky0, int kyloc0,
-                                                  int residue, int Zq, const cplx *__restrict__ Dbuf,
-                                                  const double *__restrict__ Pbuf,
-                                                  const cplx *__restrict__ twN, const cplx *__restrict__ twL,
+__global__ __launch_bounds__(W *L / E) void k_zfft(JobList jobs, StoreLayout S, int ky0, int kyloc0, int nky, int Zq,
+                                                  const cplx *__restrict__ Y, const cplx *__restrict__ twL,
                                                   cplx *__restrict__ out) {
     using PL  = zdfft::Plan<L, E>;
     using LDS = zdfft::ColsInner<L, W>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int T = PL::T;
-    const int N = g.N, half = g.half, R = N / L;
+    const int N = S.N;
     const int w = threadIdx.x % W, t = threadIdx.x / W;
     const int x   = blockIdx.x * W + w;
-    const int kyl = blockIdx.y;  // row inside the generated slab
+    const int kyl = blockIdx.y;
     const int ky  = ky0 + kyl;
     const int kind = jobs.kind[blockIdx.z];
     const bool twin_only = (kind == JOB_A_TWIN || kind == JOB_B_TWIN || kind == JOB_D_TWIN);
     if (ky == 0 && twin_only) return;  // ky = 0 is its own twin plane: every column written as "self"
 
-    const int kx = x > half ? x - N : x;
+    const cplx *src = Y + (((long long) blockIdx.z * nky + kyl) * L) * N + x;
     double re[E], im[E];
 #pragma unroll
-    for (int e = 0; e < E; e++) re[e] = im[e] = 0.0;
-
-    for (int k1 = 0; k1 < R; k1++) {
-        double fr = 1.0, fi = 0.0;  // W_R^{k1 * residue}
-        if (R > 1) {
-            const cplx f = twN[(int) (((long long) k1 * residue * L) & (N - 1))];
-            fr = f.x;
-            fi = f.y;
-        }
-#pragma unroll
-        for (int e = 0; e < E; e++) {
-            const int z = t + T * e + L * k1;
-            // which generated mode feeds (ky, z, x)?  For ky = 0 the reference copies the conjugate
-            // half-plane back (zeldovich.cpp:485-503): losers take conj of the mode at -k.
-            int zs = z, xs = x;
-            bool cj = false, zero = false;
-            if (ky == 0) {
-                if (z > half) {
-                    zs = N - z;
-                    xs = (N - x) & (N - 1);
-                    cj = true;
-                } else if (z == 0) {
-                    if (x == 0)
-                        zero = true;
-                    else if (x > half) {
-                        xs = N - x;
-                        cj = true;
-                    }
-                }
-            }
-            const long long idx = ((long long) kyl * N + zs) * N + xs;
-            cplx D = Dbuf[idx];
-            if (zero) D.x = D.y = 0.0;
-            if (cj) D.y = -D.y;
-            double sx, sy, sz, f = 1.0;
-            if (g.qPLT) {
-                const double4 pv = reinterpret_cast<const double4 *>(Pbuf)[idx];
-                const double sg  = cj ? -1.0 : 1.0;  // s(k) = -s(-k) for the conjugated copy
-                sx = sg * pv.x;
-                sy = sg * pv.y;
-                sz = sg * pv.z;
-                f  = pv.w;
-            } else {
-                const int kz = z > half ? z - N : z;
-                double k2    = (double) (kx * kx + ky * ky + kz * kz) * g.fundamental2;
-                if (k2 == 0.0) k2 = 1.0;
-                const double ik2 = 1.0 / k2;
-                sx = (double) kx * g.fundamental * ik2;
-                sy = (double) ky * g.fundamental * ik2;
-                sz = (double) kz * g.fundamental * ik2;
-            }
-            double cr, ci;
-            switch (kind) {
-                case JOB_A_SELF: cr = 1.0 - sx; ci = 0.0; break;
-                case JOB_A_TWIN: cr = 1.0 + sx; ci = 0.0; break;
-                case JOB_B_SELF: cr = -sz; ci = sy; break;
-                case JOB_B_TWIN: cr = sz; ci = sy; break;
-                case JOB_C_BOTH: cr = -f * sx; ci = 0.0; break;
-                case JOB_D_SELF: cr = -f * sz; ci = f * sy; break;
-                case JOB_D_TWIN: cr = f * sz; ci = f * sy; break;
-                default: cr = 1.0; ci = 0.0; break;
-            }
-            double vr = cr * D.x - ci * D.y, vi = cr * D.y + ci * D.x;
-            if (R > 1) {
-                const double a = vr * fr - vi * fi, b = vr * fi + vi * fr;
-                vr = a;
-                vi = b;
-            }
-            re[e] += vr;
-            im[e] += vi;
-        }
+    for (int e = 0; e < E; e++) {
+        const cplx v = src[(long long) (t + T * e) * N];
+        re[e] = v.x;
+        im[e] = v.y;
     }
-    if (R > 1) {  // W_N^{k2 * residue}
-#pragma unroll
-        for (int e = 0; e < E; e++) {
-            const int k2 = t + T * e;
-            const cplx f = twN[(int) (((long long) k2 * residue) & (N - 1))];
-            const double a = re[e] * f.x - im[e] * f.y, b = re[e] * f.y + im[e] * f.x;
-            re[e] = a;
-            im[e] = b;
-        }
-    }
-
     zdfft::fft_line<PL, LDS>(re, im, t, w, lds, twL);
 
-    // store: plane index z2 = t + T*e of this residue pass; destination chunk = owner of that plane
     const int arr = (kind == JOB_A_SELF || kind == JOB_A_TWIN || kind == JOB_DENS) ? 0
                     : (kind == JOB_B_SELF || kind == JOB_B_TWIN)                    ? 1
                     : (kind == JOB_C_BOTH)                                          ? 2
@@ -359,8 +374,7 @@ __global__ __launch_bounds__(W *L / E) void k_zfft(GenConst g, JobList jobs, Sto
     for (int e = 0; e < E; e++) {
         const int z2 = t + T * e;
         const int dst = z2 / Zq, zl = z2 - dst * Zq;
-        const long long base = (long long) dst * S.chunk_stride + (long long) zl * S.z_stride + (long long) arr * S.a_stride;
-        if (st_self) out[base + (long long) loc_self * N + x] = cplx{re[e], im[e]};
+        if (st_self) out[store_offset(S, dst, zl, arr, loc_self) + x] = cplx{re[e], im[e]};
         if (st_twin) {
             cplx v;
             if (kind == JOB_C_BOTH) {
@@ -370,22 +384,23 @@ __global__ __launch_bounds__(W *L / E) void k_zfft(GenConst g, JobList jobs, Sto
                 v.x = re[e];
                 v.y = -im[e];
             }
-            out[base + (long long) loc_twin * N + xt] = v;
+            out[store_offset(S, dst, zl, arr, loc_twin) + xt] = v;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // k_yfft: in-place y FFT of the block store.  grid: (N/W, narray, nplanes)  block: W*N/E
-template <int N, int E, int W>
-__global__ __launch_bounds__(W *N / E) void k_yfft(StoreLayout S, const cplx *__restrict__ tw, cplx *__restrict__ data) {
+template <int N, int E, int W, int MINW = 1>
+__global__ __launch_bounds__(W *N / E, MINW) void k_yfft(StoreLayout S, const cplx *__restrict__ tw, cplx *__restrict__ data) {
     using PL  = zdfft::Plan<N, E>;
     using LDS = zdfft::ColsInner<N, W>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int T = PL::T;
     const int w = threadIdx.x % W, t = threadIdx.x / W;
     const int x = blockIdx.x * W + w;
-    cplx *base = data + (long long) blockIdx.z * S.z_stride + (long long) blockIdx.y * S.a_stride + x;
+    cplx *base = data + x;
+    const int zl = blockIdx.z, a = blockIdx.y;
     double re[E], im[E];
 #pragma unroll
     for (int e = 0; e < E; e++) {
@@ -393,14 +408,14 @@ __global__ __launch_bounds__(W *N / E) void k_yfft(StoreLayout S, const cplx *__
         if (ky == N / 2) {  // Nyquist row is identically zero (zeldovich.cpp:644-650)
             re[e] = im[e] = 0.0;
         } else {
-            const cplx v = base[row_offset(S, ky)];
+            const cplx v = base[row_offset(S, zl, a, ky)];
             re[e] = v.x;
             im[e] = v.y;
         }
     }
     zdfft::fft_line<PL, LDS>(re, im, t, w, lds, tw);
 #pragma unroll
-    for (int e = 0; e < E; e++) base[row_offset(S, t + T * e)] = cplx{re[e], im[e]};
+    for (int e = 0; e < E; e++) base[row_offset(S, zl, a, t + T * e)] = cplx{re[e], im[e]};
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -422,7 +437,7 @@ __global__ __launch_bounds__(ROWS *NA *N / E) void k_xfft(StoreLayout S, EpiCons
     const int row = line / NA, a = line % NA;
     const int y  = blockIdx.x * ROWS + row;
     const int pl = plane0 + blockIdx.y;  // local plane index inside the store
-    const cplx *src = data + (long long) pl * S.z_stride + (long long) a * S.a_stride + row_offset(S, y);
+    const cplx *src = data + row_offset(S, pl, a, y);
     double re[E], im[E];
 #pragma unroll
     for (int e = 0; e < E; e++) {
@@ -624,14 +639,30 @@ __global__ void k_copy16(const uint4 *__restrict__ in, uint4 *__restrict__ out, 
 
 namespace zd {
 
-int launch_gen(const GenConst &g, const GenJumps &J, int ky0, int nky, void *Dbuf, void *Pbuf, hipStream_t st) {
+template <int NJ, bool PLT, bool PLAW>
+static int launch_gen_t(const GenConst &g, const GenJumps &J, const JobList &jobs, int ky0, int nky, int L, int residue,
+                        const void *twN, void *Y, hipStream_t st) {
     const int N = g.N;
-    const int bx = (N + GEN_BX - 1) / GEN_BX;
-    if (N % GEN_ZR != 0) return 2;
-    dim3 grid(bx, N / GEN_ZR, nky), block(GEN_BX);
-    hipLaunchKernelGGL(k_gen<GEN_ZR>, grid, block, 0, st, g, J, ky0, (cplx *) Dbuf, (double *) Pbuf);
+    dim3 grid((N + GEN_BX - 1) / GEN_BX, L / GEN_ZR, nky), block(GEN_BX);
+    hipLaunchKernelGGL((k_gen<GEN_ZR, NJ, PLT, PLAW>), grid, block, 0, st, g, J, jobs, ky0, nky, L, residue,
+                       (const cplx *) twN, (cplx *) Y);
     ZD_LAUNCH_CHECK();
     return 0;
+}
+int launch_gen(const GenConst &g, const GenJumps &J, const JobList &jobs, int ky0, int nky, int L, int residue,
+               const void *twN, void *Y, hipStream_t st) {
+    if (L % GEN_ZR != 0) return 2;
+#define GCASE(nj, plt)                                                                                        \
+    if (jobs.n == nj && (g.qPLT != 0) == plt) {                                                               \
+        if (g.is_powerlaw) return launch_gen_t<nj, plt, true>(g, J, jobs, ky0, nky, L, residue, twN, Y, st); \
+        return launch_gen_t<nj, plt, false>(g, J, jobs, ky0, nky, L, residue, twN, Y, st);                    \
+    }
+    GCASE(1, false)
+    GCASE(1, true)
+    GCASE(4, false)
+    GCASE(7, true)
+#undef GCASE
+    return 2;
 }
 
 int launch_test_modes(const GenConst &g, long long n, const int *kxyz, uint64_t *draws, double *D, hipStream_t st) {
@@ -642,9 +673,8 @@ int launch_test_modes(const GenConst &g, long long n, const int *kxyz, uint64_t 
 }
 
 template <int L, int E, int W>
-static int launch_zfft_t(const GenConst &g, const JobList &jobs, const StoreLayout &S, int ky0, int kyloc0, int nky,
-                         int residue, int Zq, const void *Dbuf, const void *Pbuf, const void *twN, const void *twL,
-                         void *out, hipStream_t st) {
+static int launch_zfft_t(const JobList &jobs, const StoreLayout &S, int ky0, int kyloc0, int nky, int Zq, const void *Y,
+                         const void *twL, void *out, hipStream_t st) {
     constexpr int threads = W * L / E;
     const size_t shmem = sizeof(double) * zdfft::ColsInner<L, W>::SIZE;
     static bool attr_set = false;
@@ -652,18 +682,17 @@ static int launch_zfft_t(const GenConst &g, const JobList &jobs, const StoreLayo
         hipFuncSetAttribute((const void *) k_zfft<L, E, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
         attr_set = true;
     }
-    dim3 grid(g.N / W, nky, jobs.n), block(threads);
-    hipLaunchKernelGGL((k_zfft<L, E, W>), grid, block, shmem, st, g, jobs, S, ky0, kyloc0, residue, Zq,
-                       (const cplx *) Dbuf, (const double *) Pbuf, (const cplx *) twN, (const cplx *) twL, (cplx *) out);
+    dim3 grid(S.N / W, nky, jobs.n), block(threads);
+    hipLaunchKernelGGL((k_zfft<L, E, W>), grid, block, shmem, st, jobs, S, ky0, kyloc0, nky, Zq, (const cplx *) Y,
+                       (const cplx *) twL, (cplx *) out);
     ZD_LAUNCH_CHECK();
     return 0;
 }
 
-int launch_zfft(int L, const GenConst &g, const JobList &jobs, const StoreLayout &S, int ky0, int kyloc0, int nky,
-                int residue, int Zq, const void *Dbuf, const void *Pbuf, const void *twN, const void *twL, void *out,
-                hipStream_t st) {
+int launch_zfft(int L, const JobList &jobs, const StoreLayout &S, int ky0, int kyloc0, int nky, int Zq, const void *Y,
+                const void *twL, void *out, hipStream_t st) {
 #define ZCASE(l, e, w) \
-    case l: return launch_zfft_t<l, e, w>(g, jobs, S, ky0, kyloc0, nky, residue, Zq, Dbuf, Pbuf, twN, twL, out, st);
+    case l: return launch_zfft_t<l, e, w>(jobs, S, ky0, kyloc0, nky, Zq, Y, twL, out, st);
     switch (L) {
         ZCASE(32, 16, 32)
         ZCASE(64, 16, 32)
@@ -671,7 +700,7 @@ int launch_zfft(int L, const GenConst &g, const JobList &jobs, const StoreLayout
         ZCASE(256, 16, 16)
         ZCASE(512, 16, 16)
         ZCASE(1024, 16, 8)
-        ZCASE(2048, 16, 4)
+        ZCASE(2048, 16, 8)
         ZCASE(4096, 16, 4)
     }
 #undef ZCASE
@@ -682,8 +711,8 @@ int zfft_tile_width(int L) {
     switch (L) {
         case 32: case 64: case 128: return 32;
         case 256: case 512: return 16;
-        case 1024: return 8;
-        case 2048: case 4096: return 4;
+        case 1024: case 2048: return 8;
+        case 4096: return 4;
     }
     return 0;
 }
@@ -712,7 +741,7 @@ int launch_yfft(const StoreLayout &S, int nplanes, const void *tw, void *data, h
         YCASE(256, 16, 16)
         YCASE(512, 16, 16)
         YCASE(1024, 16, 8)
-        YCASE(2048, 16, 4)
+        YCASE(2048, 16, 8)
         YCASE(4096, 16, 4)
     }
 #undef YCASE
@@ -791,13 +820,35 @@ int launch_test_fft(int n, int kind, const void *tw, const void *in, void *out, 
         TCASE(256, 16, 16)
         TCASE(512, 16, 16)
         TCASE(1024, 16, 8)
-        TCASE(2048, 16, 4)
+        TCASE(2048, 16, 8)
         TCASE(4096, 16, 4)
     }
 #undef TCASE
     return 2;
 }
 int test_fft_tile_width(int n) { return zfft_tile_width(n); }
+
+// ---- tuning harness: the y pass in alternative tile shapes (zd_test_yfft_variant) ----
+template <int N, int E, int W, int MINW>
+static int launch_yfft_v(const StoreLayout &S, int nplanes, const void *tw, void *data, hipStream_t st) {
+    constexpr int threads = W * N / E;
+    const size_t shmem = sizeof(double) * zdfft::ColsInner<N, W>::SIZE;
+    hipFuncSetAttribute((const void *) k_yfft<N, E, W, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+    dim3 grid(N / W, S.narray, nplanes), block(threads);
+    hipLaunchKernelGGL((k_yfft<N, E, W, MINW>), grid, block, shmem, st, S, (const cplx *) tw, (cplx *) data);
+    ZD_LAUNCH_CHECK();
+    return 0;
+}
+int launch_yfft_variant(int variant, const StoreLayout &S, int nplanes, const void *tw, void *data, hipStream_t st) {
+#define VC(id, n, e, w, m) \
+    if (S.N == n && variant == id) return launch_yfft_v<n, e, w, m>(S, nplanes, tw, data, st);
+    VC(0, 2048, 16, 4, 1) VC(1, 2048, 16, 4, 4) VC(2, 2048, 16, 8, 4) VC(3, 2048, 8, 4, 4) VC(4, 2048, 8, 2, 4)
+    VC(5, 2048, 16, 2, 4) VC(6, 2048, 8, 4, 8) VC(7, 2048, 16, 2, 2) VC(8, 2048, 4, 2, 8) VC(9, 2048, 8, 2, 8)
+    VC(0, 1024, 16, 8, 1) VC(1, 1024, 16, 8, 4) VC(2, 1024, 16, 16, 4) VC(3, 1024, 8, 8, 4) VC(4, 1024, 8, 4, 4)
+    VC(5, 1024, 16, 4, 4) VC(6, 1024, 8, 8, 8) VC(7, 1024, 16, 4, 2) VC(8, 1024, 4, 4, 8) VC(9, 1024, 8, 4, 8)
+#undef VC
+    return 2;
+}
 
 int launch_copy16(const void *in, void *out, long long n16, hipStream_t st) {
     hipLaunchKernelGGL(k_copy16, dim3(256 * 8), dim3(256), 0, st, (const uint4 *) in, (uint4 *) out, n16);

@@ -7,15 +7,16 @@ namespace zd {
 constexpr int GEN_BX = 256;  // threads (consecutive x) per generator workgroup
 constexpr int GEN_ZR = 16;   // z rows walked by one generator thread
 
-int launch_gen(const GenConst &g, const GenJumps &J, int ky0, int nky, void *Dbuf, void *Pbuf, hipStream_t st);
+int launch_gen(const GenConst &g, const GenJumps &J, const JobList &jobs, int ky0, int nky, int L, int residue,
+               const void *twN, void *Y, hipStream_t st);
 int launch_test_modes(const GenConst &g, long long n, const int *kxyz, uint64_t *draws, double *D, hipStream_t st);
-int launch_zfft(int L, const GenConst &g, const JobList &jobs, const StoreLayout &S, int ky0, int kyloc0, int nky,
-                int residue, int Zq, const void *Dbuf, const void *Pbuf, const void *twN, const void *twL, void *out,
-                hipStream_t st);
+int launch_zfft(int L, const JobList &jobs, const StoreLayout &S, int ky0, int kyloc0, int nky, int Zq, const void *Y,
+                const void *twL, void *out, hipStream_t st);
 int zfft_tile_width(int L);
 int launch_yfft(const StoreLayout &S, int nplanes, const void *tw, void *data, hipStream_t st);
 int launch_xfft(const StoreLayout &S, const EpiConst &ec, const void *tw, const void *data, int plane0, int nplanes,
                 int z_first, int z_step, void *records, float *density, Reduce *red, hipStream_t st);
+int launch_yfft_variant(int variant, const StoreLayout &S, int nplanes, const void *tw, void *data, hipStream_t st);
 int launch_test_fft(int n, int kind, const void *tw, const void *in, void *out, long long lines, hipStream_t st);
 int test_fft_tile_width(int n);
 int launch_copy16(const void *in, void *out, long long n16, hipStream_t st);
