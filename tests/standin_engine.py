@@ -27,6 +27,9 @@ class NumpyEngine:
         while (1 << lBz) > self.Zq:
             lBz -= 1
         self.lBk, self.lBz = lBk, lBz
+        lBk = min(20, self.Hq.bit_length() - 1)  # library default: all row slots of a half in one block,
+        lBz = 0                                   # one plane per block (measured best on MI355X)
+        self.lBk, self.lBz = lBk, lBz
         self.a_stride = (N << lBk) << lBz
         self.zb_stride = self.a_stride * self.na
         self.kb_stride = self.zb_stride * (self.Zq >> lBz)

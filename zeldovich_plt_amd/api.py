@@ -88,6 +88,12 @@ def load_library():
         raise RuntimeError(
             "zeldovich_plt_amd: %s is missing — run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C zeldovich_plt_amd/csrc`; there is no CPU fallback." % LIB_PATH)
+    try:
+        # torch bundles its own HIP runtime; it must be the first one initialised in the process,
+        # otherwise torch later reports "No HIP GPUs are available" (measured on the MI355X box)
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     L.zd_generate.argtypes = [C.POINTER(ZdParams), C.POINTER(ZdPk), vp, i64, SLAB_CB, vp, C.POINTER(ZdStats)]

@@ -73,9 +73,13 @@ struct zd_plan {
     u128 *d_rowstate = nullptr;
     cplx *d_twN = nullptr, *d_twL = nullptr;
     zd::Reduce *d_red = nullptr;
-    // folded FFT inputs of one slab of half-space rows: Y[job][row][k2][x]
-    cplx *d_Y = nullptr;
+    // folded FFT inputs of one slab of half-space rows: Y[job][row][k2][x]; double-buffered so that
+    // k_gen (VALU-bound) of slab s+1 runs beside k_zfft (HBM-bound) of slab s on a second stream
+    cplx *d_Y[2] = {nullptr, nullptr};
     int slab_rows = 0;  // rows generated per k_gen launch
+    hipStream_t s_gen = nullptr, s_fft = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_gen[2] = {nullptr, nullptr}, ev_fft[2] = {nullptr, nullptr};
+    bool overlap = true;
     // timing
     std::vector<EventPair> events;
     std::vector<hipEvent_t> pool;
@@ -301,6 +305,10 @@ int zd_plan_create(const zd_params *p, const zd_pk *pk, const double *eig, int64
     S.half   = pl->half;
     S.Hq     = pl->Hq;
     S.narray = pl->narray;
+    S.prune     = getenv("ZD_PRUNE") ? atoi(getenv("ZD_PRUNE")) : 7;  // bit 0 k_gen, 1 k_zfft, 2 k_yfft
+    S.kmax      = g.kmax;
+    S.fund2     = g.fundamental2;
+    S.k2_cutoff = p->corner_modes ? 0.0 : g.k2_cutoff;  // CornerModes: only the |k_i| == kmax rule prunes
     {
         const long long target = std::max<long long>(1, ((long long) 2 << 20) / ((long long) pl->N * 16));
         int lt = 0;
@@ -318,13 +326,13 @@ int zd_plan_create(const zd_params *p, const zd_pk *pk, const double *eig, int64
         while ((1 << lBz) > pl->Zq) lBz--;
         S.lBk = lBk;
         S.lBz = lBz;
-        int row_pad = 0, arr_pad = 0, plane_pad = 0;  // in complex elements
-        if (const char *env = getenv("ZD_PAD")) sscanf(env, "%d,%d,%d", &row_pad, &arr_pad, &plane_pad);
-        S.pitch        = pl->N + row_pad;
-        S.a_stride     = (((long long) S.pitch << lBk) << lBz) + arr_pad;
-        S.zb_stride    = S.a_stride * pl->narray + plane_pad;
-        S.kb_stride    = S.zb_stride * (pl->Zq >> lBz);
-        S.chunk_stride = S.kb_stride * ((2 * pl->Hq) >> lBk);
+        int row_pad = 0;  // in complex elements
+        if (const char *env = getenv("ZD_PAD")) sscanf(env, "%d", &row_pad);
+        S.pitch      = pl->N + row_pad;
+        S.a_rows     = (1 << lBk) << lBz;
+        S.zb_rows    = S.a_rows * pl->narray;
+        S.kb_rows    = S.zb_rows * (pl->Zq >> lBz);
+        S.chunk_rows = S.kb_rows * ((2 * pl->Hq) >> lBk);
     }
 
     pl->ec.N        = pl->N;
@@ -338,11 +346,21 @@ int zd_plan_create(const zd_params *p, const zd_pk *pk, const double *eig, int64
     // ---- folded-input slab: enough rows to fill the chip, bounded to ~1 GB ----
     {
         const int64_t row_b = y_bytes_per_row(pl);
-        int rows = (int) std::max<int64_t>(1, ((int64_t) 1 << 30) / row_b);
+        int rows = (int) std::max<int64_t>(1, ((int64_t) 1 << 29) / row_b);
         rows     = std::min(rows, pl->Hq);
         while (pl->Hq % rows) rows--;
         pl->slab_rows = rows;
-        PLCHECK(hipMalloc((void **) &pl->d_Y, (size_t) row_b * rows));
+        pl->overlap   = getenv("ZD_NO_OVERLAP") == nullptr;
+        for (int i = 0; i < (pl->overlap ? 2 : 1); i++) PLCHECK(hipMalloc((void **) &pl->d_Y[i], (size_t) row_b * rows));
+        if (pl->overlap) {
+            PLCHECK(hipStreamCreateWithFlags(&pl->s_gen, hipStreamNonBlocking));
+            PLCHECK(hipStreamCreateWithFlags(&pl->s_fft, hipStreamNonBlocking));
+            PLCHECK(hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming));
+            for (int i = 0; i < 2; i++) {
+                PLCHECK(hipEventCreateWithFlags(&pl->ev_gen[i], hipEventDisableTiming));
+                PLCHECK(hipEventCreateWithFlags(&pl->ev_fft[i], hipEventDisableTiming));
+            }
+        }
     }
 #undef PLCHECK
     *out = pl;
@@ -359,14 +377,24 @@ void zd_plan_destroy(zd_plan *pl) {
     hipFree(pl->d_twN);
     hipFree(pl->d_twL);
     hipFree(pl->d_red);
-    hipFree(pl->d_Y);
+    hipFree(pl->d_Y[0]);
+    hipFree(pl->d_Y[1]);
+    if (pl->s_gen) hipStreamDestroy(pl->s_gen);
+    if (pl->s_fft) hipStreamDestroy(pl->s_fft);
+    if (pl->ev_fork) hipEventDestroy(pl->ev_fork);
+    for (int i = 0; i < 2; i++) {
+        if (pl->ev_gen[i]) hipEventDestroy(pl->ev_gen[i]);
+        if (pl->ev_fft[i]) hipEventDestroy(pl->ev_fft[i]);
+    }
     delete pl;
 }
 
 int32_t zd_plan_narray(const zd_plan *pl) { return pl->narray; }
 int32_t zd_plan_stream_factor(const zd_plan *pl) { return pl->R; }
 int32_t zd_plan_record_size(const zd_plan *pl) { return pl->ec.recsize; }
-int64_t zd_plan_exchange_bytes(const zd_plan *pl) { return (int64_t) pl->S.chunk_stride * pl->nranks * 16; }
+int64_t zd_plan_exchange_bytes(const zd_plan *pl) {
+    return (int64_t) pl->S.chunk_rows * pl->S.pitch * pl->nranks * 16;
+}
 int64_t zd_plan_local_planes(const zd_plan *pl) { return pl->Zq; }
 int64_t zd_plan_plane_z(const zd_plan *pl, int residue, int64_t local_plane) {
     return residue + (int64_t) pl->R * ((int64_t) pl->rank * pl->Zq + local_plane);
@@ -376,16 +404,44 @@ int zd_plan_stage_z(zd_plan *pl, int residue, void *d_send, void *hip_stream) {
     hipStream_t st = (hipStream_t) hip_stream;
     if (residue < 0 || residue >= pl->R) return 1;
     const int ky_first = pl->rank * pl->Hq;
-    for (int r0 = 0; r0 < pl->Hq; r0 += pl->slab_rows) {
-        const int nky = std::min(pl->slab_rows, pl->Hq - r0);
-        tick(pl, ZD_K_GEN, st, true);
-        if (zd::launch_gen(pl->g, pl->J, pl->jobs, ky_first + r0, nky, pl->L, residue, pl->d_twN, pl->d_Y, st)) return 1;
-        tick(pl, ZD_K_GEN, st, false);
-        tick(pl, ZD_K_ZFFT, st, true);
-        if (zd::launch_zfft(pl->L, pl->jobs, pl->S, ky_first + r0, r0, nky, pl->Zq, pl->d_Y, pl->d_twL, d_send, st))
-            return 1;
-        tick(pl, ZD_K_ZFFT, st, false);
+    if (!pl->overlap) {
+        for (int r0 = 0; r0 < pl->Hq; r0 += pl->slab_rows) {
+            const int nky = std::min(pl->slab_rows, pl->Hq - r0);
+            tick(pl, ZD_K_GEN, st, true);
+            if (zd::launch_gen(pl->g, pl->J, pl->jobs, pl->S, ky_first + r0, nky, pl->L, residue, pl->d_twN, pl->d_Y[0], st)) return 1;
+            tick(pl, ZD_K_GEN, st, false);
+            tick(pl, ZD_K_ZFFT, st, true);
+            if (zd::launch_zfft(pl->L, pl->jobs, pl->S, ky_first + r0, r0, nky, pl->Zq, pl->d_Y[0], pl->d_twL, d_send, st))
+                return 1;
+            tick(pl, ZD_K_ZFFT, st, false);
+        }
+        return 0;
     }
+    // fork: both worker streams start after everything already queued on the caller's stream
+    HIPCHECK(hipEventRecord(pl->ev_fork, st));
+    HIPCHECK(hipStreamWaitEvent(pl->s_gen, pl->ev_fork, 0));
+    HIPCHECK(hipStreamWaitEvent(pl->s_fft, pl->ev_fork, 0));
+    int slab = 0;
+    for (int r0 = 0; r0 < pl->Hq; r0 += pl->slab_rows, slab++) {
+        const int nky = std::min(pl->slab_rows, pl->Hq - r0);
+        const int b   = slab & 1;
+        // k_gen may overwrite Y[b] only after the k_zfft that read it (two slabs ago) has finished
+        if (slab >= 2) HIPCHECK(hipStreamWaitEvent(pl->s_gen, pl->ev_fft[b], 0));
+        tick(pl, ZD_K_GEN, pl->s_gen, true);
+        if (zd::launch_gen(pl->g, pl->J, pl->jobs, pl->S, ky_first + r0, nky, pl->L, residue, pl->d_twN, pl->d_Y[b], pl->s_gen))
+            return 1;
+        tick(pl, ZD_K_GEN, pl->s_gen, false);
+        HIPCHECK(hipEventRecord(pl->ev_gen[b], pl->s_gen));
+        HIPCHECK(hipStreamWaitEvent(pl->s_fft, pl->ev_gen[b], 0));
+        tick(pl, ZD_K_ZFFT, pl->s_fft, true);
+        if (zd::launch_zfft(pl->L, pl->jobs, pl->S, ky_first + r0, r0, nky, pl->Zq, pl->d_Y[b], pl->d_twL, d_send, pl->s_fft))
+            return 1;
+        tick(pl, ZD_K_ZFFT, pl->s_fft, false);
+        HIPCHECK(hipEventRecord(pl->ev_fft[b], pl->s_fft));
+    }
+    // join: the caller's stream continues after the last k_zfft (which is after every k_gen)
+    HIPCHECK(hipEventRecord(pl->ev_fork, pl->s_fft));
+    HIPCHECK(hipStreamWaitEvent(st, pl->ev_fork, 0));
     return 0;
 }
 
@@ -641,14 +697,14 @@ int zd_test_yfft_variant(int32_t n, int32_t variant, int32_t narray, int32_t npl
         lBk = (lt + 1) / 2; lBz = lt - lBk;
         while ((1 << lBz) > nplanes) lBz--;
     }
-    S.lBk = lBk; S.lBz = lBz; S.rows_outer = 0; S.pitch = n;
-    S.a_stride = ((long long) n << lBk) << lBz;
-    S.zb_stride = S.a_stride * narray;
-    S.kb_stride = S.zb_stride * (nplanes >> lBz);
-    S.chunk_stride = S.kb_stride * (n >> lBk);
+    S.lBk = lBk; S.lBz = lBz; S.rows_outer = 0; S.pitch = n; S.prune = 0; S.kmax = 0; S.fund2 = 0; S.k2_cutoff = 0;
+    S.a_rows = (1 << lBk) << lBz;
+    S.zb_rows = S.a_rows * narray;
+    S.kb_rows = S.zb_rows * (nplanes >> lBz);
+    S.chunk_rows = S.kb_rows * (n >> lBk);
     std::vector<cplx> tw = make_twiddles(n);
     cplx *d_tw = nullptr, *d = nullptr;
-    const size_t nb = (size_t) S.chunk_stride * 16;
+    const size_t nb = (size_t) S.chunk_rows * S.pitch * 16;
     int rc = 1;
     do {
         if (hipMalloc((void **) &d_tw, sizeof(cplx) * n) != hipSuccess) break;

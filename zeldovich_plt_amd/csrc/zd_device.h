@@ -55,11 +55,26 @@ struct GenJumps {
 //   c*chunk_stride + (s/Bk)*kb_stride + (zl/Bz)*zb_stride + a*a_stride + ((zl%Bz)*Bk + s%Bk)*N + x
 struct StoreLayout {
     int N, half, Hq, narray;
-    int lBk, lBz;  // log2 of the block edge in row slots / planes
-    int rows_outer; // order inside a block: 0 = [plane][slot][x], 1 = [slot][plane][x]
-    int pitch;      // row pitch in elements (>= N; padding de-aliases power-of-two strides)
-    long long chunk_stride, kb_stride, zb_stride, a_stride;
+    int lBk, lBz;    // log2 of the block edge in row slots / planes
+    int rows_outer;  // order inside a block: 0 = [plane][slot][x], 1 = [slot][plane][x]
+    int pitch;       // row pitch in elements (>= N)
+    // all strides are in ROWS (32-bit: a 275 GB store has < 2^24 rows) so that one 32x32->64 multiply
+    // per element turns a row index into an address
+    int chunk_rows, kb_rows, zb_rows, a_rows;
+    // pruning: a (kx,ky) column whose every kz mode is zeroed by the rule of zeldovich.cpp:350-353 is
+    // identically zero after the z FFT; it is neither written by the z stage nor read by the y stage
+    int prune, kmax;
+    double fund2, k2_cutoff;
 };
+
+// true iff every mode of column (kx, ky) (signed wavenumbers) is zero for all kz
+ZD_HD bool column_is_zero(const StoreLayout &L, int kx, int ky) {
+    if (!L.prune) return false;
+    const int ax = kx < 0 ? -kx : kx, ay = ky < 0 ? -ky : ky;
+    if (ax == L.kmax || ay == L.kmax) return true;
+    // (kx^2+ky^2+kz^2)*fund2 >= (kx^2+ky^2)*fund2 in double arithmetic, so this implies the mode rule
+    return L.k2_cutoff > 0 && (double) (kx * kx + ky * ky) * L.fund2 >= L.k2_cutoff;
+}
 
 ZD_HD void row_slot(const StoreLayout &L, int ky, int &chunk, int &slot) {
     int kyh, tw;
@@ -76,13 +91,15 @@ ZD_HD void row_slot(const StoreLayout &L, int ky, int &chunk, int &slot) {
     chunk = kyh / L.Hq;
     slot  = kyh - chunk * L.Hq + tw * L.Hq;
 }
-// offset of column 0 of (chunk, local plane zl, array a, row slot)
-ZD_HD long long store_offset(const StoreLayout &L, int chunk, int zl, int a, int slot) {
+// row index of (chunk, local plane zl, array a, row slot); element offset = row * pitch + x
+ZD_HD int store_row(const StoreLayout &L, int chunk, int zl, int a, int slot) {
     const int Bk = 1 << L.lBk, Bz = 1 << L.lBz;
-    return (long long) chunk * L.chunk_stride + (long long) (slot >> L.lBk) * L.kb_stride
-           + (long long) (zl >> L.lBz) * L.zb_stride + (long long) a * L.a_stride
-           + (long long) (L.rows_outer ? (((slot & (Bk - 1)) << L.lBz) + (zl & (Bz - 1)))
-                                        : (((zl & (Bz - 1)) << L.lBk) + (slot & (Bk - 1)))) * L.pitch;
+    return chunk * L.chunk_rows + (slot >> L.lBk) * L.kb_rows + (zl >> L.lBz) * L.zb_rows + a * L.a_rows
+           + (L.rows_outer ? (((slot & (Bk - 1)) << L.lBz) + (zl & (Bz - 1)))
+                           : (((zl & (Bz - 1)) << L.lBk) + (slot & (Bk - 1))));
+}
+ZD_HD long long store_offset(const StoreLayout &L, int chunk, int zl, int a, int slot) {
+    return (long long) store_row(L, chunk, zl, a, slot) * L.pitch;
 }
 ZD_HD long long row_offset(const StoreLayout &L, int zl, int a, int ky) {
     int c, s;

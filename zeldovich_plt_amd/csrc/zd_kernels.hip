@@ -168,8 +168,8 @@ __device__ void get_eigenmode_dev(const GenConst &g, int kx, int ky, int kz, dou
 //   Y[((j*nky + kyl)*L + k2)*N + x]   complex
 // grid: (ceil(N/GEN_BX), L/ZR, nky)  block: GEN_BX
 template <int ZR, int NJ, bool PLT, bool PLAW>
-__global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, JobList jobs, int ky0, int nky, int L,
-                                                int residue, const cplx *__restrict__ twN,
+__global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, JobList jobs, StoreLayout S, int zW, int ky0,
+                                                int nky, int L, int residue, const cplx *__restrict__ twN,
                                                 cplx *__restrict__ Y) {
     const int N = g.N, half = g.half, R = N / L;
     const int x   = blockIdx.x * GEN_BX + threadIdx.x;
@@ -178,6 +178,15 @@ __global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, JobList 
     const int ky  = ky0 + kyl;
     if (x >= N) return;
     const int kx = x > half ? x - N : x;
+    if (S.prune & 1) {  // the whole k_zfft tile this column belongs to is identically zero: nothing to produce
+        bool all_zero = true;
+        const int xt0 = x - x % zW;
+        for (int i = 0; i < zW; i++) {
+            const int xi = xt0 + i;
+            all_zero = all_zero && column_is_zero(S, xi > half ? xi - N : xi, ky);
+        }
+        if (all_zero) return;
+    }
     u128 s = 0;
     if (ky != 0) {  // state one step ahead of the first mode's counter
         const int kz0 = k20 > half ? k20 - N : k20;  // k20 > N/2 only happens when R = 1
@@ -351,7 +360,9 @@ __global__ __launch_bounds__(W *L / E) void k_zfft(JobList jobs, StoreLayout S, 
     const int kind = jobs.kind[blockIdx.z];
     const bool twin_only = (kind == JOB_A_TWIN || kind == JOB_B_TWIN || kind == JOB_D_TWIN);
     if (ky == 0 && twin_only) return;  // ky = 0 is its own twin plane: every column written as "self"
-
+    if (S.prune & 2) {  // tile of identically-zero columns: k_gen produced nothing, k_yfft will not read it
+        if (__syncthreads_and(column_is_zero(S, x > S.half ? x - N : x, ky))) return;
+    }
     const cplx *src = Y + (((long long) blockIdx.z * nky + kyl) * L) * N + x;
     double re[E], im[E];
 #pragma unroll
@@ -368,24 +379,18 @@ __global__ __launch_bounds__(W *L / E) void k_zfft(JobList jobs, StoreLayout S, 
                                                                                     : 3;
     const bool st_self = !twin_only;
     const bool st_twin = (ky != 0) && (twin_only || kind == JOB_C_BOTH || kind == JOB_DENS);
+    const double sgr = (kind == JOB_C_BOTH) ? -1.0 : 1.0, sgi = (kind == JOB_C_BOTH) ? 1.0 : -1.0;  // -conj / conj
     const int loc_self = kyloc0 + kyl, loc_twin = S.Hq + kyloc0 + kyl;
-    const int xt = (N - x) & (N - 1);
+    // the twin row sits a constant number of rows away from the self row (same plane, same array)
+    const int drow = store_row(S, 0, 0, 0, loc_twin) - store_row(S, 0, 0, 0, loc_self);
+    const int xt   = (N - x) & (N - 1);
 #pragma unroll
     for (int e = 0; e < E; e++) {
-        const int z2 = t + T * e;
+        const int z2  = t + T * e;
         const int dst = z2 / Zq, zl = z2 - dst * Zq;
-        if (st_self) out[store_offset(S, dst, zl, arr, loc_self) + x] = cplx{re[e], im[e]};
-        if (st_twin) {
-            cplx v;
-            if (kind == JOB_C_BOTH) {
-                v.x = -re[e];
-                v.y = im[e];
-            } else {
-                v.x = re[e];
-                v.y = -im[e];
-            }
-            out[store_offset(S, dst, zl, arr, loc_twin) + xt] = v;
-        }
+        const int row = store_row(S, dst, zl, arr, loc_self);
+        if (st_self) out[(long long) row * S.pitch + x] = cplx{re[e], im[e]};
+        if (st_twin) out[(long long) (row + drow) * S.pitch + xt] = cplx{sgr * re[e], sgi * im[e]};
     }
 }
 
@@ -401,17 +406,17 @@ __global__ __launch_bounds__(W *N / E, MINW) void k_yfft(StoreLayout S, const cp
     const int x = blockIdx.x * W + w;
     cplx *base = data + x;
     const int zl = blockIdx.z, a = blockIdx.y;
+    const int kxs = x > N / 2 ? x - N : x;
     double re[E], im[E];
 #pragma unroll
     for (int e = 0; e < E; e++) {
         const int ky = t + T * e;
-        if (ky == N / 2) {  // Nyquist row is identically zero (zeldovich.cpp:644-650)
-            re[e] = im[e] = 0.0;
-        } else {
-            const cplx v = base[row_offset(S, zl, a, ky)];
-            re[e] = v.x;
-            im[e] = v.y;
-        }
+        // Nyquist row (zeldovich.cpp:644-650) and pruned columns are identically zero: not read
+        const bool skip = (ky == N / 2) || ((S.prune & 4) && column_is_zero(S, kxs, ky > N / 2 ? ky - N : ky));
+        cplx v = cplx{0.0, 0.0};
+        if (!skip) v = base[row_offset(S, zl, a, ky)];
+        re[e] = v.x;
+        im[e] = v.y;
     }
     zdfft::fft_line<PL, LDS>(re, im, t, w, lds, tw);
 #pragma unroll
@@ -639,23 +644,25 @@ __global__ void k_copy16(const uint4 *__restrict__ in, uint4 *__restrict__ out, 
 
 namespace zd {
 
+int zfft_tile_width(int L);
+
 template <int NJ, bool PLT, bool PLAW>
-static int launch_gen_t(const GenConst &g, const GenJumps &J, const JobList &jobs, int ky0, int nky, int L, int residue,
-                        const void *twN, void *Y, hipStream_t st) {
+static int launch_gen_t(const GenConst &g, const GenJumps &J, const JobList &jobs, const StoreLayout &S, int ky0, int nky,
+                        int L, int residue, const void *twN, void *Y, hipStream_t st) {
     const int N = g.N;
     dim3 grid((N + GEN_BX - 1) / GEN_BX, L / GEN_ZR, nky), block(GEN_BX);
-    hipLaunchKernelGGL((k_gen<GEN_ZR, NJ, PLT, PLAW>), grid, block, 0, st, g, J, jobs, ky0, nky, L, residue,
-                       (const cplx *) twN, (cplx *) Y);
+    hipLaunchKernelGGL((k_gen<GEN_ZR, NJ, PLT, PLAW>), grid, block, 0, st, g, J, jobs, S, zfft_tile_width(L), ky0, nky,
+                       L, residue, (const cplx *) twN, (cplx *) Y);
     ZD_LAUNCH_CHECK();
     return 0;
 }
-int launch_gen(const GenConst &g, const GenJumps &J, const JobList &jobs, int ky0, int nky, int L, int residue,
-               const void *twN, void *Y, hipStream_t st) {
+int launch_gen(const GenConst &g, const GenJumps &J, const JobList &jobs, const StoreLayout &S, int ky0, int nky, int L,
+               int residue, const void *twN, void *Y, hipStream_t st) {
     if (L % GEN_ZR != 0) return 2;
 #define GCASE(nj, plt)                                                                                        \
     if (jobs.n == nj && (g.qPLT != 0) == plt) {                                                               \
-        if (g.is_powerlaw) return launch_gen_t<nj, plt, true>(g, J, jobs, ky0, nky, L, residue, twN, Y, st); \
-        return launch_gen_t<nj, plt, false>(g, J, jobs, ky0, nky, L, residue, twN, Y, st);                    \
+        if (g.is_powerlaw) return launch_gen_t<nj, plt, true>(g, J, jobs, S, ky0, nky, L, residue, twN, Y, st); \
+        return launch_gen_t<nj, plt, false>(g, J, jobs, S, ky0, nky, L, residue, twN, Y, st);                    \
     }
     GCASE(1, false)
     GCASE(1, true)
