@@ -304,6 +304,8 @@ int zd_plan_create(const zd_params *p, const zd_pk *pk, const double *eig, int64
     S.N      = pl->N;
     S.half   = pl->half;
     S.Hq     = pl->Hq;
+    S.lHq    = 0;
+    while ((1 << S.lHq) < pl->Hq) S.lHq++;
     S.narray = pl->narray;
     S.prune     = getenv("ZD_PRUNE") ? atoi(getenv("ZD_PRUNE")) : 7;  // bit 0 k_gen, 1 k_zfft, 2 k_yfft
     S.kmax      = g.kmax;
@@ -343,10 +345,10 @@ int zd_plan_create(const zd_params *p, const zd_pk *pk, const double *eig, int64
     pl->ec.qdensity = p->qdensity;
     pl->ec.vnorm    = p->qPLT ? 1.0 : (sqrt(1. + 24 * p->f_cluster) - 1) * .25;  // output.cpp:78-82
 
-    // ---- folded-input slab: enough rows to fill the chip, bounded to ~1 GB ----
+    // ---- folded-input slabs (two, for the gen||zfft overlap): enough rows per launch to fill the chip ----
     {
         const int64_t row_b = y_bytes_per_row(pl);
-        int rows = (int) std::max<int64_t>(1, ((int64_t) 1 << 29) / row_b);
+        int rows = (int) std::max<int64_t>(1, ((int64_t) 3 << 29) / row_b);  // ~1.5 GB per buffer
         rows     = std::min(rows, pl->Hq);
         while (pl->Hq % rows) rows--;
         pl->slab_rows = rows;
@@ -689,6 +691,8 @@ int zd_test_yfft_variant(int32_t n, int32_t variant, int32_t narray, int32_t npl
                          double *ms_per_launch) {
     zd::StoreLayout S;
     S.N = n; S.half = n / 2; S.Hq = n / 2; S.narray = narray;
+    S.lHq = 0;
+    while ((1 << S.lHq) < S.Hq) S.lHq++;
     int lBk = 0, lBz = 0;
     if (tiled) {
         const long long target = std::max<long long>(1, ((long long) 2 << 20) / ((long long) n * 16));

@@ -55,6 +55,7 @@ struct GenJumps {
 //   c*chunk_stride + (s/Bk)*kb_stride + (zl/Bz)*zb_stride + a*a_stride + ((zl%Bz)*Bk + s%Bk)*N + x
 struct StoreLayout {
     int N, half, Hq, narray;
+    int lHq;         // log2(Hq): Hq, Zq, N are powers of two, so every division is a shift
     int lBk, lBz;    // log2 of the block edge in row slots / planes
     int rows_outer;  // order inside a block: 0 = [plane][slot][x], 1 = [slot][plane][x]
     int pitch;       // row pitch in elements (>= N)
@@ -88,8 +89,8 @@ ZD_HD void row_slot(const StoreLayout &L, int ky, int &chunk, int &slot) {
         kyh = L.N - ky;
         tw  = 1;
     }
-    chunk = kyh / L.Hq;
-    slot  = kyh - chunk * L.Hq + tw * L.Hq;
+    chunk = kyh >> L.lHq;
+    slot  = (kyh & (L.Hq - 1)) + (tw << L.lHq);
 }
 // row index of (chunk, local plane zl, array a, row slot); element offset = row * pitch + x
 ZD_HD int store_row(const StoreLayout &L, int chunk, int zl, int a, int slot) {

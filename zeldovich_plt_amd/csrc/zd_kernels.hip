@@ -179,10 +179,12 @@ __global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, JobList 
     if (x >= N) return;
     const int kx = x > half ? x - N : x;
     if (S.prune & 1) {  // the whole k_zfft tile this column belongs to is identically zero: nothing to produce
+        // k_zfft reads this column through the tile [xt0, xt0+zW) ("self" jobs) and through the tile
+        // shifted by one column ("twin" jobs): skip only if both are entirely zero
         bool all_zero = true;
         const int xt0 = x - x % zW;
-        for (int i = 0; i < zW; i++) {
-            const int xi = xt0 + i;
+        for (int i = -1; i <= zW; i++) {
+            const int xi = (xt0 + i) & (N - 1);
             all_zero = all_zero && column_is_zero(S, xi > half ? xi - N : xi, ky);
         }
         if (all_zero) return;
@@ -354,12 +356,15 @@ __global__ __launch_bounds__(W *L / E) void k_zfft(JobList jobs, StoreLayout S, 
     constexpr int T = PL::T;
     const int N = S.N;
     const int w = threadIdx.x % W, t = threadIdx.x / W;
-    const int x   = blockIdx.x * W + w;
     const int kyl = blockIdx.y;
     const int ky  = ky0 + kyl;
     const int kind = jobs.kind[blockIdx.z];
     const bool twin_only = (kind == JOB_A_TWIN || kind == JOB_B_TWIN || kind == JOB_D_TWIN);
+    // twin columns are stored mirrored (column N-x): shifting the tile of twin-only jobs by one column
+    // makes the mirrored run start on a tile boundary, i.e. whole 128-byte lines instead of 112 + 16 B
+    const int x = (blockIdx.x * W + w + (twin_only ? 1 : 0)) & (N - 1);
     if (ky == 0 && twin_only) return;  // ky = 0 is its own twin plane: every column written as "self"
+    const int lZq = 31 - __clz(Zq);
     if (S.prune & 2) {  // tile of identically-zero columns: k_gen produced nothing, k_yfft will not read it
         if (__syncthreads_and(column_is_zero(S, x > S.half ? x - N : x, ky))) return;
     }
@@ -367,11 +372,13 @@ __global__ __launch_bounds__(W *L / E) void k_zfft(JobList jobs, StoreLayout S, 
     double re[E], im[E];
 #pragma unroll
     for (int e = 0; e < E; e++) {
-        const cplx v = src[(long long) (t + T * e) * N];
+        cplx v = cplx{1.0 + e, 2.0 * t};
+        if (!(S.prune & 8)) v = src[(long long) (t + T * e) * N];  // bit 3: tuning ablation (skip loads)
         re[e] = v.x;
         im[e] = v.y;
     }
     zdfft::fft_line<PL, LDS>(re, im, t, w, lds, twL);
+    if ((S.prune & 16) && re[0] != 123.456) return;  // bit 4: tuning ablation (skip stores)
 
     const int arr = (kind == JOB_A_SELF || kind == JOB_A_TWIN || kind == JOB_DENS) ? 0
                     : (kind == JOB_B_SELF || kind == JOB_B_TWIN)                    ? 1
@@ -387,7 +394,7 @@ __global__ __launch_bounds__(W *L / E) void k_zfft(JobList jobs, StoreLayout S, 
 #pragma unroll
     for (int e = 0; e < E; e++) {
         const int z2  = t + T * e;
-        const int dst = z2 / Zq, zl = z2 - dst * Zq;
+        const int dst = z2 >> lZq, zl = z2 & (Zq - 1);  // Zq = 2^lZq
         const int row = store_row(S, dst, zl, arr, loc_self);
         if (st_self) out[(long long) row * S.pitch + x] = cplx{re[e], im[e]};
         if (st_twin) out[(long long) (row + drow) * S.pitch + xt] = cplx{sgr * re[e], sgi * im[e]};
