@@ -60,11 +60,11 @@ def cpu_baseline(ppd, plt, fmt, eig):
     from oracle import zdo
     zdo.build()
     cores = os.cpu_count() or 1
-    n = min(ppd, 256)
-    while n > 64 and n ** 3 * (64 if plt else 32) * 2.2 > 24e9:
+    n = min(ppd, 512 if cores >= 32 else 256)  # bounded sample: ~10-30 s of CPU work
+    while n > 64 and n ** 3 * (64 if plt else 32) * 2.2 > 40e9:
         n //= 2
     pk = zdo.pk_from_file(WMAP, 720.0)
-    kw = dict(numblock=4, icformat=fmt, nthreads=cores)
+    kw = dict(numblock=2, icformat=fmt, nthreads=cores)  # NumBlock=2: widest OpenMP loops (block = n/2 planes)
     if plt:
         kw.update(qPLT=1, qPLTrescale=1, PLT_target_z=5.0, z_initial=49.0)
     p = zdo.make_params(n, **kw)
@@ -166,6 +166,9 @@ def main():
         per_launch_particles = particles * args.steps / world / launches
         avg_ms = kms[dom] / launches
         achieved = alg[dom] * per_launch_particles / (avg_ms * 1e-3) / 1e9
+        per_kernel = {k: {"alg_GBps": alg[k] * particles * args.steps / world / (kms[k] * 1e-3) / 1e9 if kms[k] > 0 else None,
+                          "ms_per_step": kms[k] / args.steps, "launches_per_step": kl[k] / args.steps,
+                          "alg_bytes_per_particle": alg[k]} for k in alg}
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tfile):
@@ -189,7 +192,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches": launches,
-                         "alg_bytes_per_particle": alg[dom]},
+                         "alg_bytes_per_particle": alg[dom],
+                         "note": "k_gen and k_zfft run concurrently on two streams, so their hipEvent spans overlap"},
+            "kernels": per_kernel,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
