@@ -58,7 +58,7 @@ class NumpyEngine:
                 + a * self.a_stride + (((zl & (Bz - 1)) << self.lBk) + (slot & (Bk - 1))) * self.N)
 
     def stage_z(self, residue, send):
-        buf = send.numpy().view(np.complex128)
+        buf = send.numpy().view(np.complex128).reshape(-1)
         N, Hq, Zq = self.N, self.Hq, self.Zq
         for kyh in range(self.rank * Hq, (self.rank + 1) * Hq):
             rows = [(kyh, kyh - self.rank * Hq)]
@@ -72,7 +72,7 @@ class NumpyEngine:
                         buf[o:o + N] = self.zt[a, ky, residue + self.R * z2, :]
 
     def stage_y(self, recv):
-        buf = recv.numpy().view(np.complex128)
+        buf = recv.numpy().view(np.complex128).reshape(-1)
         N = self.N
         for zl in range(self.Zq):
             for a in range(self.na):
@@ -89,7 +89,7 @@ class NumpyEngine:
                     buf[offs[y]:offs[y] + N] = plane[y]
 
     def stage_x(self, residue, recv, plane0, nplanes, out):
-        buf = recv.numpy().view(np.complex128)
+        buf = recv.numpy().view(np.complex128).reshape(-1)
         o_out = out.numpy().view(np.complex128)
         N = self.N
         for i in range(nplanes):

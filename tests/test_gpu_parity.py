@@ -257,3 +257,36 @@ def test_bench_pipeline_driver(zd, oracle, ps, opk):
     assert np.array_equal(rec["ijk"], ref["ijk"])
     assert _rel(rec["d"], ref["d"]) < 1e-6 and _rel(rec["v"], ref["v"]) < 1e-6
     plan.close()
+
+
+@pytest.mark.parametrize("n,kw", [(256, dict()), (256, dict(k_cutoff=2.0)), (128, dict(k_cutoff=4.0, stream_factor=2)),
+                                  (128, dict(corner_modes=1)), (256, dict(stream_factor=8))])
+def test_pruned_columns_and_larger_grids(zd, oracle, ps, opk, n, kw):
+    """sizes where whole z-FFT tiles are pruned (identically-zero (kx,ky) columns are neither generated,
+    transformed nor read back), CornerModes (only the |k_i| == kmax rule prunes) and deep streaming"""
+    _compare(zd, oracle, ps, opk, n, fmt="RVZel", **kw)
+
+
+def test_plt_pruned_256(zd, oracle, ps, opk):
+    eig = oracle.synthetic_eigenmodes(48)
+    _compare(zd, oracle, ps, opk, 256, fmt="RVdoubleZel", eig=eig, qPLT=1, qPLTrescale=1, PLT_target_z=5.0,
+             stream_factor=2)
+
+
+def test_oversampling_invariance_on_gpu(zd, ps):
+    """README: PPD=2N with k_cutoff=2 sub-sampled x2 equals PPD=N with k_cutoff=1 (size-independent property)"""
+    lo = zd.generate(zd.make_params(128), ps)["records"]["d"]
+    hi = zd.generate(zd.make_params(256, k_cutoff=2.0, stream_factor=2), ps)["records"]["d"]
+    assert np.abs(hi[::2, ::2, ::2] - lo).max() < 1e-13 * np.abs(lo).max() + 1e-15
+
+
+def test_stream_factor_invariance_at_1024(zd, ps):
+    """full-size-ish property test (no oracle): the reductions of a PPD=1024 run do not depend on R"""
+    a = zd.generate(zd.make_params(1024, icformat="RVZel", stream_factor=1), ps, collect=False)
+    b = zd.generate(zd.make_params(1024, icformat="RVZel", stream_factor=4), ps, collect=False)
+    assert abs(a["density_variance"] - b["density_variance"]) <= 1e-11 * a["density_variance"]
+    assert np.abs(a["max_disp"] - b["max_disp"]).max() <= 1e-11 * np.abs(a["max_disp"]).max()
+    # the printed sanity check of the reference (zeldovich.cpp:987-996): rms pixel density vs sigma(R)
+    rms = np.sqrt(a["density_variance"] / 1024.0 ** 3)
+    pred = ps.sigmaR(720.0 / 1024 / 4.0) * 720.0 ** 1.5
+    assert 0.5 < rms / pred < 1.5
