@@ -69,6 +69,7 @@ struct zd_plan {
     // device tables
     double *d_pk = nullptr;  // x | y | y2
     int *d_lut = nullptr;
+    double *d_pktab = nullptr;
     double *d_eig = nullptr;
     u128 *d_rowstate = nullptr;
     cplx *d_twN = nullptr, *d_twL = nullptr;
@@ -281,6 +282,21 @@ int zd_plan_create(const zd_params *p, const zd_pk *pk, const double *eig, int64
         PLCHECK(hipMalloc((void **) &pl->d_twL, sizeof(cplx) * twL.size()));
         PLCHECK(hipMemcpy(pl->d_twL, twL.data(), sizeof(cplx) * twL.size(), hipMemcpyHostToDevice));
     }
+    // {P, 1/k^2} table over the integer |k|^2 that can carry power (zero rule of zeldovich.cpp:350-353)
+    if (!getenv("ZD_NO_PKTAB")) {
+        const double half2 = (double) pl->half * pl->half;
+        double nmax = p->corner_modes ? 3.0 * half2 : std::min(3.0 * half2, g.k2_cutoff / g.fundamental2 * (1 + 1e-9) + 2);
+        const long long n = (long long) nmax + 2;
+        if (n <= ((long long) 1 << 26)) {
+            PLCHECK(hipMalloc((void **) &pl->d_pktab, sizeof(double) * 2 * (size_t) n));
+            if (zd::launch_pk_table(g, (int) n, pl->d_pktab, 0)) {
+                zd_plan_destroy(pl);
+                return 1;
+            }
+            PLCHECK(hipDeviceSynchronize());
+            g.pk_tab = (const double2 *) pl->d_pktab;
+        }
+    }
     PLCHECK(hipMalloc((void **) &pl->d_red, sizeof(zd::Reduce)));
     PLCHECK(hipMemset(pl->d_red, 0, sizeof(zd::Reduce)));
 
@@ -374,6 +390,7 @@ void zd_plan_destroy(zd_plan *pl) {
     collect_events(pl);
     hipFree(pl->d_pk);
     hipFree(pl->d_lut);
+    hipFree(pl->d_pktab);
     hipFree(pl->d_eig);
     hipFree(pl->d_rowstate);
     hipFree(pl->d_twN);

@@ -3,6 +3,9 @@
 #include <stdint.h>
 #include "zd_fft.h"
 #include "zd_pcg.h"
+#if !defined(__HIPCC__)
+struct double2 { double x, y; };
+#endif
 
 namespace zd {
 
@@ -20,6 +23,7 @@ struct GenConst {
     // PowerSpectrum
     int pk_n, fixed_power, is_powerlaw;
     const double *pk_x, *pk_y, *pk_y2;
+    const double2 *pk_tab;    // {P(k), 1/k^2} indexed by integer kx^2+ky^2+kz^2 (NULL: evaluate per mode)
     const int *pk_lut;        // PK_LUT uniform cells over [x0, x_last] -> start segment
     double lut_x0, lut_inv_dx;
     double pk_norm, pk_smooth2, powerlaw_index;

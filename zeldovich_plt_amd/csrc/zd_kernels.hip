@@ -41,12 +41,13 @@ __device__ __forceinline__ u128 advance_bits(u128 s, uint64_t delta) {
 // table over ln k gives a start index and a short forward scan lands on exactly the segment the
 // bisection would return (largest klo with x[klo] <= v, clamped to [0, n-2]).
 template <bool PLAW>
-__device__ __forceinline__ double pk_power(const GenConst &g, double k) {
-    if (k <= 0.0) return 0.0;
+__device__ __forceinline__ double pk_power(const GenConst &g, double k2) {  // k2 = |k|^2
+    if (k2 <= 0.0) return 0.0;
     if constexpr (PLAW) {
-        return pow(k, g.powerlaw_index) * exp(-k * k * g.pk_smooth2) * g.pk_norm;
+        const double k = sqrt(k2);
+        return pow(k, g.powerlaw_index) * exp(-k2 * g.pk_smooth2) * g.pk_norm;
     } else {
-        const double v = log(k);
+        const double v = 0.5 * log(k2);  // = log(sqrt(k2)) to 1 ulp
         int c   = (int) ((v - g.lut_x0) * g.lut_inv_dx);
         c       = c < 0 ? 0 : (c >= PK_LUT ? PK_LUT - 1 : c);
         int klo = g.pk_lut[c];
@@ -58,7 +59,7 @@ __device__ __forceinline__ double pk_power(const GenConst &g, double k) {
         const double a = (xh - v) / h, b = (v - xl) / h;
         const double val = a * g.pk_y[klo] + b * g.pk_y[khi]
                            + ((a * a * a - a) * g.pk_y2[klo] + (b * b * b - b) * g.pk_y2[khi]) * (h * h) / 6.0;
-        return exp(val - k * k * g.pk_smooth2) * g.pk_norm;
+        return exp(val - k2 * g.pk_smooth2) * g.pk_norm;
     }
 }
 
@@ -71,13 +72,35 @@ __device__ __forceinline__ bool mode_is_zero(const GenConst &g, int kx, int ky, 
     return false;
 }
 
-// cgauss<2> given the two raw draws
-template <bool PLAW>
-__device__ __forceinline__ void gauss_mode(const GenConst &g, double kmag, uint64_t r1, uint64_t r2,
-                                           double &dr, double &di) {
-    const double Pk = (g.ablate & 1) ? 1e-9 * kmag : pk_power<PLAW>(g, kmag);
-    double R        = zdpcg::u01(r1);
-    double theta    = zdpcg::u01(r2);
+// sin and cos of 2*pi*theta for theta in (0,1]: exact octant reduction (theta*8 is exact), then the
+// fdlibm kernel polynomials on [0, pi/4].  cgauss<2> (power_spectrum.cpp:353-356) evaluates
+// cos/sin(fl(2*M_PI*theta)); the two differ by the rounding of that product, ~4e-16 absolute.
+__device__ __forceinline__ void sincos2pi(double theta, double &sn, double &cs) {
+    const double t8 = theta * 8.0;
+    const int q     = (int) t8;
+    const double f  = t8 - (double) q;
+    const int k     = q & 7;
+    const double r  = (k & 1) ? 1.0 - f : f;
+    const double a  = 0.78539816339744830962 * r;  // pi/4 * r
+    const double z  = a * a;
+    // __kernel_sin / __kernel_cos coefficients (fdlibm k_sin.c, k_cos.c)
+    const double sp = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04
+                      + z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+    const double s0 = a + a * z * sp;
+    const double cp = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05
+                      + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+    const double c0 = 1.0 - (0.5 * z - z * z * cp);
+    const bool swap = ((k + 1) & 2) != 0;  // k = 1,2,5,6
+    const double sv = swap ? c0 : s0, cv = swap ? s0 : c0;
+    sn = (k >= 4) ? -sv : sv;                      // k = 4..7: sin < 0
+    cs = (k >= 2 && k <= 5) ? -cv : cv;            // k = 2..5: cos < 0
+}
+
+// cgauss<2> (power_spectrum.cpp:338-359) given P(k) and the two raw draws
+__device__ __forceinline__ void gauss_from_pk(const GenConst &g, double Pk, uint64_t r1, uint64_t r2, double &dr,
+                                              double &di) {
+    double R           = zdpcg::u01(r1);
+    const double theta = zdpcg::u01(r2);
     if (g.ablate & 2) {
         dr = R * Pk;
         di = theta * Pk;
@@ -87,53 +110,74 @@ __device__ __forceinline__ void gauss_mode(const GenConst &g, double kmag, uint6
         R = sqrt(-Pk * log(R));
     else
         R = sqrt(Pk);
-    theta = (2 * 3.14159265358979323846) * theta;
-    double s, c;
-    sincos(theta, &s, &c);
-    dr = R * c;
-    di = R * s;
+    double sn, cs;
+    sincos2pi(theta, sn, cs);
+    dr = R * cs;
+    di = R * sn;
+}
+template <bool PLAW>
+__device__ __forceinline__ void gauss_mode(const GenConst &g, double k2, uint64_t r1, uint64_t r2, double &dr,
+                                           double &di) {
+    gauss_from_pk(g, (g.ablate & 1) ? 1e-9 * k2 : pk_power<PLAW>(g, k2), r1, r2, dr, di);
 }
 
-// interp_eigmode + get_eigenmode (src/zeldovich.cpp:154-276); out = e_x,e_y,e_z (weighted), lambda
-__device__ void get_eigenmode_dev(const GenConst &g, int kx, int ky, int kz, double (&out)[4]) {
-    const long long N = g.N, ep = g.eig_ppd;
-    const long long halfppd = ep / 2 + 1, ppdhalf = ep / 2;
-    const int ikx = kx < 0 ? (int) N + kx : kx;
-    const int iky = ky < 0 ? (int) N + ky : ky;
-    int ikz       = kz < 0 ? (int) N + kz : kz;
-    ikz           = ikz > N / 2 ? (int) N - ikz : ikz;
+// interp_eigmode + get_eigenmode (src/zeldovich.cpp:154-276); out = e_x,e_y,e_z (weighted), lambda.
+// The per-axis part of the lookup (table index or lower/upper corner + fraction, incl. the "never
+// interpolate across the +-Nyquist seam" rule :176-183 and the wrap :194-198) depends on one wavenumber
+// only, so the generator hoists x (fixed per thread) and y (fixed per row) out of its mode loop.
+struct EigAxis {
+    int l, h;   // exact stride: l = table index, h unused; interpolation: lower / upper corner
+    double f;   // fraction towards h
+};
+__device__ __forceinline__ EigAxis eig_axis(const GenConst &g, int ik) {  // ik = table-space index 0..N-1
+    EigAxis a;
+    const int N = g.N, ep = (int) g.eig_ppd;
+    if (ep % N == 0) {
+        a.l = ik * (ep / N);
+        a.h = a.l;
+        a.f = 0.0;
+        return a;
+    }
+    const int halfppd = ep / 2 + 1, ppdhalf = ep / 2;
+    double f = ((double) ep) / N * ik;
+    if (f > ppdhalf && f < halfppd) f = floor(f + 1);
+    a.l = (int) f;
+    a.h = a.l + 1;
+    if (a.h == ep) a.h = 0;
+    a.f = f - a.l;
+    return a;
+}
+__device__ __forceinline__ int eig_index_x(const GenConst &g, int kx) { return kx < 0 ? g.N + kx : kx; }
+__device__ __forceinline__ int eig_index_z(const GenConst &g, int kz) {
+    const int i = kz < 0 ? g.N + kz : kz;
+    return i > g.N / 2 ? g.N - i : i;  // +k half-space of the rfft layout
+}
+__device__ __forceinline__ void get_eigenmode_dev(const GenConst &g, int kx, int ky, int kz, const EigAxis &ax,
+                                                  const EigAxis &ay, const EigAxis &az, double (&out)[4]) {
+    const int ep = (int) g.eig_ppd, halfppd = ep / 2 + 1;
     const double k2 = (double) (kx * kx + ky * ky + kz * kz);
     double eh[4];
-    const double *E = g.eig;
-#define ZD_EIG(_x, _y, _z, _i) E[((long long) (_x) * ep + (_y)) * halfppd * 4 + (long long) (_z) * 4 + (_i)]
-    if (ep % N == 0) {
-        const long long sx = ikx * ep / N, sy = iky * ep / N, sz = ikz * ep / N;
-#pragma unroll
-        for (int i = 0; i < 4; i++) eh[i] = ZD_EIG(sx, sy, sz, i);
+    const double2 *E = reinterpret_cast<const double2 *>(g.eig);  // [x][y][z][4] doubles = 2 double2 per entry
+    if (ep % g.N == 0) {
+        const int i = ((ax.l * ep + ay.l) * halfppd + az.l) * 2;
+        const double2 q0 = E[i], q1 = E[i + 1];
+        eh[0] = q0.x;
+        eh[1] = q0.y;
+        eh[2] = q1.x;
+        eh[3] = q1.y;
     } else {
-        double fx = ((double) ep) / N * ikx, fy = ((double) ep) / N * iky, fz = ((double) ep) / N * ikz;
-        if (fx > ppdhalf && fx < halfppd) fx = floor(fx + 1);
-        if (fy > ppdhalf && fy < halfppd) fy = floor(fy + 1);
-        if (fz > ppdhalf && fz < halfppd) fz = floor(fz + 1);
-        int xl = (int) fx, xh = xl + 1, yl = (int) fy, yh = yl + 1, zl = (int) fz, zh = zl + 1;
-        if (xh == ep) xh = 0;
-        if (yh == ep) yh = 0;
-        if (zh == ep) zh = 0;
-        fx -= xl;
-        fy -= yl;
-        fz -= zl;
         // trilinear weights and corners in the reference's order f[0..7] = (x l/h, y l/h, z l/h) with z
         // fastest; accumulated left to right like the single expression of zeldovich.cpp:218-225.
         // Corners with zero weight are not read (the reference reads them: same value unless non-finite).
         eh[0] = eh[1] = eh[2] = eh[3] = 0.0;
-#pragma unroll 1
+#pragma unroll 2
         for (int c = 0; c < 8; c++) {
-            const double wx = (c & 4) ? fx : 1 - fx, wy = (c & 2) ? fy : 1 - fy, wz = (c & 1) ? fz : 1 - fz;
+            const double wx = (c & 4) ? ax.f : 1 - ax.f, wy = (c & 2) ? ay.f : 1 - ay.f, wz = (c & 1) ? az.f : 1 - az.f;
             const double wgt = wx * wy * wz;
             if (wgt != 0) {
-                const int cx = (c & 4) ? xh : xl, cy = (c & 2) ? yh : yl, cz = (c & 1) ? zh : zl;
-                const double2 *q = reinterpret_cast<const double2 *>(&ZD_EIG(cx, cy, cz, 0));
-                const double2 q0 = q[0], q1 = q[1];
+                const int cx = (c & 4) ? ax.h : ax.l, cy = (c & 2) ? ay.h : ay.l, cz = (c & 1) ? az.h : az.l;
+                const int i  = ((cx * ep + cy) * halfppd + cz) * 2;
+                const double2 q0 = E[i], q1 = E[i + 1];
                 eh[0] += wgt * q0.x;
                 eh[1] += wgt * q0.y;
                 eh[2] += wgt * q1.x;
@@ -141,18 +185,31 @@ __device__ void get_eigenmode_dev(const GenConst &g, int kx, int ky, int kz, dou
             }
         }
     }
-#undef ZD_EIG
     eh[2] *= (kz < 0 ? -1.0 : 1.0);  // copysign(1, kz) for an int: kz = 0 -> +1
-    const double mag = sqrt(eh[0] * eh[0] + eh[1] * eh[1] + eh[2] * eh[2]);
-    eh[0] /= mag;
-    eh[1] /= mag;
-    eh[2] /= mag;
+    const double imag = 1.0 / sqrt(eh[0] * eh[0] + eh[1] * eh[1] + eh[2] * eh[2]);
+    eh[0] *= imag;  // the reference divides each component (zeldovich.cpp:257-259): <= 1 ulp apart
+    eh[1] *= imag;
+    eh[2] *= imag;
     double norm = k2 / (kx * eh[0] + ky * eh[1] + kz * eh[2]);
     if (k2 == 0.0 || !isfinite(norm)) norm = 0.0;
     out[0] = norm * eh[0];
     out[1] = norm * eh[1];
     out[2] = norm * eh[2];
     out[3] = eh[3];
+}
+
+// table of {P(k), 1/k^2} indexed by the integer kx^2+ky^2+kz^2 (built with the same device code that
+// would evaluate it per mode, so table and direct evaluation agree bitwise)
+template <bool PLAW>
+__global__ void k_pk_table(GenConst g, int n, double2 *__restrict__ tab) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double k2 = (double) i * g.fundamental2;
+    double2 v;
+    v.x = pk_power<PLAW>(g, k2);
+    if (k2 == 0.0) k2 = 1.0;
+    v.y = 1.0 / k2;
+    tab[i] = v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -188,6 +245,11 @@ __global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, JobList 
             all_zero = all_zero && column_is_zero(S, xi > half ? xi - N : xi, ky);
         }
         if (all_zero) return;
+    }
+    EigAxis eax = {0, 0, 0.0}, eay = {0, 0, 0.0};
+    if constexpr (PLT) {
+        eax = eig_axis(g, eig_index_x(g, kx));
+        eay = eig_axis(g, ky);
     }
     u128 s = 0;
     if (ky != 0) {  // state one step ahead of the first mode's counter
@@ -244,18 +306,31 @@ __global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, JobList 
             const int kxm = xs > half ? xs - N : xs, kzm = zs > half ? zs - N : zs;  // generated mode
             const int k2i = kxm * kxm + ky * ky + kzm * kzm;
             double k2v    = (double) k2i * g.fundamental2;
-            double dr = 0.0, di = 0.0;
-            if (!zero && !mode_is_zero(g, kxm, ky, kzm, k2v)) gauss_mode<PLAW>(g, sqrt(k2v), r1, r2, dr, di);
+            double dr = 0.0, di = 0.0, ik2 = 1.0;
+            if (!zero && !mode_is_zero(g, kxm, ky, kzm, k2v)) {
+                if (g.pk_tab) {  // {P(k), 1/k^2} by integer k^2
+                    const double2 pv = g.pk_tab[k2i];
+                    ik2 = pv.y;
+                    gauss_from_pk(g, (g.ablate & 1) ? 1e-9 * k2v : pv.x, r1, r2, dr, di);
+                } else {
+                    gauss_mode<PLAW>(g, k2v, r1, r2, dr, di);
+                    ik2 = 1.0 / (k2v == 0.0 ? 1.0 : k2v);
+                }
+            }
             if (dr == 0.0 && di == 0.0) continue;  // zero modes add nothing (zeldovich.cpp:403,435-438)
-            if (k2v == 0.0) k2v = 1.0;
-            const double ik2 = 1.0 / k2v;
             double sx, sy, sz, f = 1.0;
             if constexpr (PLT) {
                 double e[4];
                 if (g.ablate & 8) {
                     e[0] = kxm; e[1] = ky; e[2] = kzm; e[3] = 1.0 - 1e-9 * k2i;
-                } else
-                    get_eigenmode_dev(g, kxm, ky, kzm, e);
+                } else {
+                    const EigAxis eaz = eig_axis(g, eig_index_z(g, kzm));
+                    if (cj) {  // mirrored source mode (ky = 0 plane only): its own x axis
+                        const EigAxis eaxm = eig_axis(g, eig_index_x(g, kxm));
+                        get_eigenmode_dev(g, kxm, ky, kzm, eaxm, eay, eaz, e);
+                    } else
+                        get_eigenmode_dev(g, kxm, ky, kzm, eax, eay, eaz, e);
+                }
                 f = (sqrt(1. + 24 * e[3] * g.f_cluster) - 1) * .25;
                 double rescale = 1.0;
                 if (g.qPLTrescale) rescale = exp(g.ln_growth_ratio * (g.target_f - f));
@@ -304,7 +379,8 @@ __global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, JobList 
         }
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
-            const long long idx = (((long long) j * nky + kyl) * L + k2) * N + x;
+            // a slab holds < 2^31 elements (1.5 GB / 16 B): 32-bit index arithmetic
+            const unsigned idx = (unsigned) (((j * nky + kyl) * L + k2) * N + x);
             Y[idx] = cplx{accr[j] * pr - acci[j] * pi, accr[j] * pi + acci[j] * pr};
         }
     }
@@ -331,9 +407,9 @@ __global__ void k_test_modes(GenConst g, long long n, const int *__restrict__ kx
         double dr = 0, di = 0;
         if (!mode_is_zero(g, kx, ky, kz, k2)) {
             if (g.is_powerlaw)
-                gauss_mode<true>(g, sqrt(k2), r1, r2, dr, di);
+                gauss_mode<true>(g, k2, r1, r2, dr, di);
             else
-                gauss_mode<false>(g, sqrt(k2), r1, r2, dr, di);
+                gauss_mode<false>(g, k2, r1, r2, dr, di);
         }
         D[2 * i]     = dr;
         D[2 * i + 1] = di;
@@ -677,6 +753,16 @@ int launch_gen(const GenConst &g, const GenJumps &J, const JobList &jobs, const 
     GCASE(7, true)
 #undef GCASE
     return 2;
+}
+
+int launch_pk_table(const GenConst &g, int n, void *tab, hipStream_t st) {
+    dim3 grid((n + 255) / 256), block(256);
+    if (g.is_powerlaw)
+        hipLaunchKernelGGL(k_pk_table<true>, grid, block, 0, st, g, n, (double2 *) tab);
+    else
+        hipLaunchKernelGGL(k_pk_table<false>, grid, block, 0, st, g, n, (double2 *) tab);
+    ZD_LAUNCH_CHECK();
+    return 0;
 }
 
 int launch_test_modes(const GenConst &g, long long n, const int *kxyz, uint64_t *draws, double *D, hipStream_t st) {
