@@ -509,10 +509,17 @@ __global__ __launch_bounds__(W *N / E, MINW) void k_yfft(StoreLayout S, const cp
 // ------------------------------------------------------------------------------------------------
 // k_xfft: x FFT of ROWS rows x NA arrays per workgroup, then the WriteParticlesSlab epilogue.
 //   grid: (N/ROWS, nplanes)   block: ROWS*NA*N/E
+// passes over x of the epilogue: keep the field staging area of a workgroup <= 64 KB
+constexpr int XFFT_NH(int N, int NA, int ROWS) {
+    int nh = 1;
+    while ((long long) ROWS * 2 * NA * N * 8 / nh > 65536 && nh < 16) nh *= 2;
+    return nh;
+}
+
 __device__ __forceinline__ unsigned long long dbits(double v) { return (unsigned long long) __double_as_longlong(v); }
 
 template <int N, int E, int NA, int ROWS>
-__global__ __launch_bounds__(ROWS *NA *N / E) void k_xfft(StoreLayout S, EpiConst ec, const cplx *__restrict__ tw,
+__global__ __launch_bounds__(ROWS *NA *N / E, (ROWS * NA * N / E == 512 ? 4 : 1)) void k_xfft(StoreLayout S, EpiConst ec, const cplx *__restrict__ tw,
                                                          const cplx *__restrict__ data, int plane0,
                                                          int z_first, int z_step, char *__restrict__ records,
                                                          float *__restrict__ density, Reduce *__restrict__ red) {
@@ -534,87 +541,92 @@ __global__ __launch_bounds__(ROWS *NA *N / E) void k_xfft(StoreLayout S, EpiCons
         im[e] = v.y;
     }
     zdfft::fft_line<PL, LDS>(re, im, t, line, lds, tw);
-    __syncthreads();
-    // fields of this line into LDS: fld[(row*2*NA + 2a + {0,1})*N + x]
-    double *fld = lds;
-#pragma unroll
-    for (int e = 0; e < E; e++) {
-        const int xx = t + T * e;
-        fld[(row * 2 * NA + 2 * a) * N + xx]     = re[e];
-        fld[(row * 2 * NA + 2 * a + 1) * N + xx] = im[e];
-    }
-    __syncthreads();
 
     // ---- WriteParticlesSlab (src/output.cpp:86-203) ----
+    // The unpacked fields go through LDS in NH passes over x so that the staging area stays <= 64 KB
+    // (two workgroups per CU): pass h covers x in [h*N/NH, (h+1)*N/NH) = elements e in [h*E/NH, ...).
+    constexpr int NH = XFFT_NH(N, NA, ROWS), NXH = N / NH, EH = E / NH;
     const int z = z_first + z_step * (int) blockIdx.y;
     double ssq = 0.0, mp[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
     const long long plane_rec0 = (long long) blockIdx.y * N * N;
-    for (int i = threadIdx.x; i < ROWS * N; i += NT) {
-        const int r = i / N, xx = i - r * N;
-        const int yy = blockIdx.x * ROWS + r;
-        const double *f = fld + (r * 2 * NA) * N + xx;
-        const double dens = f[0];
-        ssq += dens * dens;
-        const long long pidx = plane_rec0 + (long long) yy * N + xx;
-        if (density) density[pidx] = (float) dens;
-        if (NA >= 2) {
-            double pos[3], vel[3];
-            pos[0] = f[1 * N];
-            pos[1] = f[2 * N];
-            pos[2] = f[3 * N];
-            if (NA == 4) {
-                vel[0] = f[5 * N] * ec.vnorm;
-                vel[1] = f[6 * N] * ec.vnorm;
-                vel[2] = f[7 * N] * ec.vnorm;
-            } else {
-                vel[0] = pos[0] * ec.vnorm;
-                vel[1] = pos[1] * ec.vnorm;
-                vel[2] = pos[2] * ec.vnorm;
-            }
+    double *fld = lds;  // fld[(row*2*NA + 2a + {0,1})*NXH + x - h*NXH]
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
-                mp[j] = fmax(mp[j], pos[j]);
-                mn[j] = fmax(mn[j], -pos[j]);
-            }
-            if (records) {
-                char *rec = records + pidx * ec.recsize;
-                const unsigned int ij = ((unsigned int) z & 0xffffu) | (((unsigned int) yy & 0xffffu) << 16);
-                const unsigned int k0 = ((unsigned int) xx & 0xffffu);
-                if (ec.icformat == 1) {  // RVZel: u16 i,j,k + pad, float displ[3], vel[3]
-                    uint4 q0, q1;
-                    q0.x = ij;
-                    q0.y = k0;
-                    q0.z = __float_as_uint((float) pos[2]);
-                    q0.w = __float_as_uint((float) pos[1]);
-                    q1.x = __float_as_uint((float) pos[0]);
-                    q1.y = __float_as_uint((float) vel[2]);
-                    q1.z = __float_as_uint((float) vel[1]);
-                    q1.w = __float_as_uint((float) vel[0]);
-                    reinterpret_cast<uint4 *>(rec)[0] = q0;
-                    reinterpret_cast<uint4 *>(rec)[1] = q1;
-                } else if (ec.icformat == 2) {  // RVdoubleZel: 56 B
-                    unsigned long long *r8 = reinterpret_cast<unsigned long long *>(rec);
-                    r8[0] = (unsigned long long) ij | ((unsigned long long) k0 << 32);
-                    double *d = reinterpret_cast<double *>(rec + 8);
-                    d[0] = pos[2];
-                    d[1] = pos[1];
-                    d[2] = pos[0];
-                    d[3] = vel[2];
-                    d[4] = vel[1];
-                    d[5] = vel[0];
-                } else if (ec.icformat == 0) {  // Zeldovich: u16 i,j,k + pad, double displ[3]
-                    double2 q0, q1;
-                    q0.x = __longlong_as_double((long long) ((unsigned long long) ij | ((unsigned long long) k0 << 32)));
-                    q0.y = pos[2];
-                    q1.x = pos[1];
-                    q1.y = pos[0];
-                    reinterpret_cast<double2 *>(rec)[0] = q0;
-                    reinterpret_cast<double2 *>(rec)[1] = q1;
-                } else {  // ZelSimple: float displ[3]
-                    float *d = reinterpret_cast<float *>(rec);
-                    d[0] = (float) pos[2];
-                    d[1] = (float) pos[1];
-                    d[2] = (float) pos[0];
+    for (int h = 0; h < NH; h++) {
+        __syncthreads();
+#pragma unroll
+        for (int e2 = 0; e2 < EH; e2++) {
+            const int e = h * EH + e2, xl = t + T * e - h * NXH;
+            fld[(row * 2 * NA + 2 * a) * NXH + xl]     = re[e];
+            fld[(row * 2 * NA + 2 * a + 1) * NXH + xl] = im[e];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < ROWS * NXH; i += NT) {
+            const int r = i / NXH, xl = i - r * NXH, xx = xl + h * NXH;
+            const int yy = blockIdx.x * ROWS + r;
+            const double *f = fld + (r * 2 * NA) * NXH + xl;
+            const double dens = f[0];
+            ssq += dens * dens;
+            const long long pidx = plane_rec0 + (long long) yy * N + xx;
+            if (density) density[pidx] = (float) dens;
+            if (NA >= 2) {
+                double pos[3], vel[3];
+                pos[0] = f[1 * NXH];
+                pos[1] = f[2 * NXH];
+                pos[2] = f[3 * NXH];
+                if (NA == 4) {
+                    vel[0] = f[5 * NXH] * ec.vnorm;
+                    vel[1] = f[6 * NXH] * ec.vnorm;
+                    vel[2] = f[7 * NXH] * ec.vnorm;
+                } else {
+                    vel[0] = pos[0] * ec.vnorm;
+                    vel[1] = pos[1] * ec.vnorm;
+                    vel[2] = pos[2] * ec.vnorm;
+                }
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    mp[j] = fmax(mp[j], pos[j]);
+                    mn[j] = fmax(mn[j], -pos[j]);
+                }
+                if (records) {
+                    char *rec = records + pidx * ec.recsize;
+                    const unsigned int ij = ((unsigned int) z & 0xffffu) | (((unsigned int) yy & 0xffffu) << 16);
+                    const unsigned int k0 = ((unsigned int) xx & 0xffffu);
+                    if (ec.icformat == 1) {  // RVZel: u16 i,j,k + pad, float displ[3], vel[3]
+                        uint4 q0, q1;
+                        q0.x = ij;
+                        q0.y = k0;
+                        q0.z = __float_as_uint((float) pos[2]);
+                        q0.w = __float_as_uint((float) pos[1]);
+                        q1.x = __float_as_uint((float) pos[0]);
+                        q1.y = __float_as_uint((float) vel[2]);
+                        q1.z = __float_as_uint((float) vel[1]);
+                        q1.w = __float_as_uint((float) vel[0]);
+                        reinterpret_cast<uint4 *>(rec)[0] = q0;
+                        reinterpret_cast<uint4 *>(rec)[1] = q1;
+                    } else if (ec.icformat == 2) {  // RVdoubleZel: 56 B
+                        unsigned long long *r8 = reinterpret_cast<unsigned long long *>(rec);
+                        r8[0] = (unsigned long long) ij | ((unsigned long long) k0 << 32);
+                        double *d = reinterpret_cast<double *>(rec + 8);
+                        d[0] = pos[2];
+                        d[1] = pos[1];
+                        d[2] = pos[0];
+                        d[3] = vel[2];
+                        d[4] = vel[1];
+                        d[5] = vel[0];
+                    } else if (ec.icformat == 0) {  // Zeldovich: u16 i,j,k + pad, double displ[3]
+                        double2 q0, q1;
+                        q0.x = __longlong_as_double((long long) ((unsigned long long) ij | ((unsigned long long) k0 << 32)));
+                        q0.y = pos[2];
+                        q1.x = pos[1];
+                        q1.y = pos[0];
+                        reinterpret_cast<double2 *>(rec)[0] = q0;
+                        reinterpret_cast<double2 *>(rec)[1] = q1;
+                    } else {  // ZelSimple: float displ[3]
+                        float *d = reinterpret_cast<float *>(rec);
+                        d[0] = (float) pos[2];
+                        d[1] = (float) pos[1];
+                        d[2] = (float) pos[0];
+                    }
                 }
             }
         }
@@ -853,7 +865,7 @@ template <int N, int E, int NA, int ROWS>
 static int launch_xfft_t(const StoreLayout &S, const EpiConst &ec, const void *tw, const void *data, int plane0,
                          int nplanes, int z_first, int z_step, void *records, float *density, Reduce *red, hipStream_t st) {
     constexpr int WL = ROWS * NA, threads = WL * N / E;
-    constexpr size_t fft_dbl = zdfft::LineInner<N, WL>::SIZE, fld_dbl = (size_t) ROWS * 2 * NA * N;
+    constexpr size_t fft_dbl = zdfft::LineInner<N, WL>::SIZE, fld_dbl = (size_t) ROWS * 2 * NA * N / XFFT_NH(N, NA, ROWS);
     const size_t shmem = sizeof(double) * (fft_dbl > fld_dbl ? fft_dbl : fld_dbl);
     if (shmem > 160 * 1024) {
         fprintf(stderr, "zeldovich_hip: x pass for PPD %d with %d arrays needs %zu B of LDS (> 160 KB): unsupported\n", N, NA, shmem);
