@@ -340,10 +340,12 @@ int zd_plan_create(const zd_params *p, const zd_pk *pk, const double *eig, int64
                 lBk = a; lBz = b; S.rows_outer = o;
             }
         }
-        while ((1 << lBk) > pl->Hq) lBk--;
+        const int max_lBk = S.lHq + (nranks == 1 ? 1 : 0);  // one rank: self + twin slots in ONE block
+        while (lBk > max_lBk) lBk--;
         while ((1 << lBz) > pl->Zq) lBz--;
         S.lBk = lBk;
         S.lBz = lBz;
+        S.one_block = (nranks == 1 && lBk == S.lHq + 1 && lBz == 0 && !S.rows_outer) ? 1 : 0;
         int row_pad = 0;  // in complex elements
         if (const char *env = getenv("ZD_PAD")) sscanf(env, "%d", &row_pad);
         S.pitch      = pl->N + row_pad;
@@ -718,7 +720,7 @@ int zd_test_yfft_variant(int32_t n, int32_t variant, int32_t narray, int32_t npl
         lBk = (lt + 1) / 2; lBz = lt - lBk;
         while ((1 << lBz) > nplanes) lBz--;
     }
-    S.lBk = lBk; S.lBz = lBz; S.rows_outer = 0; S.pitch = n; S.prune = 0; S.kmax = 0; S.fund2 = 0; S.k2_cutoff = 0;
+    S.lBk = lBk; S.lBz = lBz; S.rows_outer = 0; S.one_block = 0; S.pitch = n; S.prune = 0; S.kmax = 0; S.fund2 = 0; S.k2_cutoff = 0;
     S.a_rows = (1 << lBk) << lBz;
     S.zb_rows = S.a_rows * narray;
     S.kb_rows = S.zb_rows * (nplanes >> lBz);

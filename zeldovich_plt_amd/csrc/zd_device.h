@@ -62,6 +62,7 @@ struct StoreLayout {
     int lHq;         // log2(Hq): Hq, Zq, N are powers of two, so every division is a shift
     int lBk, lBz;    // log2 of the block edge in row slots / planes
     int rows_outer;  // order inside a block: 0 = [plane][slot][x], 1 = [slot][plane][x]
+    int one_block;   // 1: single rank and Bk = 2*Hq, Bz = 1 -> slot s of (plane, array) is row s of one contiguous region
     int pitch;       // row pitch in elements (>= N)
     // all strides are in ROWS (32-bit: a 275 GB store has < 2^24 rows) so that one 32x32->64 multiply
     // per element turns a row index into an address

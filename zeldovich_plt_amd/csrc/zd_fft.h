@@ -202,31 +202,58 @@ ZD_HD int out_index(int t, int q, int r) {
 // LDS addressing policies: idx(o, w) = position of element o of line w inside the tile.
 //  ColsInner: lines interleaved ([o][w]) — lanes run along w (strided-axis passes: y and z)
 //  LineInner: each line contiguous with one pad double per 16 ([w][o + o/16]) — lanes run along t
+// Both are (piecewise) linear in o, which the exchange code exploits: ONE address per thread plus
+// compile-time offsets (ds_read/ds_write immediates) instead of 16 separately computed addresses.
+//   lin(delta): idx(o + delta, w) == idx(o, w) + step(delta) for every o
+//   unit16:     idx(o + r, w) == idx(o, w) + ustep(r) when o % 16 == 0 and 0 <= r < 16
 template <int N, int W>
 struct ColsInner {
     static constexpr int SIZE = N * W;
     static ZD_HD int idx(int o, int w) { return o * W + w; }
+    static constexpr bool lin(int) { return true; }
+    static constexpr int step(int delta) { return delta * W; }
+    static constexpr int ustep(int r) { return r * W; }
 };
 template <int N, int W>
 struct LineInner {
     static constexpr int PITCH = N + N / 16;
     static constexpr int SIZE  = PITCH * W;
     static ZD_HD int idx(int o, int w) { return w * PITCH + o + (o >> 4); }
+    static constexpr bool lin(int delta) { return delta % 16 == 0; }
+    static constexpr int step(int delta) { return delta + delta / 16; }
+    static constexpr int ustep(int r) { return r; }
 };
 
 template <class PL, int P, class LDS>
 ZD_HD void xchg_write(const double (&v)[PL::E], int t, int w, double *lds) {
-    constexpr int E = PL::E, R = PL::radix(P), B = E / R;
+    constexpr int E = PL::E, R = PL::radix(P), B = E / R, NS = PL::ns(P), T = PL::T;
 #pragma unroll
     for (int q = 0; q < B; q++) {
+        const int j    = t + q * T;
+        const int o0   = (j / NS) * (NS * R) + (j & (NS - 1));  // output 0 of butterfly j
+        const int base = LDS::idx(o0, w);
 #pragma unroll
-        for (int r = 0; r < R; r++) lds[LDS::idx(out_index<PL, P>(t, q, r), w)] = v[q + r * B];
+        for (int r = 0; r < R; r++) {
+            if constexpr (LDS::lin(NS))
+                lds[base + LDS::step(r * NS)] = v[q + r * B];
+            else if constexpr (NS == 1 && R == 16)  // o0 = 16 j: a multiple of 16
+                lds[base + LDS::ustep(r)] = v[q + r * B];
+            else
+                lds[LDS::idx(o0 + r * NS, w)] = v[q + r * B];
+        }
     }
 }
 template <class PL, class LDS>
 ZD_HD void xchg_read(double (&v)[PL::E], int t, int w, const double *lds) {
+    constexpr int T = PL::T;
+    if constexpr (LDS::lin(T)) {
+        const int base = LDS::idx(t, w);
 #pragma unroll
-    for (int e = 0; e < PL::E; e++) v[e] = lds[LDS::idx(t + PL::T * e, w)];
+        for (int e = 0; e < PL::E; e++) v[e] = lds[base + LDS::step(T * e)];
+    } else {
+#pragma unroll
+        for (int e = 0; e < PL::E; e++) v[e] = lds[LDS::idx(t + T * e, w)];
+    }
 }
 
 #if defined(__HIPCC__)

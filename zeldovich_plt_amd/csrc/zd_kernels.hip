@@ -467,9 +467,11 @@ __global__ __launch_bounds__(W *L / E) void k_zfft(JobList jobs, StoreLayout S, 
     // the twin row sits a constant number of rows away from the self row (same plane, same array)
     const int drow = store_row(S, 0, 0, 0, loc_twin) - store_row(S, 0, 0, 0, loc_self);
     const int xt   = (N - x) & (N - 1);
+    int t2 = t;
+    asm volatile("" : "+v"(t2));  // keep the store-address arithmetic after the FFT (register pressure)
 #pragma unroll
     for (int e = 0; e < E; e++) {
-        const int z2  = t + T * e;
+        const int z2  = t2 + T * e;
         const int dst = z2 >> lZq, zl = z2 & (Zq - 1);  // Zq = 2^lZq
         const int row = store_row(S, dst, zl, arr, loc_self);
         if (st_self) out[(long long) row * S.pitch + x] = cplx{re[e], im[e]};
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(W *L / E) void k_zfft(JobList jobs, StoreLayout S, 
 
 // ------------------------------------------------------------------------------------------------
 // k_yfft: in-place y FFT of the block store.  grid: (N/W, narray, nplanes)  block: W*N/E
-template <int N, int E, int W, int MINW = 1>
+template <int N, int E, int W, int MINW = 1, bool ONEBLOCK = false>
 __global__ __launch_bounds__(W *N / E, MINW) void k_yfft(StoreLayout S, const cplx *__restrict__ tw, cplx *__restrict__ data) {
     using PL  = zdfft::Plan<N, E>;
     using LDS = zdfft::ColsInner<N, W>;
@@ -487,23 +489,53 @@ __global__ __launch_bounds__(W *N / E, MINW) void k_yfft(StoreLayout S, const cp
     constexpr int T = PL::T;
     const int w = threadIdx.x % W, t = threadIdx.x / W;
     const int x = blockIdx.x * W + w;
-    cplx *base = data + x;
     const int zl = blockIdx.z, a = blockIdx.y;
     const int kxs = x > N / 2 ? x - N : x;
     double re[E], im[E];
+    if constexpr (ONEBLOCK) {
+        // single rank, all 2*Hq row slots of a (plane, array) contiguous: one 64-bit scalar base per
+        // workgroup and 32-bit byte offsets per element (half the address registers, no spills)
+        char *base = reinterpret_cast<char *>(data + (long long) store_row(S, 0, zl, a, 0) * S.pitch);
+        const unsigned xb = (unsigned) x * 16u, pb = (unsigned) S.pitch * 16u;
 #pragma unroll
-    for (int e = 0; e < E; e++) {
-        const int ky = t + T * e;
-        // Nyquist row (zeldovich.cpp:644-650) and pruned columns are identically zero: not read
-        const bool skip = (ky == N / 2) || ((S.prune & 4) && column_is_zero(S, kxs, ky > N / 2 ? ky - N : ky));
-        cplx v = cplx{0.0, 0.0};
-        if (!skip) v = base[row_offset(S, zl, a, ky)];
-        re[e] = v.x;
-        im[e] = v.y;
+        for (int e = 0; e < E; e++) {
+            const int ky = t + T * e;
+            const bool skip = (ky == N / 2) || ((S.prune & 4) && column_is_zero(S, kxs, ky > N / 2 ? ky - N : ky));
+            const unsigned slot = ky < N / 2 ? ky : N / 2 + (N - ky);
+            cplx v = cplx{0.0, 0.0};
+            if (!skip) v = *reinterpret_cast<const cplx *>(base + (slot * pb + xb));
+            re[e] = v.x;
+            im[e] = v.y;
+        }
+        zdfft::fft_line<PL, LDS>(re, im, t, w, lds, tw);
+        // the store offsets equal the load offsets; recompute them from a laundered thread index so the
+        // compiler does not keep 16 offset registers alive (and spill them) across the whole FFT
+        int t2 = t;
+        asm volatile("" : "+v"(t2));
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int y = t2 + T * e;
+            const unsigned slot = y < N / 2 ? y : (y == N / 2 ? N / 2 : N / 2 + (N - y));
+            *reinterpret_cast<cplx *>(base + (slot * pb + xb)) = cplx{re[e], im[e]};
+        }
+    } else {
+        cplx *base = data + x;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int ky = t + T * e;
+            // Nyquist row (zeldovich.cpp:644-650) and pruned columns are identically zero: not read
+            const bool skip = (ky == N / 2) || ((S.prune & 4) && column_is_zero(S, kxs, ky > N / 2 ? ky - N : ky));
+            cplx v = cplx{0.0, 0.0};
+            if (!skip) v = base[row_offset(S, zl, a, ky)];
+            re[e] = v.x;
+            im[e] = v.y;
+        }
+        zdfft::fft_line<PL, LDS>(re, im, t, w, lds, tw);
+        int t2 = t;
+        asm volatile("" : "+v"(t2));  // see above: do not carry the load offsets across the FFT
+#pragma unroll
+        for (int e = 0; e < E; e++) base[row_offset(S, zl, a, t2 + T * e)] = cplx{re[e], im[e]};
     }
-    zdfft::fft_line<PL, LDS>(re, im, t, w, lds, tw);
-#pragma unroll
-    for (int e = 0; e < E; e++) base[row_offset(S, zl, a, t + T * e)] = cplx{re[e], im[e]};
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -550,12 +582,14 @@ __global__ __launch_bounds__(ROWS *NA *N / E, (ROWS * NA * N / E == 512 ? 4 : 1)
     double ssq = 0.0, mp[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
     const long long plane_rec0 = (long long) blockIdx.y * N * N;
     double *fld = lds;  // fld[(row*2*NA + 2a + {0,1})*NXH + x - h*NXH]
+    int t2 = t;
+    asm volatile("" : "+v"(t2));  // keep the staging-address arithmetic after the FFT (register pressure)
 #pragma unroll
     for (int h = 0; h < NH; h++) {
         __syncthreads();
 #pragma unroll
         for (int e2 = 0; e2 < EH; e2++) {
-            const int e = h * EH + e2, xl = t + T * e - h * NXH;
+            const int e = h * EH + e2, xl = t2 + T * e - h * NXH;
             fld[(row * 2 * NA + 2 * a) * NXH + xl]     = re[e];
             fld[(row * 2 * NA + 2 * a + 1) * NXH + xl] = im[e];
         }
@@ -835,11 +869,15 @@ static int launch_yfft_t(const StoreLayout &S, int nplanes, const void *tw, void
     const size_t shmem = sizeof(double) * zdfft::ColsInner<N, W>::SIZE;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void *) k_yfft<N, E, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+        hipFuncSetAttribute((const void *) k_yfft<N, E, W, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+        hipFuncSetAttribute((const void *) k_yfft<N, E, W, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
         attr_set = true;
     }
     dim3 grid(N / W, S.narray, nplanes), block(threads);
-    hipLaunchKernelGGL((k_yfft<N, E, W>), grid, block, shmem, st, S, (const cplx *) tw, (cplx *) data);
+    if (S.one_block)
+        hipLaunchKernelGGL((k_yfft<N, E, W, 1, true>), grid, block, shmem, st, S, (const cplx *) tw, (cplx *) data);
+    else
+        hipLaunchKernelGGL((k_yfft<N, E, W, 1, false>), grid, block, shmem, st, S, (const cplx *) tw, (cplx *) data);
     ZD_LAUNCH_CHECK();
     return 0;
 }
