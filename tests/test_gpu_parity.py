@@ -88,7 +88,7 @@ def test_mode_amplitudes(zd, oracle, ps, opk):
     assert err < 1e-13
 
 
-@pytest.mark.parametrize("n", [32, 64, 128, 256, 512, 1024, 2048, 4096])
+@pytest.mark.parametrize("n", [32, 64, 128, 256, 512, 1024, 2048, 4096, 8192])
 @pytest.mark.parametrize("kind", [0, 1])
 def test_fft_lines(zd, n, kind):
     """the register/LDS FFT engine vs numpy (unnormalised inverse DFT), both LDS layouts"""
@@ -290,3 +290,11 @@ def test_stream_factor_invariance_at_1024(zd, ps):
     rms = np.sqrt(a["density_variance"] / 1024.0 ** 3)
     pred = ps.sigmaR(720.0 / 1024 / 4.0) * 720.0 ** 1.5
     assert 0.5 < rms / pred < 1.5
+
+
+def test_parseval_oversampling_property(zd, ps):
+    """size-independent property used at full scale (PPD=8192 k_cutoff=2 vs PPD=4096):
+    the same band-limited modes sampled on a 2x finer lattice give exactly 8x the sum of dens^2"""
+    a = zd.generate(zd.make_params(128, icformat="RVZel"), ps, collect=False)
+    b = zd.generate(zd.make_params(256, k_cutoff=2.0, icformat="RVZel", stream_factor=4), ps, collect=False)
+    assert abs(b["density_variance"] / a["density_variance"] - 8.0) < 1e-12

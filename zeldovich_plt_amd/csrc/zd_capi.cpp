@@ -134,6 +134,7 @@ int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes
     const int narray = p->qdensity == 2 ? 1 : (p->qPLT ? 4 : 2);
     for (int R = 1; N / R >= 32; R *= 2) {
         if ((N / R) % nranks) break;
+        if (N / R > 4096) continue;  // z-FFT kernels exist up to length 4096
         int64_t store = N * N * (N / R) / nranks * 16 * narray;
         if (nranks > 1) store *= 2;  // separate send and receive buffers
         if (store <= budget_bytes) return R;
@@ -144,8 +145,8 @@ int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes
 int zd_plan_create(const zd_params *p, const zd_pk *pk, const double *eig, int64_t eig_ppd, int rank, int nranks,
                    zd_plan **out) {
     const int64_t N = p->ppd;
-    if (!is_pow2(N) || N < 32 || N > 4096) {
-        fprintf(stderr, "zeldovich_hip: PPD = %lld unsupported (power of two in [32, 4096] required)\n", (long long) N);
+    if (!is_pow2(N) || N < 32 || N > 8192) {
+        fprintf(stderr, "zeldovich_hip: PPD = %lld unsupported (power of two in [32, 8192] required)\n", (long long) N);
         return 1;
     }
     if (p->qPLT && (eig == NULL || eig_ppd <= 0)) {
@@ -153,7 +154,7 @@ int zd_plan_create(const zd_params *p, const zd_pk *pk, const double *eig, int64
         return 1;
     }
     int R = p->stream_factor > 0 ? p->stream_factor : 1;
-    if (!is_pow2(R) || N / R < 32) {
+    if (!is_pow2(R) || N / R < 32 || N / R > 4096) {
         fprintf(stderr, "zeldovich_hip: stream factor %d invalid for PPD %lld\n", R, (long long) N);
         return 1;
     }

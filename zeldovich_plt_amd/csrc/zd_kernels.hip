@@ -444,12 +444,14 @@ __global__ __launch_bounds__(W *L / E) void k_zfft(JobList jobs, StoreLayout S, 
     if (S.prune & 2) {  // tile of identically-zero columns: k_gen produced nothing, k_yfft will not read it
         if (__syncthreads_and(column_is_zero(S, x > S.half ? x - N : x, ky))) return;
     }
-    const cplx *src = Y + (((long long) blockIdx.z * nky + kyl) * L) * N + x;
+    // one 64-bit scalar base per workgroup + 32-bit byte offsets (a job's column tile spans L*N*16 B < 4 GB)
+    const char *src = reinterpret_cast<const char *>(Y + (((long long) blockIdx.z * nky + kyl) * L) * N);
+    const unsigned xb = (unsigned) x * 16u, rb = (unsigned) N * 16u;
     double re[E], im[E];
 #pragma unroll
     for (int e = 0; e < E; e++) {
         cplx v = cplx{1.0 + e, 2.0 * t};
-        if (!(S.prune & 8)) v = src[(long long) (t + T * e) * N];  // bit 3: tuning ablation (skip loads)
+        if (!(S.prune & 8)) v = *reinterpret_cast<const cplx *>(src + ((unsigned) (t + T * e) * rb + xb));  // bit 3: ablation
         re[e] = v.x;
         im[e] = v.y;
     }
@@ -859,6 +861,7 @@ int zfft_tile_width(int L) {
         case 256: case 512: return 16;
         case 1024: case 2048: return 8;
         case 4096: return 4;
+        case 8192: return 2;
     }
     return 0;
 }
@@ -893,9 +896,10 @@ int launch_yfft(const StoreLayout &S, int nplanes, const void *tw, void *data, h
         YCASE(1024, 16, 8)
         YCASE(2048, 16, 8)
         YCASE(4096, 16, 4)
+        YCASE(8192, 16, 2)
     }
 #undef YCASE
-    fprintf(stderr, "zeldovich_hip: unsupported PPD %d (power of two in [32,4096] required)\n", S.N);
+    fprintf(stderr, "zeldovich_hip: unsupported PPD %d (power of two in [32,8192] required)\n", S.N);
     return 2;
 }
 
@@ -905,6 +909,10 @@ static int launch_xfft_t(const StoreLayout &S, const EpiConst &ec, const void *t
     constexpr int WL = ROWS * NA, threads = WL * N / E;
     constexpr size_t fft_dbl = zdfft::LineInner<N, WL>::SIZE, fld_dbl = (size_t) ROWS * 2 * NA * N / XFFT_NH(N, NA, ROWS);
     const size_t shmem = sizeof(double) * (fft_dbl > fld_dbl ? fft_dbl : fld_dbl);
+    if (threads > 1024) {
+        fprintf(stderr, "zeldovich_hip: x pass for PPD %d with %d arrays needs %d threads per workgroup: unsupported\n", N, NA, threads);
+        return 2;
+    }
     if (shmem > 160 * 1024) {
         fprintf(stderr, "zeldovich_hip: x pass for PPD %d with %d arrays needs %zu B of LDS (> 160 KB): unsupported\n", N, NA, shmem);
         return 2;
@@ -936,6 +944,7 @@ int launch_xfft(const StoreLayout &S, const EpiConst &ec, const void *tw, const 
         XCASE(1024, 16, 4, 2, 1)
         XCASE(2048, 16, 2, 1, 1)
         XCASE(4096, 16, 1, 1, 1)
+        XCASE(8192, 16, 1, 1, 1)
     }
 #undef XCASE
     fprintf(stderr, "zeldovich_hip: unsupported PPD %d\n", S.N);
@@ -972,6 +981,7 @@ int launch_test_fft(int n, int kind, const void *tw, const void *in, void *out, 
         TCASE(1024, 16, 8)
         TCASE(2048, 16, 8)
         TCASE(4096, 16, 4)
+        TCASE(8192, 16, 2)
     }
 #undef TCASE
     return 2;
