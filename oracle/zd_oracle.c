@@ -348,6 +348,21 @@ void zdo_pk_free(zdo_pk *pk) {
     pk->x = pk->y = pk->y2 = NULL;
 }
 
+/* primordial_power / infer_Tk: src/power_spectrum.cpp:263-274 */
+static double primordial_power(const zdo_pk *pk, double k) {
+    if (k <= 0.0) return 0.0;
+    return pk->primordial_norm * exp(log(k) * pk->n_s);
+}
+double zdo_infer_Tk(const zdo_pk *pk, double k) {
+    if (k <= 0.0) return 1.0;
+    return sqrt(zdo_power(pk, k) / primordial_power(pk, k));
+}
+void zdo_pk_set_primordial(zdo_pk *pk, double n_s) { /* Normalize: src/power_spectrum.cpp:221-222 */
+    pk->n_s             = n_s;
+    pk->primordial_norm = 1.;
+    pk->primordial_norm = zdo_power(pk, pk->kmin) / primordial_power(pk, pk->kmin);
+}
+
 /* cgauss<2>: src/power_spectrum.cpp:338-359 */
 static void cgauss2(const zdo_pk *pk, double wavenumber, zdo_pcg *rng, double out[2]) {
     double Pk    = zdo_power(pk, wavenumber);
@@ -538,6 +553,11 @@ static void fft_exec(const fft_plan *p, double *data, int64_t stride, double *tm
     }
 }
 
+/* forward (sign -1) transform = conj(inverse(conj x)); ForwardFFT_Yonly / Forward2dFFT (:116-135) */
+static void conj_plane(double *p, int64_t count) {
+    for (int64_t i = 0; i < count; i++) p[2 * i + 1] = -p[2 * i + 1];
+}
+
 /* InverseFFT_Yonly: 1-D transform along the first (long-stride) index of p[n][n]   :93-114 */
 static void inverse_fft_first_index(const fft_plan *pl, double *p, int n) {
     double *tmp = (double *) malloc(sizeof(double) * 2 * (size_t) n);
@@ -550,6 +570,17 @@ static void inverse_fft_2d(const fft_plan *pl, double *p, int n) {
     for (int r = 0; r < n; r++) fft_exec(pl, p + 2 * (int64_t) r * n, 1, tmp);
     for (int c = 0; c < n; c++) fft_exec(pl, p + 2 * c, n, tmp);
     free(tmp);
+}
+
+static void forward_fft_first_index(const fft_plan *pl, double *p, int n) {
+    conj_plane(p, (int64_t) n * n);
+    inverse_fft_first_index(pl, p, n);
+    conj_plane(p, (int64_t) n * n);
+}
+static void forward_fft_2d(const fft_plan *pl, double *p, int n) {
+    conj_plane(p, (int64_t) n * n);
+    inverse_fft_2d(pl, p, n);
+    conj_plane(p, (int64_t) n * n);
 }
 
 /* ------------------------------------------------------------------------------------------- */
@@ -597,9 +628,11 @@ static inline void cset(double *d, double re, double im) {
 }
 
 /* LoadPlane without the trailing z FFTs: src/zeldovich.cpp:278-503 */
+#define AYZX_PHI(_slab, _a, _y, _z, _x) ((_slab) + 2 * ((int64_t) (_x) + g->ppd * ((_z) + g->ppd * ((_a) + (int64_t) (_y)))))
+
 static void load_plane_modes(const geom *g, const zdo_params *param, const zdo_pk *Pk, zdo_pcg *v2rng,
                              const double *eig, int64_t eig_ppd, int yblock, int yres, double *slab,
-                             double *slabHer) {
+                             double *slabHer, int gen_phi, const double *input_phi_slab) {
     int64_t ppd = g->ppd, ppdhalf = g->ppdhalf;
     double fundamental2 = param->fundamental * param->fundamental;
     double ik_cutoff    = 1.0 / param->k_cutoff;
@@ -649,6 +682,24 @@ static void load_plane_modes(const geom *g, const zdo_params *param, const zdo_p
             }
             if (k2 == 0.0) k2 = 1.0;
             double ik2 = 1. / k2;
+
+            if (gen_phi || input_phi_slab) { /* f_NL: src/zeldovich.cpp:377-400 */
+                double H0 = 100., c = 299792.458;
+                double growth = 1. / (1 + param->z_initial);
+                double M = 2. * growth * c * c * zdo_infer_Tk(Pk, kmag) * k2 / (3. * param->Omega_M * H0 * H0);
+                if (gen_phi) {
+                    cset(AYZX(slab, 0, yres, z, x), D[0] / M, D[1] / M);
+                    cset(AYZX(slabHer, 0, yresHer, zHer, xHer), D[0] / M, -D[1] / M);
+                    continue;
+                }
+                if (kx == 0 && ky == 0 && kz == 0) {
+                    D[0] = D[1] = 0.;
+                } else {
+                    const double *ph = AYZX_PHI((double *) input_phi_slab, 0, yres, z, x);
+                    D[0] = ph[0] * M;
+                    D[1] = ph[1] * M;
+                }
+            }
 
             if (D[0] != 0. || D[1] != 0.) {
                 double e[4];
@@ -843,36 +894,51 @@ static int check_geom(const zdo_params *p, geom *g) {
     return 0;
 }
 
-int zdo_run(const zdo_params *param, const zdo_pk *Pk, const double *eig, int64_t eig_ppd, void *records,
-            float *density, double *planes, zdo_stats *stats) {
-    geom gg, *g = &gg;
-    if (check_geom(param, g)) return 1;
-#ifdef _OPENMP
-    if (param->nthreads > 0) omp_set_num_threads(param->nthreads);
-#endif
-    memset(stats, 0, sizeof(*stats));
+/* StoreBlockForward / LoadBlockForward: src/block_array.cpp:416-464 (block rows ordered [a][yres][zres]) */
+static void store_block_forward(const geom *g, double *arr, int yblock, int zblock, const double *slab) {
+    double *io = blk_ptr(g, arr, yblock, zblock);
+    for (int a = 0; a < g->narray; a++)
+        for (int yres = 0; yres < g->block; yres++)
+            for (int zres = 0; zres < g->block; zres++) {
+                int y = yres + g->block * yblock;
+                memcpy(io, AZYX((double *) slab, a, zres, y, 0), sizeof(double) * 2 * (size_t) g->ppd);
+                io += 2 * g->ppd;
+            }
+}
+static void load_block_forward(const geom *g, double *arr, int yblock, int zblock, double *slab) {
+    double *io = blk_ptr(g, arr, yblock, zblock);
+    for (int a = 0; a < g->narray; a++)
+        for (int yres = 0; yres < g->block; yres++)
+            for (int zres = 0; zres < g->block; zres++) {
+                int z = zres + g->block * zblock;
+                memcpy(AYZX(slab, a, yres, z, 0), io, sizeof(double) * 2 * (size_t) g->ppd);
+                io += 2 * g->ppd;
+            }
+}
+
+/* ZeldovichZ: src/zeldovich.cpp:517-601 */
+static int zeldovich_z(const geom *g, const zdo_params *param, const zdo_pk *Pk, zdo_pcg *v2rng, const double *eig,
+                       int64_t eig_ppd, const fft_plan *pl, double *arr, int gen_phi, const geom *gphi,
+                       double *phi_arr, zdo_stats *stats) {
     int64_t ppd = g->ppd;
     int n       = (int) ppd;
-    fft_plan *pl = fft_plan_create(n);
-    zdo_pcg *v2rng = make_v2rng(param);
-
-    int64_t total = ppd * ppd * ppd * g->narray;
-    double *arr   = (double *) malloc((size_t) total * 2 * sizeof(double));
-    if (arr) { /* BlockArray constructor zeroes in parallel, outside the stage timers (block_array.cpp:63-66) */
-#pragma omp parallel for schedule(static)
-        for (int64_t i = 0; i < 2 * total; i++) arr[i] = 0.0;
-    }
-    int64_t len   = (int64_t) g->block * ppd * ppd * g->narray;
+    int64_t len = (int64_t) g->block * ppd * ppd * g->narray;
     double *slab    = (double *) calloc((size_t) len, 2 * sizeof(double));
     double *slabHer = (double *) calloc((size_t) len, 2 * sizeof(double));
-    if (!arr || !slab || !slabHer) return 2;
-
-    /* ---- ZeldovichZ: src/zeldovich.cpp:517-601 ---- */
+    double *input_phi_slab = NULL;
+    if (phi_arr) input_phi_slab = (double *) calloc((size_t) gphi->block * ppd * ppd, 2 * sizeof(double));
+    if (!slab || !slabHer || (phi_arr && !input_phi_slab)) return 2;
     for (int yblock = 0; yblock < g->numblock / 2; yblock++) {
+        if (phi_arr) {
+#pragma omp parallel for schedule(dynamic, 1)
+            for (int zblock = 0; zblock < gphi->numblock; zblock++) load_block_forward(gphi, phi_arr, yblock, zblock, input_phi_slab);
+        }
         double t0 = now_sec();
 #pragma omp parallel for schedule(dynamic, 1)
         for (int yres = 0; yres < g->block; yres++) {
-            load_plane_modes(g, param, Pk, v2rng, eig, eig_ppd, yblock, yres, slab, slabHer);
+            if (input_phi_slab) /* ForwardFFT_Yonly of the phi plane: :324-326 */
+                forward_fft_first_index(pl, input_phi_slab + 2 * (int64_t) yres * ppd * ppd, n);
+            load_plane_modes(g, param, Pk, v2rng, eig, eig_ppd, yblock, yres, slab, slabHer, gen_phi, input_phi_slab);
             int yresHer = g->block - 1 - yres;
             for (int a = 0; a < g->narray; a++) { /* :508-511 */
                 inverse_fft_first_index(pl, AYZX(slab, a, yres, 0, 0), n);
@@ -890,6 +956,88 @@ int zdo_run(const zdo_params *param, const zdo_pk *Pk, const double *eig, int64_
         stats->t_store += t2 - t1;
     }
     free(slabHer);
+    free(slab);
+    free(input_phi_slab);
+    return 0;
+}
+
+/* ZeldovichXY_Phi: src/zeldovich.cpp:699-790 */
+static int zeldovich_xy_phi(const geom *g, const zdo_params *param, const fft_plan *pl, double *arr) {
+    int64_t ppd = g->ppd;
+    int n       = (int) ppd;
+    int64_t len = (int64_t) g->block * ppd * ppd * g->narray;
+    double *slab = (double *) calloc((size_t) len, 2 * sizeof(double));
+    if (!slab) return 2;
+    double inv_ppd3 = 1. / ppd / ppd / ppd;
+    for (int zblock = 0; zblock < g->numblock; zblock++) {
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int yblock = 0; yblock < g->numblock; yblock++) load_block(g, arr, yblock, zblock, slab);
+        int ynyq = (int) (ppd / 2);
+        for (int zres = 0; zres < g->block; zres++)
+            for (int a = 0; a < g->narray; a++)
+                for (int x = 0; x < ppd; x++) cset(AZYX(slab, a, zres, ynyq, x), 0.0, 0.0);
+        for (int a = 0; a < g->narray; a++) {
+#pragma omp parallel for schedule(dynamic, 1)
+            for (int zres = 0; zres < g->block; zres++) inverse_fft_2d(pl, AZYX(slab, a, zres, 0, 0), n);
+        }
+#pragma omp parallel for schedule(static)
+        for (int zres = 0; zres < g->block; zres++)
+            for (int y = 0; y < ppd; y++)
+                for (int x = 0; x < ppd; x++) {
+                    double *p  = AZYX(slab, 0, zres, y, x);
+                    double phi = p[0];
+                    cset(p, (phi + param->f_NL * phi * phi) * inv_ppd3, 0.0);
+                }
+        for (int a = 0; a < g->narray; a++) {
+#pragma omp parallel for schedule(dynamic, 1)
+            for (int zres = 0; zres < g->block; zres++) forward_fft_2d(pl, AZYX(slab, a, zres, 0, 0), n);
+        }
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int yblock = 0; yblock < g->numblock; yblock++) store_block_forward(g, arr, yblock, zblock, slab);
+    }
+    free(slab);
+    return 0;
+}
+
+int zdo_run(const zdo_params *param, const zdo_pk *Pk, const double *eig, int64_t eig_ppd, void *records,
+            float *density, double *planes, zdo_stats *stats) {
+    geom gg, *g = &gg;
+    if (check_geom(param, g)) return 1;
+#ifdef _OPENMP
+    if (param->nthreads > 0) omp_set_num_threads(param->nthreads);
+#endif
+    memset(stats, 0, sizeof(*stats));
+    int64_t ppd = g->ppd;
+    int n       = (int) ppd;
+    fft_plan *pl = fft_plan_create(n);
+    zdo_pcg *v2rng = make_v2rng(param);
+
+    /* ---- f_NL: phi field, local non-Gaussian transform (src/zeldovich.cpp:945-960) ---- */
+    geom gphi = *g;
+    gphi.narray = 1;
+    double *phi_arr = NULL;
+    if (param->f_NL != 0.) {
+        int64_t tp = ppd * ppd * ppd;
+        phi_arr    = (double *) calloc((size_t) tp, 2 * sizeof(double));
+        if (!phi_arr) return 2;
+        zdo_stats dummy;
+        memset(&dummy, 0, sizeof(dummy));
+        if (zeldovich_z(&gphi, param, Pk, v2rng, eig, eig_ppd, pl, phi_arr, 1, NULL, NULL, &dummy)) return 2;
+        if (zeldovich_xy_phi(&gphi, param, pl, phi_arr)) return 2;
+    }
+
+    int64_t total = ppd * ppd * ppd * g->narray;
+    double *arr   = (double *) malloc((size_t) total * 2 * sizeof(double));
+    if (arr) { /* BlockArray constructor zeroes in parallel, outside the stage timers (block_array.cpp:63-66) */
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < 2 * total; i++) arr[i] = 0.0;
+    }
+    int64_t len  = (int64_t) g->block * ppd * ppd * g->narray;
+    double *slab = (double *) calloc((size_t) len, 2 * sizeof(double));
+    if (!arr || !slab) return 2;
+
+    if (zeldovich_z(g, param, Pk, v2rng, eig, eig_ppd, pl, arr, 0, &gphi, phi_arr, stats)) return 2;
+    free(phi_arr);
 
     /* ---- ZeldovichXY: src/zeldovich.cpp:611-695 ---- */
     int recsize = zdo_record_size(param->icformat);
@@ -949,7 +1097,7 @@ int zdo_mode_cube(const zdo_params *param, const zdo_pk *Pk, const double *eig, 
     memset(cube, 0, sizeof(double) * 2 * (size_t) (ppd * ppd * ppd * g->narray));
     for (int yblock = 0; yblock < g->numblock / 2; yblock++) {
         for (int yres = 0; yres < g->block; yres++)
-            load_plane_modes(g, param, Pk, v2rng, eig, eig_ppd, yblock, yres, slab, slabHer);
+            load_plane_modes(g, param, Pk, v2rng, eig, eig_ppd, yblock, yres, slab, slabHer, 0, NULL);
         for (int yres = 0; yres < g->block; yres++) {
             for (int which = 0; which < 2; which++) {
                 /* global y index as stored, then the LoadBlock shift (src/block_array.cpp:487-491) */

@@ -55,6 +55,7 @@ typedef struct {
     int CornerModes;
     int icformat; /* 0 Zeldovich, 1 RVZel, 2 RVdoubleZel, 3 ZelSimple  (include/output.h:44-49) */
     int nthreads; /* OpenMP threads for the oracle (0 = runtime default) */
+    double f_NL, n_s, Omega_M; /* local primordial non-Gaussianity (include/parameters.h:56-58) */
 } zdo_params;
 
 typedef struct {
@@ -65,6 +66,7 @@ typedef struct {
     double powerlaw_index;
     double kmin, kmax;
     double Rnorm;
+    double primordial_norm, n_s; /* src/power_spectrum.cpp:221-222 (f_NL only) */
 } zdo_pk;
 
 typedef struct {
@@ -91,6 +93,9 @@ int zdo_pk_from_file(zdo_pk *pk, const char *path, double Pk_scale, double Pk_no
 int zdo_pk_from_powerlaw(zdo_pk *pk, double index, double Pk_norm, double Pk_sigma,
                          double Pk_sigma_ratio, double Pk_smooth, int fix_to_mean, double boxsize);
 void zdo_pk_free(zdo_pk *pk);
+/* primordial_norm = power(kmin)/kmin^n_s (src/power_spectrum.cpp:221-222); call after creation when f_NL != 0 */
+void zdo_pk_set_primordial(zdo_pk *pk, double n_s);
+double zdo_infer_Tk(const zdo_pk *pk, double k); /* src/power_spectrum.cpp:268-274 */
 double zdo_power(const zdo_pk *pk, double k);
 double zdo_sigmaR(zdo_pk *pk, double R);
 

@@ -40,7 +40,7 @@ class Params(C.Structure):
         ("f_cluster", C.c_double), ("qonemode", C.c_int), ("one_mode", C.c_int * 3),
         ("qPLT", C.c_int), ("qPLTrescale", C.c_int), ("PLT_target_z", C.c_double),
         ("z_initial", C.c_double), ("CornerModes", C.c_int), ("icformat", C.c_int),
-        ("nthreads", C.c_int),
+        ("nthreads", C.c_int), ("f_NL", C.c_double), ("n_s", C.c_double), ("Omega_M", C.c_double),
     ]
 
 
@@ -50,6 +50,7 @@ class Pk(C.Structure):
         ("y2", C.POINTER(C.c_double)), ("normalization", C.c_double), ("Pk_smooth2", C.c_double),
         ("fixed_power", C.c_int), ("is_powerlaw", C.c_int), ("powerlaw_index", C.c_double),
         ("kmin", C.c_double), ("kmax", C.c_double), ("Rnorm", C.c_double),
+        ("primordial_norm", C.c_double), ("n_s", C.c_double),
     ]
 
 
@@ -89,6 +90,9 @@ def lib():
                                     C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
         L.zdo_get_eigenmode.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64,
                                         C.c_int, C.POINTER(C.c_double)]
+        L.zdo_pk_set_primordial.argtypes = [C.POINTER(Pk), C.c_double]
+        L.zdo_infer_Tk.argtypes = [C.POINTER(Pk), C.c_double]
+        L.zdo_infer_Tk.restype = C.c_double
         L.zdo_spline_build.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.zdo_spline_val.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
         _lib = L
@@ -119,7 +123,8 @@ def ref():
 
 def make_params(ppd, numblock=2, boxsize=720.0, seed=12346, k_cutoff=1.0, qPLT=0, qPLTrescale=0,
                 PLT_target_z=0.0, z_initial=49.0, f_cluster=1.0, icformat="RVdoubleZel", qdensity=0,
-                qoneslab=-1, qonemode=0, one_mode=(0, 0, 0), CornerModes=0, cpd=None, nthreads=0):
+                qoneslab=-1, qonemode=0, one_mode=(0, 0, 0), CornerModes=0, cpd=None, nthreads=0,
+                f_NL=0.0, n_s=1.0, Omega_M=1.0):
     p = Params()
     p.ppd = ppd
     p.numblock = numblock
@@ -143,6 +148,7 @@ def make_params(ppd, numblock=2, boxsize=720.0, seed=12346, k_cutoff=1.0, qPLT=0
     p.CornerModes = CornerModes
     p.icformat = ICFORMATS[icformat]
     p.nthreads = nthreads
+    p.f_NL, p.n_s, p.Omega_M = f_NL, n_s, Omega_M
     return p
 
 
