@@ -48,6 +48,8 @@ typedef struct zd_params {
     /* --- optional MI355X knobs (0 = let the library decide); not present in the reference --- */
     int32_t stream_factor; /* R: number of z-residue passes (power of two) */
     int32_t profile;       /* 1: bracket every kernel with hipEvents and report per-kernel ms */
+    /* --- local primordial non-Gaussianity (include/parameters.h:56-58); f_NL = 0 disables the path --- */
+    double f_NL, n_s, Omega_M;
 } zd_params;
 
 /* PowerSpectrum state after InitFromFile/InitFromPowerLaw + Normalize (src/power_spectrum.cpp:130-223).
@@ -61,6 +63,7 @@ typedef struct zd_pk {
     int32_t is_powerlaw;
     double powerlaw_index;
     double kmax; /* largest tabulated k (extrapolation warning only) */
+    double kmin; /* smallest positive tabulated k (1e-4 for a power law): anchors primordial_norm, f_NL only */
 } zd_pk;
 
 /* Names of the kernels in timing arrays */

@@ -70,6 +70,7 @@ def test_params_from_file(zd, tmp_path):
     (("ICFormat = \"RVZel\"", "ICFormat = \"Zeldovich\""), False),  # PLT needs an RV format
     (("ZD_k_cutoff = 1.0", "ZD_k_cutoff = 0.5"), False),
     (("ZD_Seed = 12346", "ZD_Seed = -7   # negative seeds sign-extend"), True),
+    (("ZD_f_NL = 0", "ZD_f_NL = 50\nZD_n_s = 0.965\nOmega_M = 0.3"), True),
     (("NP = 2097152", "NP = 2.097152D6"), True),        # Fortran exponent
 ])
 def test_params_validation(zd, tmp_path, mutation, ok):

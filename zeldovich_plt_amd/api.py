@@ -32,6 +32,7 @@ class ZdParams(C.Structure):
         ("qoneslab", C.c_int32), ("qonemode", C.c_int32), ("one_mode", C.c_int32 * 3),
         ("qPLT", C.c_int32), ("qPLTrescale", C.c_int32), ("icformat", C.c_int32),
         ("stream_factor", C.c_int32), ("profile", C.c_int32),
+        ("f_NL", C.c_double), ("n_s", C.c_double), ("Omega_M", C.c_double),
     ]
 
 
@@ -40,7 +41,7 @@ class ZdPk(C.Structure):
         ("n", C.c_int32), ("x", C.POINTER(C.c_double)), ("y", C.POINTER(C.c_double)),
         ("y2", C.POINTER(C.c_double)), ("normalization", C.c_double), ("Pk_smooth2", C.c_double),
         ("fixed_power", C.c_int32), ("is_powerlaw", C.c_int32), ("powerlaw_index", C.c_double),
-        ("kmax", C.c_double),
+        ("kmax", C.c_double), ("kmin", C.c_double),
     ]
 
 
@@ -137,7 +138,7 @@ def load_library():
 def make_params(ppd, numblock=2, boxsize=720.0, seed=12346, k_cutoff=1.0, qPLT=0, qPLTrescale=0,
                 PLT_target_z=0.0, z_initial=49.0, f_cluster=1.0, icformat="RVdoubleZel", qdensity=0,
                 qoneslab=-1, qonemode=0, one_mode=(0, 0, 0), corner_modes=0, cpd=None, stream_factor=0,
-                profile=0):
+                profile=0, f_NL=0.0, n_s=1.0, Omega_M=1.0):
     """Parameters with the derived quantities of Parameters::setup (src/parameters.cpp:172-174)."""
     p = ZdParams()
     p.ppd = ppd
@@ -161,6 +162,7 @@ def make_params(ppd, numblock=2, boxsize=720.0, seed=12346, k_cutoff=1.0, qPLT=0
     p.icformat = ICFORMATS[icformat]
     p.stream_factor = stream_factor
     p.profile = profile
+    p.f_NL, p.n_s, p.Omega_M = f_NL, n_s, Omega_M
     return p
 
 

@@ -70,6 +70,7 @@ struct zd_plan {
     double *d_pk = nullptr;  // x | y | y2
     int *d_lut = nullptr;
     double *d_pktab = nullptr;
+    double *d_fnlM = nullptr;  // f_NL: M(k) by integer |k|^2
     double *d_eig = nullptr;
     u128 *d_rowstate = nullptr;
     cplx *d_twN = nullptr, *d_twL = nullptr;
@@ -142,8 +143,21 @@ int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes
     return -1;
 }
 
+// phi_mode 1: first f_NL pass (one array holding phi = D/M); phik != NULL: second pass (D = phik * M)
+static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig, int64_t eig_ppd, int rank, int nranks,
+                          int phi_mode, const cplx *phik, zd_plan **out);
+
 int zd_plan_create(const zd_params *p, const zd_pk *pk, const double *eig, int64_t eig_ppd, int rank, int nranks,
                    zd_plan **out) {
+    if (p->f_NL != 0.) {
+        fprintf(stderr, "zeldovich_hip: ZD_f_NL != 0 is only available through zd_generate (single GPU)\n");
+        return 1;
+    }
+    return plan_create_ex(p, pk, eig, eig_ppd, rank, nranks, 0, nullptr, out);
+}
+
+static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig, int64_t eig_ppd, int rank, int nranks,
+                          int phi_mode, const cplx *phik, zd_plan **out) {
     const int64_t N = p->ppd;
     if (!is_pow2(N) || N < 32 || N > 8192) {
         fprintf(stderr, "zeldovich_hip: PPD = %lld unsupported (power of two in [32, 8192] required)\n", (long long) N);
@@ -168,7 +182,7 @@ int zd_plan_create(const zd_params *p, const zd_pk *pk, const double *eig, int64
     pl->nranks  = nranks;
     pl->N       = (int) N;
     pl->half    = (int) (N / 2);
-    pl->narray  = p->qdensity == 2 ? 1 : (p->qPLT ? 4 : 2);  // zeldovich.cpp:871-876
+    pl->narray  = (phi_mode == 1 || p->qdensity == 2) ? 1 : (p->qPLT ? 4 : 2);  // zeldovich.cpp:871-876
     pl->R       = R;
     pl->L       = (int) (N / R);
     pl->Hq      = pl->half / nranks;
@@ -206,6 +220,9 @@ int zd_plan_create(const zd_params *p, const zd_pk *pk, const double *eig, int64
         g.ln_growth_ratio = log(a_NL / a0);
     }
     g.eig_ppd = eig_ppd;
+    g.gen_phi = phi_mode == 1;
+    g.phik    = phik;
+    if (phi_mode == 1) g.qPLT = 0;  // the phi pass stops before the displacement algebra (zeldovich.cpp:385-391)
 
 #define PLCHECK(call)                                                                             \
     do {                                                                                          \
@@ -298,6 +315,22 @@ int zd_plan_create(const zd_params *p, const zd_pk *pk, const double *eig, int64
             g.pk_tab = (const double2 *) pl->d_pktab;
         }
     }
+    if (phi_mode == 1 || phik) {  // M(k) = 2 g c^2 T(k) k^2 / (3 Omega_M H0^2), zeldovich.cpp:377-383
+        const double H0 = 100., c = 299792.458, growth = 1. / (1 + p->z_initial);
+        g.fnl_pre = 2. * growth * c * c;
+        g.fnl_den = 3. * p->Omega_M * H0 * H0;
+        g.n_s     = p->n_s;
+        // Normalize(): primordial_norm = power(kmin) / primordial_power(kmin) with norm 1 (power_spectrum.cpp:221-222)
+        g.primordial_norm = zd_pk_power(pk, pk->kmin) / (1. * exp(log(pk->kmin) * p->n_s));
+        const long long n = 3LL * pl->half * pl->half + 2;
+        PLCHECK(hipMalloc((void **) &pl->d_fnlM, sizeof(double) * (size_t) n));
+        if (zd::launch_fnl_table(g, (int) n, pl->d_fnlM, 0)) {
+            zd_plan_destroy(pl);
+            return 1;
+        }
+        PLCHECK(hipDeviceSynchronize());
+        g.fnl_M = pl->d_fnlM;
+    }
     PLCHECK(hipMalloc((void **) &pl->d_red, sizeof(zd::Reduce)));
     PLCHECK(hipMemset(pl->d_red, 0, sizeof(zd::Reduce)));
 
@@ -325,6 +358,7 @@ int zd_plan_create(const zd_params *p, const zd_pk *pk, const double *eig, int64
     while ((1 << S.lHq) < pl->Hq) S.lHq++;
     S.narray = pl->narray;
     S.prune     = getenv("ZD_PRUNE") ? atoi(getenv("ZD_PRUNE")) : 7;  // bit 0 k_gen, 1 k_zfft, 2 k_yfft
+    if (phik) S.prune = 0;  // f_NL second pass: every mode carries power (the zero rule is bypassed)
     S.kmax      = g.kmax;
     S.fund2     = g.fundamental2;
     S.k2_cutoff = p->corner_modes ? 0.0 : g.k2_cutoff;  // CornerModes: only the |k_i| == kmax rule prunes
@@ -394,6 +428,7 @@ void zd_plan_destroy(zd_plan *pl) {
     hipFree(pl->d_pk);
     hipFree(pl->d_lut);
     hipFree(pl->d_pktab);
+    hipFree(pl->d_fnlM);
     hipFree(pl->d_eig);
     hipFree(pl->d_rowstate);
     hipFree(pl->d_twN);
@@ -540,8 +575,52 @@ int zd_generate(const zd_params *p_in, const zd_pk *pk, const double *eig, int64
         }
         p.stream_factor = R;
     }
+    // ---- f_NL: phi field -> local transform -> Fourier space again (zeldovich.cpp:945-960) ----
+    cplx *d_phik = nullptr;
+    if (p.f_NL != 0.) {
+        zd_params pp     = p;
+        pp.stream_factor = 1;  // the forward z transform needs every plane resident
+        pp.qPLT          = 0;  // the phi pass never reaches the displacement algebra
+        zd_plan *ph      = nullptr;
+        if (plan_create_ex(&pp, pk, nullptr, 0, 0, 1, 1, nullptr, &ph)) return 1;
+        void *d_phi = nullptr;
+        int frc     = 1;
+        do {
+            if (hipMalloc(&d_phi, (size_t) zd_plan_exchange_bytes(ph)) != hipSuccess
+                || hipMalloc((void **) &d_phik, (size_t) (N / 2) * N * N * 16) != hipSuccess) {
+                fprintf(stderr, "zeldovich_hip: f_NL needs %.1f GB of HBM for the phi field at PPD %lld\n",
+                        (zd_plan_exchange_bytes(ph) + (N / 2) * N * N * 16) / 1e9, (long long) N);
+                break;
+            }
+            fprintf(stderr, "Generating phi field\n");
+            if (zd_plan_stage_z(ph, 0, d_phi, 0) || zd_plan_stage_y(ph, d_phi, 0)) break;
+            if (zd::launch_fnl_stage(0, ph->S, p.f_NL, ph->d_twN, d_phi, nullptr, 0)) break;
+            if (zd::launch_fnl_stage(1, ph->S, p.f_NL, ph->d_twN, d_phi, nullptr, 0)) break;
+            if (zd::launch_fnl_stage(2, ph->S, p.f_NL, ph->d_twN, d_phi, d_phik, 0)) break;
+            if (hipDeviceSynchronize() != hipSuccess) break;
+            frc = 0;
+        } while (0);
+        hipFree(d_phi);
+        zd_plan_destroy(ph);
+        if (frc) {
+            hipFree(d_phik);
+            return 1;
+        }
+        HIPCHECK(hipMemGetInfo(&free_b, &total_b));
+        if (p_in->stream_factor <= 0) {
+            const int R2 = zd_choose_stream_factor(&p, 1, (int64_t) free_b - ((int64_t) 12 << 30));
+            if (R2 < 0) {
+                hipFree(d_phik);
+                return 1;
+            }
+            p.stream_factor = R2;
+        }
+    }
     zd_plan *pl = nullptr;
-    if (zd_plan_create(&p, pk, eig, eig_ppd, 0, 1, &pl)) return 1;
+    if (plan_create_ex(&p, pk, eig, eig_ppd, 0, 1, 0, d_phik, &pl)) {
+        hipFree(d_phik);
+        return 1;
+    }
     const int R = pl->R, Zq = pl->Zq, recsize = pl->ec.recsize;
     const bool want_rec = pl->narray >= 2, want_dens = p.qdensity != 0;
 
@@ -605,6 +684,7 @@ int zd_generate(const zd_params *p_in, const zd_pk *pk, const double *eig, int64
         out->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         rc = 0;
     } while (0);
+    hipFree(d_phik);
     hipFree(d_store);
     hipFree(d_rec);
     hipFree(d_dens);

@@ -32,6 +32,11 @@ struct GenConst {
     double f_cluster, target_f, ln_growth_ratio;  // log(a_NL/a0)
     const double *eig;
     long long eig_ppd;
+    // local primordial non-Gaussianity (zeldovich.cpp:377-400): M(k) = 2 g c^2 T(k) k^2 / (3 Omega_M H0^2)
+    int gen_phi;              // 1: emit phi = D / M (first f_NL pass)
+    const zdfft::cplx *phik;  // non-NULL: D = phik[ky][z][x] * M (second pass; the zero rule is bypassed)
+    const double *fnl_M;      // M by integer kx^2+ky^2+kz^2
+    double fnl_pre, fnl_den, primordial_norm, n_s;
     // RNG: state at the start of each ky plane (== reference v2rng[ky], power_spectrum.cpp:30-36)
     const zdpcg::u128 *row_state;
 };

@@ -231,6 +231,7 @@ int zd_pk_create_from_file(const char *path, double Pk_scale, double Pk_norm, do
     pk->y  = h->sp.y.data();
     pk->y2 = h->sp.y2.data();
     pk->kmax           = kmax;
+    pk->kmin           = kmin;
     pk->powerlaw_index = 1000;
     normalize(pk, Pk_norm, Pk_sigma, Pk_sigma_ratio, Pk_smooth, fix_to_mean, boxsize);
     *hout = h;
@@ -246,6 +247,7 @@ int zd_pk_create_powerlaw(double index, double Pk_norm, double Pk_sigma, double 
     pk->powerlaw_index = index;
     pk->is_powerlaw    = 1;
     pk->kmax           = std::numeric_limits<double>::min();
+    pk->kmin           = 1e-4;  // Arbitrary; used by f_NL (power_spectrum.cpp:180)
     normalize(pk, Pk_norm, Pk_sigma, Pk_sigma_ratio, Pk_smooth, fix_to_mean, boxsize);
     *hout = h;
     return 0;
@@ -464,9 +466,14 @@ int zd_params_from_file(const char *path, zd_params *p, zd_param_strings *s) {
     if (p->qPLT) ZD_REQUIRE(s->PLT_filename[0] != 0);
     ZD_REQUIRE(p->k_cutoff >= 1);
     if (p->qPLT) ZD_REQUIRE(strncmp(s->ICFormat, "RV", 2) == 0);
-    if (s->f_NL != 0.) {
-        fprintf(stderr, "zeldovich (MI355X): ZD_f_NL != 0 (local primordial non-Gaussianity) is not supported yet.\n");
-        return 1;
+    p->f_NL    = s->f_NL;
+    p->n_s     = s->n_s;
+    p->Omega_M = s->Omega_M;
+    if (s->f_NL != 0.) {  // parameters.cpp:181-194
+        fprintf(stderr,
+                "Generating local primordial non-Gaussianity, with parameters:\n - ZD_f_NL = %g\n - ZD_n_s = %g\n"
+                " - Omega_M = %g\n - InitialRedshift = %g\n",
+                s->f_NL, s->n_s, s->Omega_M, p->z_initial);
     }
     // block geometry asserts of BlockArray (src/block_array.cpp:38-40) — kept so that reference
     // parameter files are rejected in the same situations

@@ -307,7 +307,15 @@ __global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, JobList 
             const int k2i = kxm * kxm + ky * ky + kzm * kzm;
             double k2v    = (double) k2i * g.fundamental2;
             double dr = 0.0, di = 0.0, ik2 = 1.0;
-            if (!zero && !mode_is_zero(g, kxm, ky, kzm, k2v)) {
+            if (g.phik) {  // f_NL, second pass: D = phi_NG(k) * M(k) for every mode but k = 0 (zeldovich.cpp:393-400)
+                if (k2i != 0) {
+                    const cplx ph  = g.phik[((long long) ky * N + zs) * N + xs];
+                    const double M = g.fnl_M[k2i];
+                    dr  = ph.x * M;
+                    di  = ph.y * M;
+                    ik2 = 1.0 / k2v;
+                }
+            } else if (!zero && !mode_is_zero(g, kxm, ky, kzm, k2v)) {
                 if (g.pk_tab) {  // {P(k), 1/k^2} by integer k^2
                     const double2 pv = g.pk_tab[k2i];
                     ik2 = pv.y;
@@ -318,6 +326,11 @@ __global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, JobList 
                 }
             }
             if (dr == 0.0 && di == 0.0) continue;  // zero modes add nothing (zeldovich.cpp:403,435-438)
+            if (g.gen_phi) {  // f_NL, first pass: phi = D / M (zeldovich.cpp:385-391)
+                const double M = g.fnl_M[k2i];
+                dr /= M;
+                di /= M;
+            }
             double sx, sy, sz, f = 1.0;
             if constexpr (PLT) {
                 double e[4];
@@ -710,6 +723,105 @@ __global__ __launch_bounds__(ROWS *NA *N / E, (ROWS * NA * N / E == 512 ? 4 : 1)
 }
 
 // ------------------------------------------------------------------------------------------------
+// f_NL kernels (ZeldovichXY_Phi + the forward transforms, src/zeldovich.cpp:699-790, 116-135, 324-326).
+// A forward (sign -1) transform is conj o inverse o conj, so the same register-resident engine serves.
+
+// M(k) table by integer |k|^2: infer_Tk / primordial_power (src/power_spectrum.cpp:263-274)
+template <bool PLAW>
+__global__ void k_fnl_table(GenConst g, int n, double *__restrict__ tab) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double k2 = (double) i * g.fundamental2;
+    const double kmag = sqrt(k2);
+    double Tk = 1.0;
+    if (kmag > 0.0) Tk = sqrt(pk_power<PLAW>(g, k2) / (g.primordial_norm * exp(log(kmag) * g.n_s)));
+    if (k2 == 0.0) k2 = 1.0;
+    tab[i] = g.fnl_pre * Tk * k2 / g.fnl_den;
+}
+
+// rows of the (narray = 1) store: inverse x FFT -> phi(x) -> (phi + f_NL phi^2)/N^3 -> forward x FFT, in place
+template <int N, int E, int ROWS>
+__global__ __launch_bounds__(ROWS *N / E) void k_xphi(StoreLayout S, double f_NL, double inv_ppd3, const cplx *__restrict__ tw,
+                                                     cplx *__restrict__ data) {
+    using PL  = zdfft::Plan<N, E>;
+    using LDS = zdfft::LineInner<N, ROWS>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int T = PL::T;
+    const int t = threadIdx.x % T, row = threadIdx.x / T;
+    const int y = blockIdx.x * ROWS + row, pl = blockIdx.y;
+    cplx *p = data + row_offset(S, pl, 0, y);
+    double re[E], im[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const cplx v = p[t + T * e];
+        re[e] = v.x;
+        im[e] = v.y;
+    }
+    zdfft::fft_line<PL, LDS>(re, im, t, row, lds, tw);
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const double phi = re[e];  // real(AZYX(slab,0,...)), zeldovich.cpp:753
+        re[e] = (phi + f_NL * phi * phi) * inv_ppd3;
+        im[e] = 0.0;
+    }
+    __syncthreads();
+    zdfft::fft_line<PL, LDS>(re, im, t, row, lds, tw);  // input is real: conj is the identity
+    int t2 = t;
+    asm volatile("" : "+v"(t2));
+#pragma unroll
+    for (int e = 0; e < E; e++) p[t2 + T * e] = cplx{re[e], -im[e]};
+}
+
+// forward y FFT in place on the store (all rows are data: no Nyquist zeroing, no pruning)
+template <int N, int E, int W>
+__global__ __launch_bounds__(W *N / E) void k_yfwd(StoreLayout S, const cplx *__restrict__ tw, cplx *__restrict__ data) {
+    using PL  = zdfft::Plan<N, E>;
+    using LDS = zdfft::ColsInner<N, W>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int T = PL::T;
+    const int w = threadIdx.x % W, t = threadIdx.x / W;
+    cplx *base = data + blockIdx.x * W + w;
+    const int zl = blockIdx.z;
+    double re[E], im[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const cplx v = base[row_offset(S, zl, 0, t + T * e)];
+        re[e] = v.x;
+        im[e] = -v.y;
+    }
+    zdfft::fft_line<PL, LDS>(re, im, t, w, lds, tw);
+    int t2 = t;
+    asm volatile("" : "+v"(t2));
+#pragma unroll
+    for (int e = 0; e < E; e++) base[row_offset(S, zl, 0, t2 + T * e)] = cplx{re[e], -im[e]};
+}
+
+// forward z FFT of the half-space rows: gathers a column tile across all N planes of the store and
+// writes PhiK[ky][kz][x] (what LoadBlockForward + ForwardFFT_Yonly hand to LoadPlane)
+template <int N, int E, int W>
+__global__ __launch_bounds__(W *N / E) void k_zfwd(StoreLayout S, const cplx *__restrict__ tw, const cplx *__restrict__ data,
+                                                  cplx *__restrict__ phik) {
+    using PL  = zdfft::Plan<N, E>;
+    using LDS = zdfft::ColsInner<N, W>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int T = PL::T;
+    const int w = threadIdx.x % W, t = threadIdx.x / W;
+    const int x = blockIdx.x * W + w, ky = blockIdx.y;
+    double re[E], im[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const cplx v = data[row_offset(S, t + T * e, 0, ky) + x];
+        re[e] = v.x;
+        im[e] = -v.y;
+    }
+    zdfft::fft_line<PL, LDS>(re, im, t, w, lds, tw);
+    int t2 = t;
+    asm volatile("" : "+v"(t2));
+#pragma unroll
+    for (int e = 0; e < E; e++) phik[((long long) ky * N + (t2 + T * e)) * N + x] = cplx{re[e], -im[e]};
+}
+
+// ------------------------------------------------------------------------------------------------
 // test kernels: batches of independent lines through the two LDS layouts
 template <int N, int E, int W>
 __global__ __launch_bounds__(W *N / E) void k_test_fft_cols(const cplx *__restrict__ tw, const cplx *__restrict__ in,
@@ -1007,6 +1119,59 @@ int launch_yfft_variant(int variant, const StoreLayout &S, int nplanes, const vo
     VC(0, 1024, 16, 8, 1) VC(1, 1024, 16, 8, 4) VC(2, 1024, 16, 16, 4) VC(3, 1024, 8, 8, 4) VC(4, 1024, 8, 4, 4)
     VC(5, 1024, 16, 4, 4) VC(6, 1024, 8, 8, 8) VC(7, 1024, 16, 4, 2) VC(8, 1024, 4, 4, 8) VC(9, 1024, 8, 4, 8)
 #undef VC
+    return 2;
+}
+
+int launch_fnl_table(const GenConst &g, int n, void *tab, hipStream_t st) {
+    dim3 grid((n + 255) / 256), block(256);
+    if (g.is_powerlaw)
+        hipLaunchKernelGGL(k_fnl_table<true>, grid, block, 0, st, g, n, (double *) tab);
+    else
+        hipLaunchKernelGGL(k_fnl_table<false>, grid, block, 0, st, g, n, (double *) tab);
+    ZD_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int N, int E, int W, int ROWS>
+static int launch_fnl_t(int which, const StoreLayout &S, double f_NL, const void *tw, void *data, void *phik, hipStream_t st) {
+    if (which == 0) {  // x: inverse + nonlinearity + forward
+        constexpr int threads = ROWS * N / E;
+        const size_t shmem = sizeof(double) * zdfft::LineInner<N, ROWS>::SIZE;
+        hipFuncSetAttribute((const void *) k_xphi<N, E, ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+        const double inv = 1. / N / N / N;
+        hipLaunchKernelGGL((k_xphi<N, E, ROWS>), dim3(N / ROWS, N), dim3(threads), shmem, st, S, f_NL, inv, (const cplx *) tw,
+                           (cplx *) data);
+    } else {
+        constexpr int threads = W * N / E;
+        const size_t shmem = sizeof(double) * zdfft::ColsInner<N, W>::SIZE;
+        if (which == 1) {
+            hipFuncSetAttribute((const void *) k_yfwd<N, E, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+            hipLaunchKernelGGL((k_yfwd<N, E, W>), dim3(N / W, 1, N), dim3(threads), shmem, st, S, (const cplx *) tw, (cplx *) data);
+        } else {
+            hipFuncSetAttribute((const void *) k_zfwd<N, E, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+            hipLaunchKernelGGL((k_zfwd<N, E, W>), dim3(N / W, N / 2), dim3(threads), shmem, st, S, (const cplx *) tw,
+                               (const cplx *) data, (cplx *) phik);
+        }
+    }
+    ZD_LAUNCH_CHECK();
+    return 0;
+}
+// which: 0 = x pass (inverse, phi + f_NL phi^2, forward), 1 = forward y, 2 = forward z -> phik
+int launch_fnl_stage(int which, const StoreLayout &S, double f_NL, const void *tw, void *data, void *phik, hipStream_t st) {
+#define FCASE(n, e, w, rows) \
+    case n: return launch_fnl_t<n, e, w, rows>(which, S, f_NL, tw, data, phik, st);
+    switch (S.N) {
+        FCASE(32, 16, 32, 32)
+        FCASE(64, 16, 32, 32)
+        FCASE(128, 16, 32, 32)
+        FCASE(256, 16, 16, 16)
+        FCASE(512, 16, 16, 8)
+        FCASE(1024, 16, 8, 4)
+        FCASE(2048, 16, 8, 2)
+        FCASE(4096, 16, 4, 1)
+    }
+#undef FCASE
+    fprintf(stderr, "zeldovich_hip: f_NL path supports PPD = 32..4096 (power of two), got %d\n", S.N);
     return 2;
 }
 
