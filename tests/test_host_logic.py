@@ -162,3 +162,25 @@ def test_fft_engine_host_emulation(emul, n, e, w, line):
     assert emul.emul_fft(n, e, w, line, x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)) == 0
     ref = np.fft.ifft(x, axis=1) * n
     assert np.abs(out - ref).max() / np.abs(ref).max() < 5e-15
+
+
+def test_parseheader_grammar_features(zd, tmp_path):
+    """include files, `##` block comments, backslash continuation, logical keywords, declarations without `=`
+    (subprojects/ParseHeader/src/phScanner.ll) — what Abacus-style parameter files actually use"""
+    inc = tmp_path / "common.par"
+    inc.write_text("BoxSize = 720   # from the include file\nCPD = 375\nZD_Pk_scale = 1.0\n")
+    text = (EXAMPLE % dict(out=tmp_path / "ic", eig="./eigmodes128", pk=WMAP, plt=0))
+    text = text.replace("BoxSize = 720\n", "").replace("CPD = 375\n", "").replace("ZD_Pk_scale = 1.0\n", "")
+    text = ('include "%s"\n' % inc) + text
+    text += "##\nNP = 5   this whole block is a comment\n##\n"
+    text += "ZD_qonemode = true\nZD_one_mode = 1 \\\n   2 \\\n  -3\n"
+    text += "vector a b\n1 2\n3 4\nmapvar m a\n"
+    par = tmp_path / "g.par"
+    par.write_text(text)
+    p, s = zd.params_from_file(str(par))
+    assert p.boxsize == 720 and p.cpd == 375 and p.ppd == 128
+    assert p.qonemode == 1 and list(p.one_mode) == [1, 2, -3]
+    with pytest.raises(ValueError):
+        bad = tmp_path / "bad.par"
+        bad.write_text('include "/nonexistent/file.par"\n' + text)
+        zd.params_from_file(str(bad))

@@ -307,19 +307,26 @@ static double to_double(std::string s) {
     return strtod(s.c_str(), NULL);
 }
 
-int zd_params_from_file(const char *path, zd_params *p, zd_param_strings *s) {
-    std::ifstream in(path);
-    if (!in) {
-        fprintf(stderr, "Could not open parameter file \"%s\"\n", path);
+// Reads `key = value ...` statements the way the reference's ParseHeader scanner does
+// (subprojects/ParseHeader/src/phScanner.ll:95-240): `#` comments, `##` block comments, quoted strings,
+// a trailing backslash continues the statement on the next line, `include "file"` splices another file
+// (depth <= 10, phScanner.ll:176-203), a ^B character ends the header.  Statements without `=`
+// (vector / mapvar / vcounter declarations and vector data rows) do not concern this program and are skipped.
+static int read_statements(const char *path, std::map<std::string, std::string> &kv, int depth) {
+    if (depth > 10) {
+        fprintf(stderr, "ERROR: exceeded maximum include stack depth: 10.\n");
         return 1;
     }
-    std::map<std::string, std::string> kv;
-    std::string line;
+    std::ifstream in(path);
+    if (!in) {
+        fprintf(stderr, depth ? "failed to open include file \"%s\". exiting...\n" : "Could not open parameter file \"%s\"\n", path);
+        return 1;
+    }
+    std::string line, pending;
     bool in_block_comment = false;
     while (std::getline(in, line)) {
         if (!line.empty() && line[0] == '\x02') break;  // ^B ends the header (ParseHeader convention)
-        std::string t = trim(line);
-        if (t.rfind("##", 0) == 0) {  // `##` toggles a block comment
+        if (trim(line).rfind("##", 0) == 0 && line.rfind("##", 0) == 0) {  // `##` at line start toggles a block comment
             in_block_comment = !in_block_comment;
             continue;
         }
@@ -335,12 +342,34 @@ int zd_params_from_file(const char *path, zd_params *p, zd_param_strings *s) {
             }
         }
         if (cut != std::string::npos) line = line.substr(0, cut);
+        // continuation: backslash + optional blanks at end of line
+        std::string t = line;
+        while (!t.empty() && (t.back() == ' ' || t.back() == '\t' || t.back() == '\r')) t.pop_back();
+        if (!t.empty() && t.back() == '\\') {
+            t.pop_back();
+            pending += t + " ";
+            continue;
+        }
+        line = pending + line;
+        pending.clear();
+        const std::string st = trim(line);
+        if (st.compare(0, 7, "include") == 0 && st.size() > 7 && (isspace((unsigned char) st[7]) || st[7] == '"' || st[7] == '\'')) {
+            const std::string inc = unquote(st.substr(7));
+            if (read_statements(inc.c_str(), kv, depth + 1)) return 1;
+            continue;
+        }
         const size_t eq = line.find('=');
         if (eq == std::string::npos) continue;
         const std::string key = trim(line.substr(0, eq));
         if (key.empty()) continue;
         kv[key] = trim(line.substr(eq + 1));
     }
+    return 0;
+}
+
+int zd_params_from_file(const char *path, zd_params *p, zd_param_strings *s) {
+    std::map<std::string, std::string> kv;
+    if (read_statements(path, kv, 0)) return 1;
 
     // defaults: src/parameters.cpp:13-44
     memset(p, 0, sizeof(*p));
@@ -373,7 +402,17 @@ int zd_params_from_file(const char *path, zd_params *p, zd_param_strings *s) {
         if (!must(k)) return 1;
 
     auto D = [&](const char *k, double &v) { if (has(k)) v = to_double(kv[k]); };
-    auto I = [&](const char *k, int32_t &v) { if (has(k)) v = (int32_t) strtol(kv[k].c_str(), NULL, 0); };
+    auto I = [&](const char *k, int32_t &v) {
+        if (!has(k)) return;
+        std::string t = kv[k];
+        for (auto &c : t) c = (char) tolower((unsigned char) c);
+        if (t == "true" || t == ".true.")  // logical keywords of the ParseHeader grammar
+            v = 1;
+        else if (t == "false" || t == ".false.")
+            v = 0;
+        else
+            v = (int32_t) strtol(kv[k].c_str(), NULL, 0);
+    };
     auto S = [&](const char *k, char *dst, size_t cap) {
         if (has(k)) {
             std::string v = unquote(kv[k]);
