@@ -45,6 +45,55 @@ std::vector<cplx> make_twiddles(int n) {
     return tw;
 }
 
+// LDS image of k_genf; offsets must match GenfTab (zd_kernels.hip): directions {cos, sin}(2 pi j/512) at 0,
+// ln bins {c_j, -ln c_j} at 1024, 2^(j/64) at 1392, spline segment records at 1456, uint16 segment LUT after them
+std::vector<double> build_genf_table(const zd_pk *pk, int nseg, double *lut_x0, double *lut_inv_dx) {
+    constexpr int SC = 0, LG = 1024, EX = 1392, SEG = 1456, GLUT = 1024;
+    std::vector<double> T(SEG + 6 * (size_t) nseg + GLUT / 4, 0.0);
+    const long double pi = 3.14159265358979323846264338327950288L;
+    for (int j = 0; j < 512; j++) {
+        T[SC + 2 * j]     = (double) cosl(2.0L * pi * j / 512.0L);
+        T[SC + 2 * j + 1] = (double) sinl(2.0L * pi * j / 512.0L);
+    }
+    for (int j = 0; j < 182; j++) {  // f in [(j+181)/256, (j+182)/256); bins 74, 75 surround f = 1
+        double c = 1.0, l = 0.0;
+        if (j != 74 && j != 75) {
+            c = (double) (1.0L / (((long double) (j + 181) + 0.5L) / 256.0L));
+            l = (double) (-logl((long double) c));
+        }
+        T[LG + 2 * j]     = c;
+        T[LG + 2 * j + 1] = l;
+    }
+    for (int j = 0; j < 64; j++) T[EX + j] = (double) powl(2.0L, (long double) j / 64.0L);
+    *lut_x0 = 0.0;
+    *lut_inv_dx = 0.0;
+    if (nseg > 0) {
+        for (int i = 0; i < nseg; i++) {  // SplineFunction::val, include/spline_function.h:153-162
+            const double h = pk->x[i + 1] - pk->x[i];
+            double *r = &T[SEG + 6 * (size_t) i];
+            r[0] = pk->x[i];
+            r[1] = 1.0 / h;
+            r[2] = pk->y[i];
+            r[3] = pk->y[i + 1];
+            r[4] = pk->y2[i] * (h * h) / 6.0;
+            r[5] = pk->y2[i + 1] * (h * h) / 6.0;
+        }
+        // segment start table: cell c covers ln k in [x0 + c*dx, x0 + (c+1)*dx); never past the true start
+        unsigned short *lut = reinterpret_cast<unsigned short *>(&T[SEG + 6 * (size_t) nseg]);
+        const double x0 = pk->x[0], x1 = pk->x[nseg];
+        const double dx = (x1 - x0) / GLUT;
+        int klo = 0;
+        for (int c = 0; c < GLUT; c++) {
+            const double cell_start = x0 + c * dx * (1.0 - 1e-12) - 1e-9;
+            while (klo < nseg - 1 && pk->x[klo + 1] <= cell_start) klo++;
+            lut[c] = (unsigned short) klo;
+        }
+        *lut_x0     = x0;
+        *lut_inv_dx = 1.0 / dx;
+    }
+    return T;
+}
+
 int record_size(int icformat) {  // include/output.h:19-42
     switch (icformat) {
         case ZD_FMT_ZEL: return 32;
@@ -74,6 +123,7 @@ struct zd_plan {
     double *d_eig = nullptr;
     u128 *d_rowstate = nullptr;
     cplx *d_twN = nullptr, *d_twL = nullptr;
+    double *d_genf = nullptr;  // LDS image of k_genf
     zd::Reduce *d_red = nullptr;
     // folded FFT inputs of one slab of half-space rows: Y[job][row][k2][x]; double-buffered so that
     // k_gen (VALU-bound) of slab s+1 runs beside k_zfft (HBM-bound) of slab s on a second stream
@@ -123,6 +173,10 @@ int64_t y_bytes_per_row(const zd_plan *pl) { return (int64_t) pl->jobs.n * pl->L
 // advance by (2*65536*drows - 1) draws, drows may be negative (period 2^128)
 zdpcg::Affine row_jump(long long drows) {
     const __int128 d = (__int128) 2 * 65536 * (__int128) drows - 1;
+    return zdpcg::jump_map((u128) d);
+}
+zdpcg::Affine row_jump_full(long long drows) {  // 2*65536*drows draws
+    const __int128 d = (__int128) 2 * 65536 * (__int128) drows;
     return zdpcg::jump_map((u128) d);
 }
 
@@ -201,6 +255,12 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
     g.fundamental  = p->fundamental;
     g.fundamental2 = p->fundamental * p->fundamental;
     g.k2_cutoff    = p->nyquist * p->nyquist / (p->k_cutoff * p->k_cutoff);
+    {  // the comparison `k2 >= k2_cutoff` of zeldovich.cpp:353 is monotonic in the integer |k|^2
+        long long c = (long long) floor(g.k2_cutoff / g.fundamental2);
+        while (c > 0 && (double) c * g.fundamental2 >= g.k2_cutoff) c--;
+        while ((double) c * g.fundamental2 < g.k2_cutoff) c++;
+        g.k2i_cut = (int) std::min<long long>(c, 0x7fffffffLL);
+    }
     g.pk_n         = pk->n;
     g.fixed_power  = pk->fixed_power;
     g.is_powerlaw  = pk->is_powerlaw;
@@ -292,6 +352,10 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         pl->J.fwd[1]  = row_jump(Lr + wrap);
         pl->J.back[0] = row_jump(back);
         pl->J.back[1] = row_jump(back > 0 ? back + wrap : back - wrap);
+        pl->J.fwd_full[0]  = row_jump_full(Lr);
+        pl->J.fwd_full[1]  = row_jump_full(Lr + wrap);
+        pl->J.back_full[0] = row_jump_full(back);
+        pl->J.back_full[1] = row_jump_full(back > 0 ? back + wrap : back - wrap);
     }
     {
         std::vector<cplx> twN = make_twiddles(pl->N), twL = make_twiddles(pl->L);
@@ -299,6 +363,17 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         PLCHECK(hipMemcpy(pl->d_twN, twN.data(), sizeof(cplx) * twN.size(), hipMemcpyHostToDevice));
         PLCHECK(hipMalloc((void **) &pl->d_twL, sizeof(cplx) * twL.size()));
         PLCHECK(hipMemcpy(pl->d_twL, twL.data(), sizeof(cplx) * twL.size(), hipMemcpyHostToDevice));
+        // LDS image of k_genf (layout: GenfTab in zd_kernels.hip).  Spline tables beyond 512 segments do not
+        // fit: such runs use the general generator.
+        const int nseg = pk->is_powerlaw ? 0 : pk->n - 1;
+        if (nseg <= 512 && !getenv("ZD_GEN_GENERAL")) {
+            std::vector<double> T = build_genf_table(pk, nseg, &g.glut_x0, &g.glut_inv_dx);
+            PLCHECK(hipMalloc((void **) &pl->d_genf, sizeof(double) * T.size()));
+            PLCHECK(hipMemcpy(pl->d_genf, T.data(), sizeof(double) * T.size(), hipMemcpyHostToDevice));
+            g.genf_tab  = pl->d_genf;
+            g.genf_n    = (int) T.size();
+            g.genf_nseg = nseg;
+        }
     }
     // {P, 1/k^2} table over the integer |k|^2 that can carry power (zero rule of zeldovich.cpp:350-353)
     if (!getenv("ZD_NO_PKTAB")) {
@@ -433,6 +508,7 @@ void zd_plan_destroy(zd_plan *pl) {
     hipFree(pl->d_rowstate);
     hipFree(pl->d_twN);
     hipFree(pl->d_twL);
+    hipFree(pl->d_genf);
     hipFree(pl->d_red);
     hipFree(pl->d_Y[0]);
     hipFree(pl->d_Y[1]);

@@ -20,10 +20,15 @@ struct GenConst {
     int qonemode, one_mode[3];
     int ablate;        // debug/tuning only (ZD_ABLATE env): skip parts of the generator; 0 in production
     double fundamental, fundamental2, k2_cutoff;
+    int k2i_cut;       // smallest integer |k|^2 with double(|k|^2)*fundamental2 >= k2_cutoff (the rule of :353 on integers)
     // PowerSpectrum
     int pk_n, fixed_power, is_powerlaw;
     const double *pk_x, *pk_y, *pk_y2;
     const double2 *pk_tab;    // {P(k), 1/k^2} indexed by integer kx^2+ky^2+kz^2 (NULL: evaluate per mode)
+    // k_genf: LDS image {directions, ln bins, 2^(j/64), spline segment records, segment LUT} (GenfTab, zd_kernels.hip)
+    const double *genf_tab;
+    int genf_n, genf_nseg;    // doubles in the image; spline segments (0 for a power law)
+    double glut_x0, glut_inv_dx;
     const int *pk_lut;        // PK_LUT uniform cells over [x0, x_last] -> start segment
     double lut_x0, lut_inv_dx;
     double pk_norm, pk_smooth2, powerlaw_index;
@@ -48,6 +53,9 @@ struct GenJumps {
     // wrap of the counter (rows N/2+1.. live at 65536-N+z, zeldovich.cpp:335).
     zdpcg::Affine fwd[2];   // z -> z + L         (next residue-fold term)
     zdpcg::Affine back[2];  // z -> z - (R-1)L + 1 (first term of the next k2; for R = 1: the next row)
+    // the same moves for a mode whose draws are not needed (k_genf, all 64 modes of a wave zeroed):
+    // 2*65536*drows draws in one map
+    zdpcg::Affine fwd_full[2], back_full[2];
 };
 
 // Addressing of the z-transformed block store ("BlockArray", include/block_array.h:26-35, re-laid

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "zd_device.h"
 #include "zd_launch.h"
@@ -395,6 +396,292 @@ __global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, JobList 
             // a slab holds < 2^31 elements (1.5 GB / 16 B): 32-bit index arithmetic
             const unsigned idx = (unsigned) (((j * nky + kyl) * L + k2) * N + x);
             Y[idx] = cplx{accr[j] * pr - acci[j] * pi, accr[j] * pi + acci[j] * pr};
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_genf arithmetic.  The generator is VALU-bound (2 x 128-bit LCG steps + Box-Muller + P(k) per mode,
+// redone for every z-residue pass), and a wave's 64 modes have 64 unrelated |k|^2: gathering {P, 1/k^2}
+// from the by-|k|^2 table costs 64 cache-line fills per wave-instruction and was measured to take as
+// long as all the arithmetic together.  So k_genf evaluates everything from small LDS tables
+// (GenfTab, ~22 KB, built on the host in long double):
+//   * one_rand<2> (power_spectrum.cpp:284-308) is kept as the exact integer m = r + 1 (m = 0 <=> r = 2^64-1,
+//     i.e. the value 1.0) and its correctly rounded double; the 2^-64 scale is folded into the callers;
+//   * ln x: x = 2^e f, f in [sqrt(1/2), sqrt(2)), bin j of width 1/256 with c_j ~ 1/centre, ln f = -ln c_j +
+//     log1p(f c_j - 1) (7 terms; the two bins around f = 1 have c = 1 so that ln stays relatively exact near 1);
+//   * e^x = 2^k 2^(j/64) e^r, |r| <= ln2/128 (6 terms);
+//   * cos/sin(2 pi theta): nearest of 512 tabulated directions + a 3-term rotation;
+//   * P(k): SplineFunction::val with per-segment records {x_lo, 1/h, y_lo, y_hi, y2_lo h^2/6, y2_hi h^2/6}.
+// Each is within 4e-16 (relative) of the correctly rounded result; cgauss<2> itself evaluates
+// cos/sin(fl(2*M_PI*theta)), 4e-16 away from the exact angle.
+struct GenfTab {  // offsets in doubles inside the LDS image (zd_capi.cpp: build_genf_table)
+    static constexpr int SC = 0, LG = 1024, EX = 1392, SEG = 1456, GLUT = 1024;
+    static constexpr int lut(int nseg) { return SEG + 6 * nseg; }
+    static constexpr int size(int nseg) { return SEG + 6 * nseg + GLUT / 4; }
+};
+
+__device__ __forceinline__ double u64_to_double(uint64_t m) {  // round-to-nearest: both halves are exact, one rounding in the fma
+    return fma((double) (uint32_t) (m >> 32), 4294967296.0, (double) (uint32_t) m);
+}
+
+// ln(x * 2^-ebias) for a normal x > 0
+__device__ __forceinline__ double flog(double x, int ebias, const double *T) {
+    double f = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+    int e    = __builtin_amdgcn_frexp_exp(x);
+    const bool lo = f < 0.70710678118654752440;
+    f = lo ? f + f : f;  // [sqrt(1/2), sqrt(2))
+    e = lo ? e - 1 : e;
+    const int j     = (int) (f * 256.0) - 181;
+    const double2 t = reinterpret_cast<const double2 *>(T + GenfTab::LG)[j];  // {c_j, -ln c_j}
+    const double r  = fma(f, t.x, -1.0);
+    double p = fma(r, 1.0 / 7.0, -1.0 / 6.0);
+    p = fma(r, p, 0.2);
+    p = fma(r, p, -0.25);
+    p = fma(r, p, 1.0 / 3.0);
+    p = fma(r, p, -0.5);
+    p = fma(r, p, 1.0);
+    const double de = (double) (e - ebias);
+    return fma(de, 0.69314716756343842, fma(de, 1.2996506893901347e-08, fma(r, p, t.y)));
+}
+
+__device__ __forceinline__ double fexp(double x, const double *T) {
+    x = fmin(fmax(x, -745.0), 709.0);
+    const double n = __builtin_rint(x * 92.332482616893656877);  // 64 / ln 2
+    double r = fma(-n, 0.010830424493178725, x);
+    r = fma(-n, 2.0307042021720854e-10, r);
+    const int ni = (int) n;
+    double p = fma(r, 1.0 / 720, 1.0 / 120);
+    p = fma(r, p, 1.0 / 24);
+    p = fma(r, p, 1.0 / 6);
+    p = fma(r, p, 0.5);
+    p = fma(r, p, 1.0);
+    p = fma(r, p, 1.0);
+    return ldexp(T[GenfTab::EX + (ni & 63)] * p, ni >> 6);
+}
+
+__device__ __forceinline__ double frcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return fma(fma(-d, r, 1.0), r, r);
+}
+
+// sqrt(v) for v >= 0 (v = 0 -> 0); v is far from the subnormal range (P(k) |ln R| of a mode that carries power)
+__device__ __forceinline__ double sqrt_pos(double v) {
+    const double r = __builtin_amdgcn_rsq(v);
+    double g = v * r, h = 0.5 * r;
+    const double e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    g = fma(fma(-g, g, v), h, g);
+    g = fma(fma(-g, g, v), h, g);
+    return v > 0.0 ? g : 0.0;
+}
+
+// cos/sin(2 pi m 2^-64) from sc[j] = {cos, sin}(2 pi j / 512)
+__device__ __forceinline__ void sincos_u01(double md, const double *T, double &sn, double &cs) {
+    const double t = md * 2.77555756156289135e-17;  // m * 2^-55 = theta * 512, exact
+    const double j = __builtin_rint(t);
+    const double b = (t - j) * 1.22718463030851298e-02;  // 2 pi / 512 * (theta*512 - j), |b| <= pi/512
+    const double2 a = reinterpret_cast<const double2 *>(T + GenfTab::SC)[((int) j) & 511];
+    const double b2 = b * b;
+    const double sb = fma(b * b2, fma(b2, 8.33333333333333322e-03, -1.66666666666666657e-01), b);          // sin b
+    const double cm = b2 * fma(b2, fma(b2, -1.38888888888888894e-03, 4.16666666666666644e-02), -0.5);     // cos b - 1
+    cs = a.x + fma(a.x, cm, -a.y * sb);
+    sn = a.y + fma(a.y, cm, a.x * sb);
+}
+
+// PowerSpectrum::power (src/power_spectrum.cpp:225-261) for k2 = |k|^2 > 0, from the LDS image
+template <bool PLAW>
+__device__ __forceinline__ double genf_power(const GenConst &g, const double *T, double k2) {
+    const double v = 0.5 * flog(k2, 0, T);  // ln k
+    double val;
+    if constexpr (PLAW) {
+        val = g.powerlaw_index * v;
+    } else {
+        const int nseg = g.genf_nseg;
+        const unsigned short *lut = reinterpret_cast<const unsigned short *>(T + GenfTab::lut(nseg));
+        int c = (int) ((v - g.glut_x0) * g.glut_inv_dx);
+        c     = c < 0 ? 0 : (c >= GenfTab::GLUT ? GenfTab::GLUT - 1 : c);
+        int klo = lut[c];
+        const double *seg = T + GenfTab::SEG;
+        while (klo < nseg - 1 && seg[6 * (klo + 1)] <= v) klo++;  // largest klo with x[klo] <= v (spline_function.h:146-152)
+        const double2 *rec = reinterpret_cast<const double2 *>(seg + 6 * klo);
+        const double2 q0 = rec[0], q1 = rec[1], q2 = rec[2];  // {x_lo, 1/h}, {y_lo, y_hi}, {c_lo, c_hi}
+        const double b = (v - q0.x) * q0.y, a = 1.0 - b;
+        val = fma(a, q1.x, b * q1.y) + fma(fma(a * a, a, -a), q2.x, fma(b * b, b, -b) * q2.y);
+    }
+    return fexp(fma(-k2, g.pk_smooth2, val), T) * g.pk_norm;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_genf: the production generator for the half-space rows ky >= 1 (k_gen above stays the general
+// kernel: the ky = 0 plane with its conjugate "loser" modes, the f_NL passes, the one-mode filter, the
+// direct P(k) evaluation and the tuning ablations).  Same mapping, same RNG walk and same output as
+// k_gen, restructured for the hardware:
+//   * z (hence kz, the walk map, the fold twiddle and the |kz| = kmax rule) is wave-uniform: all of
+//     that lives in SGPRs; the zero rule of zeldovich.cpp:350-353 is one integer compare per lane
+//     (k2i_cut = smallest integer |k|^2 whose double product with fundamental^2 reaches k2_cutoff);
+//   * no global-memory gathers: P(k), ln, exp and the Box-Muller direction come from LDS tables (above);
+//   * a wave whose 64 modes are all zeroed only moves the RNG (ONE multiply-add by the full-stride map);
+//   * the displacement algebra is accumulated per field, not per job: with s_j = k_j fund / k^2 and
+//     kx, ky fixed per thread,  sum (1 -+ s_x) D w = S0 -+ kx SE,  sum (-+s_z + i s_y) D w = -+SZ + i ky SE
+//     where S0 = sum D w, SE = sum (fund/k^2) D w, SZ = sum kz (fund/k^2) D w   (3 accumulators for the
+//     4 ZA jobs; PLT keeps 7 because its eigenvectors differ mode by mode).
+// grid: (ceil(N/GEN_BX), L/ZR, nrows)  block: GEN_BX          row kyl = kyl0 + blockIdx.z of the slab
+enum { GENF_DENS = 0, GENF_ZA = 1, GENF_PLT = 2 };
+
+__device__ __forceinline__ void cmac(double &ar, double &ai, double c, double dr, double di) {
+    ar = fma(c, dr, ar);
+    ai = fma(c, di, ai);
+}
+
+template <int ZR, int KIND, bool PLAW>
+__global__ __launch_bounds__(GEN_BX) void k_genf(GenConst g, GenJumps J, StoreLayout S, int zW, int ky0, int kyl0, int nky,
+                                                 int L, int residue, const cplx *__restrict__ twN,
+                                                 cplx *__restrict__ Y) {
+    constexpr int NACC = KIND == GENF_DENS ? 1 : (KIND == GENF_ZA ? 3 : 7);
+    const int N = g.N, half = g.half, R = N / L;
+    const int x   = blockIdx.x * GEN_BX + threadIdx.x;
+    const int k20 = blockIdx.y * ZR;
+    const int kyl = kyl0 + blockIdx.z;
+    const int ky  = ky0 + kyl;  // >= 1
+    extern __shared__ __attribute__((aligned(16))) double T[];  // GenfTab image
+    for (int i = threadIdx.x; i < g.genf_n / 2; i += GEN_BX)
+        reinterpret_cast<double2 *>(T)[i] = reinterpret_cast<const double2 *>(g.genf_tab)[i];
+    __syncthreads();
+    if (x >= N) return;
+    const int kx = x > half ? x - N : x;
+    if (S.prune & 1) {  // see k_gen: skip columns whose k_zfft tiles (self and shifted twin) are all zero
+        bool all_zero = true;
+        const int xt0 = x - x % zW;
+        for (int i = -1; i <= zW; i++) {
+            const int xi = (xt0 + i) & (N - 1);
+            all_zero = all_zero && column_is_zero(S, xi > half ? xi - N : xi, ky);
+        }
+        if (all_zero) return;
+    }
+    const int kxy2  = kx * kx + ky * ky;
+    const bool dead = (kx < 0 ? -kx : kx) == g.kmax || ky == g.kmax;  // zeldovich.cpp:350
+    EigAxis eax = {0, 0, 0.0}, eay = {0, 0, 0.0};
+    if constexpr (KIND == GENF_PLT) {
+        eax = eig_axis(g, eig_index_x(g, kx));
+        eay = eig_axis(g, ky);
+    }
+    u128 s;
+    {  // state one step ahead of the first mode's counter
+        const int kz0 = k20 > half ? k20 - N : k20;  // k20 > N/2 only happens when R = 1
+        const uint64_t off = 2ULL * ((uint64_t) (kz0 & 65535) * 65536ULL + (uint64_t) (kx & 65535)) + 1ULL;
+        s = advance_bits(g.row_state[ky], off);
+    }
+#pragma unroll 1
+    for (int zi = 0; zi < ZR; zi++) {
+        const int k2 = k20 + zi;
+        double accr[NACC], acci[NACC];
+#pragma unroll
+        for (int j = 0; j < NACC; j++) accr[j] = acci[j] = 0.0;
+#pragma unroll 1
+        for (int k1 = 0; k1 < R; k1++) {
+            const int z  = k2 + L * k1;
+            const int kz = z > half ? z - N : z;
+            const int k2i = kxy2 + kz * kz;
+            const bool live = !dead && (kz < 0 ? -kz : kz) != g.kmax && (g.corner_modes || k2i < g.k2i_cut);
+            int sel;
+            const zdpcg::Affine *m, *mf;
+            if (k1 + 1 < R) {
+                sel = (z > half) != (z + L > half);
+                m   = &J.fwd[sel];
+                mf  = &J.fwd_full[sel];
+            } else {
+                sel = (z > half) != (k2 + 1 > half);
+                m   = &J.back[sel];
+                mf  = &J.back_full[sel];
+            }
+            if (!__any(live)) {  // all 64 modes zeroed: their draws are not needed, only the walk moves on
+                s = zdpcg::apply(*mf, s);
+                continue;
+            }
+            const uint64_t r1 = zdpcg::output(s);
+            const u128 s2     = zdpcg::step(s);
+            const uint64_t r2 = zdpcg::output(s2);
+            s = zdpcg::apply(*m, s2);
+            if (!live) continue;
+            // ---- cgauss<2> (power_spectrum.cpp:338-359) ----
+            const double k2v = (double) k2i * g.fundamental2;
+            const double P   = (g.ablate & 16) ? 1e-9 * k2v : genf_power<PLAW>(g, T, k2v);  // bit 4: tuning ablation
+            const double ik2 = frcp(k2v);
+            const uint64_t m1 = r1 + 1ULL;  // one_rand<2>: u = (r + 1) 2^-64, and 1.0 for r = 2^64 - 1 (m = 0)
+            double v = P;
+            if (!g.fixed_power) v = m1 == 0 ? 0.0 : -P * flog(u64_to_double(m1), 64, T);
+            const double amp = sqrt_pos(v);
+            double sn, cs;
+            sincos_u01(u64_to_double(r2 + 1ULL), T, sn, cs);  // m = 0 (theta = 1) lands on direction 0 like theta = 0
+            double dr = amp * cs, di = amp * sn;
+            if (R > 1) {  // W_R^{k1 r}
+                const cplx w = twN[(int) (((long long) k1 * residue * L) & (N - 1))];
+                const double a = dr * w.x - di * w.y, b = dr * w.y + di * w.x;
+                dr = a;
+                di = b;
+            }
+            accr[0] += dr;
+            acci[0] += di;
+            if constexpr (KIND == GENF_ZA) {
+                const double q  = g.fundamental * ik2;
+                const double er = q * dr, ei = q * di;
+                accr[1] += er;
+                acci[1] += ei;
+                cmac(accr[2], acci[2], (double) kz, er, ei);
+            } else if constexpr (KIND == GENF_PLT) {
+                double e[4];
+                const EigAxis eaz = eig_axis(g, eig_index_z(g, kz));
+                get_eigenmode_dev(g, kx, ky, kz, eax, eay, eaz, e);
+                const double f = (sqrt(1. + 24 * e[3] * g.f_cluster) - 1) * .25;
+                double rescale = 1.0;
+                if (g.qPLTrescale) rescale = exp(g.ln_growth_ratio * (g.target_f - f));
+                const double sx = rescale * e[0] * g.fundamental * ik2;
+                const double sy = rescale * e[1] * g.fundamental * ik2;
+                const double sz = rescale * e[2] * g.fundamental * ik2;
+                cmac(accr[1], acci[1], sx, dr, di);
+                cmac(accr[2], acci[2], sy, dr, di);
+                cmac(accr[3], acci[3], sz, dr, di);
+                cmac(accr[4], acci[4], f * sx, dr, di);
+                cmac(accr[5], acci[5], f * sy, dr, di);
+                cmac(accr[6], acci[6], f * sz, dr, di);
+            }
+        }
+        // ---- job inputs from the field sums, times W_N^{k2 r}; Y[((j*nky + kyl)*L + k2)*N + x] ----
+        double pr = 1.0, pi = 0.0;
+        if (R > 1) {
+            const cplx w = twN[(int) (((long long) k2 * residue) & (N - 1))];
+            pr = w.x;
+            pi = w.y;
+        }
+        auto put = [&](int j, double vr, double vi) {
+            const unsigned idx = (unsigned) (((j * nky + kyl) * L + k2) * N + x);
+            Y[idx] = cplx{vr * pr - vi * pi, vr * pi + vi * pr};
+        };
+        if constexpr (KIND == GENF_DENS) {
+            put(0, accr[0], acci[0]);
+        } else {
+            double xr, xi, yr, yi, zr, zi2;
+            if constexpr (KIND == GENF_ZA) {
+                xr = (double) kx * accr[1]; xi = (double) kx * acci[1];
+                yr = (double) ky * accr[1]; yi = (double) ky * acci[1];
+                zr = accr[2];               zi2 = acci[2];
+            } else {
+                xr = accr[1]; xi = acci[1];
+                yr = accr[2]; yi = acci[2];
+                zr = accr[3]; zi2 = acci[3];
+            }
+            put(0, accr[0] - xr, acci[0] - xi);   // JOB_A_SELF  (1 - s_x) D
+            put(1, accr[0] + xr, acci[0] + xi);   // JOB_A_TWIN  (1 + s_x) D
+            put(2, -zr - yi, -zi2 + yr);          // JOB_B_SELF  (-s_z + i s_y) D
+            put(3, zr - yi, zi2 + yr);            // JOB_B_TWIN  ( s_z + i s_y) D
+            if constexpr (KIND == GENF_PLT) {
+                put(4, -accr[4], -acci[4]);                        // JOB_C_BOTH  -f s_x D
+                put(5, -accr[6] - acci[5], -acci[6] + accr[5]);    // JOB_D_SELF  f(-s_z + i s_y) D
+                put(6, accr[6] - acci[5], acci[6] + accr[5]);      // JOB_D_TWIN  f( s_z + i s_y) D
+            }
         }
     }
 }
@@ -891,21 +1178,66 @@ int zfft_tile_width(int L);
 
 template <int NJ, bool PLT, bool PLAW>
 static int launch_gen_t(const GenConst &g, const GenJumps &J, const JobList &jobs, const StoreLayout &S, int ky0, int nky,
-                        int L, int residue, const void *twN, void *Y, hipStream_t st) {
+                        int nrows, int L, int residue, const void *twN, void *Y, hipStream_t st) {
     const int N = g.N;
-    dim3 grid((N + GEN_BX - 1) / GEN_BX, L / GEN_ZR, nky), block(GEN_BX);
+    dim3 grid((N + GEN_BX - 1) / GEN_BX, L / GEN_ZR, nrows), block(GEN_BX);
     hipLaunchKernelGGL((k_gen<GEN_ZR, NJ, PLT, PLAW>), grid, block, 0, st, g, J, jobs, S, zfft_tile_width(L), ky0, nky,
                        L, residue, (const cplx *) twN, (cplx *) Y);
     ZD_LAUNCH_CHECK();
     return 0;
 }
+template <int KIND, bool PLAW>
+static int launch_genf_t(const GenConst &g, const GenJumps &J, const StoreLayout &S, int ky0, int kyl0, int nky, int nrows,
+                         int L, int residue, const void *twN, void *Y, hipStream_t st) {
+    const int N = g.N;
+    dim3 grid((N + GEN_BX - 1) / GEN_BX, L / GEN_ZR, nrows), block(GEN_BX);
+    hipLaunchKernelGGL((k_genf<GEN_ZR, KIND, PLAW>), grid, block, sizeof(double) * (size_t) g.genf_n, st, g, J, S,
+                       zfft_tile_width(L), ky0, kyl0, nky, L, residue, (const cplx *) twN, (cplx *) Y);
+    ZD_LAUNCH_CHECK();
+    return 0;
+}
+template <int KIND>
+static int launch_genf_k(const GenConst &g, const GenJumps &J, const StoreLayout &S, int ky0, int kyl0, int nky, int nrows,
+                         int L, int residue, const void *twN, void *Y, hipStream_t st) {
+    if (g.is_powerlaw) return launch_genf_t<KIND, true>(g, J, S, ky0, kyl0, nky, nrows, L, residue, twN, Y, st);
+    return launch_genf_t<KIND, false>(g, J, S, ky0, kyl0, nky, nrows, L, residue, twN, Y, st);
+}
+// the job order k_genf writes (= the order zd_plan builds)
+static bool genf_jobs_ok(const JobList &jobs) {
+    static const int za[7] = {JOB_A_SELF, JOB_A_TWIN, JOB_B_SELF, JOB_B_TWIN, JOB_C_BOTH, JOB_D_SELF, JOB_D_TWIN};
+    if (jobs.n == 1) return jobs.kind[0] == JOB_DENS;
+    if (jobs.n != 4 && jobs.n != 7) return false;
+    for (int j = 0; j < jobs.n; j++)
+        if (jobs.kind[j] != za[j]) return false;
+    return true;
+}
 int launch_gen(const GenConst &g, const GenJumps &J, const JobList &jobs, const StoreLayout &S, int ky0, int nky, int L,
                int residue, const void *twN, void *Y, hipStream_t st) {
     if (L % GEN_ZR != 0) return 2;
-#define GCASE(nj, plt)                                                                                        \
-    if (jobs.n == nj && (g.qPLT != 0) == plt) {                                                               \
-        if (g.is_powerlaw) return launch_gen_t<nj, plt, true>(g, J, jobs, S, ky0, nky, L, residue, twN, Y, st); \
-        return launch_gen_t<nj, plt, false>(g, J, jobs, S, ky0, nky, L, residue, twN, Y, st);                    \
+    static const bool force_general = getenv("ZD_GEN_GENERAL") != nullptr;
+    // rows ky >= 1 of a production run go through k_genf; everything else through the general kernel
+    const bool fast = g.genf_tab && !g.phik && !g.gen_phi && !g.qonemode && !(g.ablate & 15) && !force_general && genf_jobs_ok(jobs)
+                      && (jobs.n == 1 || (jobs.n == 7) == (g.qPLT != 0));
+    int general_rows = nky;
+    if (fast) {
+        general_rows = ky0 == 0 ? 1 : 0;  // the ky = 0 plane (conjugate "loser" modes) stays with k_gen
+        const int kyl0 = general_rows, nrows = nky - general_rows;
+        if (nrows > 0) {
+            int rc;
+            if (jobs.n == 1)
+                rc = launch_genf_k<GENF_DENS>(g, J, S, ky0, kyl0, nky, nrows, L, residue, twN, Y, st);
+            else if (jobs.n == 4)
+                rc = launch_genf_k<GENF_ZA>(g, J, S, ky0, kyl0, nky, nrows, L, residue, twN, Y, st);
+            else
+                rc = launch_genf_k<GENF_PLT>(g, J, S, ky0, kyl0, nky, nrows, L, residue, twN, Y, st);
+            if (rc) return rc;
+        }
+        if (general_rows == 0) return 0;
+    }
+#define GCASE(nj, plt)                                                                                                      \
+    if (jobs.n == nj && (g.qPLT != 0) == plt) {                                                                             \
+        if (g.is_powerlaw) return launch_gen_t<nj, plt, true>(g, J, jobs, S, ky0, nky, general_rows, L, residue, twN, Y, st); \
+        return launch_gen_t<nj, plt, false>(g, J, jobs, S, ky0, nky, general_rows, L, residue, twN, Y, st);                    \
     }
     GCASE(1, false)
     GCASE(1, true)
