@@ -124,6 +124,8 @@ struct zd_plan {
     u128 *d_rowstate = nullptr;
     cplx *d_twN = nullptr, *d_twL = nullptr;
     double *d_genf = nullptr;  // LDS image of k_genf
+    unsigned *d_tilectr = nullptr;  // one work counter per k_genf launch of a pass
+    int n_tilectr = 0, gen_max_wgs = 0;
     zd::Reduce *d_red = nullptr;
     // folded FFT inputs of one slab of half-space rows: Y[job][row][k2][x]; double-buffered so that
     // k_gen (VALU-bound) of slab s+1 runs beside k_zfft (HBM-bound) of slab s on a second stream
@@ -168,6 +170,11 @@ void collect_events(zd_plan *pl) {
     pl->events.clear();
 }
 
+// Rows of the block store are N*16 B apart: at PPD >= 2048 that is a multiple of 32 KB and the strided accesses of
+// the y pass pile onto a few HBM channels (PPD=4096: k_yfft 1.20 s -> 0.92 s with the pad, PPD=2048: 100 -> 93 ms).
+// 384 B of padding per row de-aliases them (128 B and 640 B do as well; 256 B does not at PPD=2048) for 0.6-5 % more memory.
+int store_row_pad(int64_t N) { return N >= 512 ? 24 : 0; }
+
 int64_t y_bytes_per_row(const zd_plan *pl) { return (int64_t) pl->jobs.n * pl->L * pl->N * 16; }
 
 // advance by (2*65536*drows - 1) draws, drows may be negative (period 2^128)
@@ -190,7 +197,7 @@ int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes
     for (int R = 1; N / R >= 32; R *= 2) {
         if ((N / R) % nranks) break;
         if (N / R > 4096) continue;  // z-FFT kernels exist up to length 4096
-        int64_t store = N * N * (N / R) / nranks * 16 * narray;
+        int64_t store = N * (N + store_row_pad(N)) * (N / R) / nranks * 16 * narray;
         if (nranks > 1) store *= 2;  // separate send and receive buffers
         if (store <= budget_bytes) return R;
     }
@@ -456,7 +463,7 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         S.lBk = lBk;
         S.lBz = lBz;
         S.one_block = (nranks == 1 && lBk == S.lHq + 1 && lBz == 0 && !S.rows_outer) ? 1 : 0;
-        int row_pad = 0;  // in complex elements
+        int row_pad = store_row_pad(pl->N);  // in complex elements
         if (const char *env = getenv("ZD_PAD")) sscanf(env, "%d", &row_pad);
         S.pitch      = pl->N + row_pad;
         S.a_rows     = (1 << lBk) << lBz;
@@ -476,11 +483,26 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
     // ---- folded-input slabs (two, for the gen||zfft overlap): enough rows per launch to fill the chip ----
     {
         const int64_t row_b = y_bytes_per_row(pl);
-        int rows = (int) std::max<int64_t>(1, ((int64_t) 3 << 29) / row_b);  // ~1.5 GB per buffer
+        int64_t slab_b = (int64_t) 3 << 29;  // ~1.5 GB per buffer
+        if (const char *env = getenv("ZD_SLAB_MB")) slab_b = (int64_t) atoll(env) << 20;
+        int rows = (int) std::max<int64_t>(1, slab_b / row_b);
         rows     = std::min(rows, pl->Hq);
         while (pl->Hq % rows) rows--;
         pl->slab_rows = rows;
         pl->overlap   = getenv("ZD_NO_OVERLAP") == nullptr;
+        // k_genf is a persistent kernel: a few workgroups per CU pull tiles from a counter (one per launch).  With
+        // the second stream active the grid is kept small enough that a k_zfft workgroup (64 KB LDS, 2 waves/SIMD)
+        // always fits beside the generator's waves on every CU.
+        {
+            int dev = 0, ncu = 256;
+            hipGetDevice(&dev);
+            hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+            int per_cu = pl->overlap ? 3 : 6;
+            if (const char *env = getenv("ZD_GEN_WGS")) per_cu = atoi(env);
+            pl->gen_max_wgs = std::max(1, per_cu) * std::max(1, ncu);
+            pl->n_tilectr   = pl->Hq / rows + 2;
+            PLCHECK(hipMalloc((void **) &pl->d_tilectr, sizeof(unsigned) * pl->n_tilectr));
+        }
         for (int i = 0; i < (pl->overlap ? 2 : 1); i++) PLCHECK(hipMalloc((void **) &pl->d_Y[i], (size_t) row_b * rows));
         if (pl->overlap) {
             PLCHECK(hipStreamCreateWithFlags(&pl->s_gen, hipStreamNonBlocking));
@@ -509,6 +531,7 @@ void zd_plan_destroy(zd_plan *pl) {
     hipFree(pl->d_twN);
     hipFree(pl->d_twL);
     hipFree(pl->d_genf);
+    hipFree(pl->d_tilectr);
     hipFree(pl->d_red);
     hipFree(pl->d_Y[0]);
     hipFree(pl->d_Y[1]);
@@ -538,10 +561,14 @@ int zd_plan_stage_z(zd_plan *pl, int residue, void *d_send, void *hip_stream) {
     if (residue < 0 || residue >= pl->R) return 1;
     const int ky_first = pl->rank * pl->Hq;
     if (!pl->overlap) {
-        for (int r0 = 0; r0 < pl->Hq; r0 += pl->slab_rows) {
+        HIPCHECK(hipMemsetAsync(pl->d_tilectr, 0, sizeof(unsigned) * pl->n_tilectr, st));
+        int slab = 0;
+        for (int r0 = 0; r0 < pl->Hq; r0 += pl->slab_rows, slab++) {
             const int nky = std::min(pl->slab_rows, pl->Hq - r0);
             tick(pl, ZD_K_GEN, st, true);
-            if (zd::launch_gen(pl->g, pl->J, pl->jobs, pl->S, ky_first + r0, nky, pl->L, residue, pl->d_twN, pl->d_Y[0], st)) return 1;
+            if (zd::launch_gen(pl->g, pl->J, pl->jobs, pl->S, ky_first + r0, nky, pl->L, residue, pl->d_twN, pl->d_Y[0],
+                               pl->d_tilectr + slab, pl->gen_max_wgs, st))
+                return 1;
             tick(pl, ZD_K_GEN, st, false);
             tick(pl, ZD_K_ZFFT, st, true);
             if (zd::launch_zfft(pl->L, pl->jobs, pl->S, ky_first + r0, r0, nky, pl->Zq, pl->d_Y[0], pl->d_twL, d_send, st))
@@ -554,6 +581,7 @@ int zd_plan_stage_z(zd_plan *pl, int residue, void *d_send, void *hip_stream) {
     HIPCHECK(hipEventRecord(pl->ev_fork, st));
     HIPCHECK(hipStreamWaitEvent(pl->s_gen, pl->ev_fork, 0));
     HIPCHECK(hipStreamWaitEvent(pl->s_fft, pl->ev_fork, 0));
+    HIPCHECK(hipMemsetAsync(pl->d_tilectr, 0, sizeof(unsigned) * pl->n_tilectr, pl->s_gen));
     int slab = 0;
     for (int r0 = 0; r0 < pl->Hq; r0 += pl->slab_rows, slab++) {
         const int nky = std::min(pl->slab_rows, pl->Hq - r0);
@@ -561,7 +589,8 @@ int zd_plan_stage_z(zd_plan *pl, int residue, void *d_send, void *hip_stream) {
         // k_gen may overwrite Y[b] only after the k_zfft that read it (two slabs ago) has finished
         if (slab >= 2) HIPCHECK(hipStreamWaitEvent(pl->s_gen, pl->ev_fft[b], 0));
         tick(pl, ZD_K_GEN, pl->s_gen, true);
-        if (zd::launch_gen(pl->g, pl->J, pl->jobs, pl->S, ky_first + r0, nky, pl->L, residue, pl->d_twN, pl->d_Y[b], pl->s_gen))
+        if (zd::launch_gen(pl->g, pl->J, pl->jobs, pl->S, ky_first + r0, nky, pl->L, residue, pl->d_twN, pl->d_Y[b],
+                           pl->d_tilectr + slab, pl->gen_max_wgs, pl->s_gen))
             return 1;
         tick(pl, ZD_K_GEN, pl->s_gen, false);
         HIPCHECK(hipEventRecord(pl->ev_gen[b], pl->s_gen));

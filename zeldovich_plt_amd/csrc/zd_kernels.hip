@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <algorithm>
 #include <stdlib.h>
 
 #include "zd_device.h"
@@ -421,6 +422,38 @@ struct GenfTab {  // offsets in doubles inside the LDS image (zd_capi.cpp: build
     static constexpr int size(int nseg) { return SEG + 6 * nseg + GLUT / 4; }
 };
 
+// a*b + c as the three-address VOP3 form.  Left to itself the compiler picks the two-address v_fmac_f64 for the
+// Horner steps below and then has to copy every coefficient into the destination first (a quarter of the loop's
+// vector instructions were such v_mov_b64).  CAUTION (hipcc 7.2): with these asm statements inside a lane-divergent
+// `if (...) continue` region of the mode loop the PLT kernel produced wrong displacements (15 % off; parity tests
+// caught it) — k_genf therefore keeps zeroed lanes in the arithmetic with amplitude 0 instead of branching around
+// it.  -DZD_NO_FMA_ASM builds the plain fma() version.
+__device__ __forceinline__ double fma3(double a, double b, double c) {
+#ifdef ZD_NO_FMA_ASM
+    return fma(a, b, c);
+#endif
+    double d;
+    asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+__device__ __forceinline__ double fnma3(double a, double b, double c) {  // -a*b + c
+#ifdef ZD_NO_FMA_ASM
+    return fma(-a, b, c);
+#endif
+    double d;
+    asm volatile("v_fma_f64 %0, -%1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ double fmas3(double a, double b, double c) {  // a*b - c
+#ifdef ZD_NO_FMA_ASM
+    return fma(a, b, -c);
+#endif
+    double d;
+    asm volatile("v_fma_f64 %0, %1, %2, -%3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 __device__ __forceinline__ double u64_to_double(uint64_t m) {  // round-to-nearest: both halves are exact, one rounding in the fma
     return fma((double) (uint32_t) (m >> 32), 4294967296.0, (double) (uint32_t) m);
 }
@@ -435,46 +468,46 @@ __device__ __forceinline__ double flog(double x, int ebias, const double *T) {
     const int j     = (int) (f * 256.0) - 181;
     const double2 t = reinterpret_cast<const double2 *>(T + GenfTab::LG)[j];  // {c_j, -ln c_j}
     const double r  = fma(f, t.x, -1.0);
-    double p = fma(r, 1.0 / 7.0, -1.0 / 6.0);
-    p = fma(r, p, 0.2);
-    p = fma(r, p, -0.25);
-    p = fma(r, p, 1.0 / 3.0);
-    p = fma(r, p, -0.5);
-    p = fma(r, p, 1.0);
+    double p = fma3(r, 1.0 / 7.0, -1.0 / 6.0);
+    p = fma3(r, p, 0.2);
+    p = fma3(r, p, -0.25);
+    p = fma3(r, p, 1.0 / 3.0);
+    p = fma3(r, p, -0.5);
+    p = fma3(r, p, 1.0);
     const double de = (double) (e - ebias);
-    return fma(de, 0.69314716756343842, fma(de, 1.2996506893901347e-08, fma(r, p, t.y)));
+    return fma3(de, 0.69314716756343842, fma3(de, 1.2996506893901347e-08, fma3(r, p, t.y)));
 }
 
 __device__ __forceinline__ double fexp(double x, const double *T) {
     x = fmin(fmax(x, -745.0), 709.0);
     const double n = __builtin_rint(x * 92.332482616893656877);  // 64 / ln 2
-    double r = fma(-n, 0.010830424493178725, x);
-    r = fma(-n, 2.0307042021720854e-10, r);
+    double r = fma3(n, -0.010830424493178725, x);
+    r = fma3(n, -2.0307042021720854e-10, r);
     const int ni = (int) n;
-    double p = fma(r, 1.0 / 720, 1.0 / 120);
-    p = fma(r, p, 1.0 / 24);
-    p = fma(r, p, 1.0 / 6);
-    p = fma(r, p, 0.5);
-    p = fma(r, p, 1.0);
-    p = fma(r, p, 1.0);
+    double p = fma3(r, 1.0 / 720, 1.0 / 120);
+    p = fma3(r, p, 1.0 / 24);
+    p = fma3(r, p, 1.0 / 6);
+    p = fma3(r, p, 0.5);
+    p = fma3(r, p, 1.0);
+    p = fma3(r, p, 1.0);
     return ldexp(T[GenfTab::EX + (ni & 63)] * p, ni >> 6);
 }
 
 __device__ __forceinline__ double frcp(double d) {
     double r = __builtin_amdgcn_rcp(d);
-    r = fma(fma(-d, r, 1.0), r, r);
-    return fma(fma(-d, r, 1.0), r, r);
+    r = fma3(fnma3(d, r, 1.0), r, r);
+    return fma3(fnma3(d, r, 1.0), r, r);
 }
 
 // sqrt(v) for v >= 0 (v = 0 -> 0); v is far from the subnormal range (P(k) |ln R| of a mode that carries power)
 __device__ __forceinline__ double sqrt_pos(double v) {
     const double r = __builtin_amdgcn_rsq(v);
     double g = v * r, h = 0.5 * r;
-    const double e = fma(-h, g, 0.5);
-    g = fma(g, e, g);
-    h = fma(h, e, h);
-    g = fma(fma(-g, g, v), h, g);
-    g = fma(fma(-g, g, v), h, g);
+    const double e = fnma3(h, g, 0.5);
+    g = fma3(g, e, g);
+    h = fma3(h, e, h);
+    g = fma3(fnma3(g, g, v), h, g);
+    g = fma3(fnma3(g, g, v), h, g);
     return v > 0.0 ? g : 0.0;
 }
 
@@ -485,10 +518,10 @@ __device__ __forceinline__ void sincos_u01(double md, const double *T, double &s
     const double b = (t - j) * 1.22718463030851298e-02;  // 2 pi / 512 * (theta*512 - j), |b| <= pi/512
     const double2 a = reinterpret_cast<const double2 *>(T + GenfTab::SC)[((int) j) & 511];
     const double b2 = b * b;
-    const double sb = fma(b * b2, fma(b2, 8.33333333333333322e-03, -1.66666666666666657e-01), b);          // sin b
-    const double cm = b2 * fma(b2, fma(b2, -1.38888888888888894e-03, 4.16666666666666644e-02), -0.5);     // cos b - 1
-    cs = a.x + fma(a.x, cm, -a.y * sb);
-    sn = a.y + fma(a.y, cm, a.x * sb);
+    const double sb = fma3(b * b2, fma3(b2, 8.33333333333333322e-03, -1.66666666666666657e-01), b);          // sin b
+    const double cm = b2 * fma3(b2, fma3(b2, -1.38888888888888894e-03, 4.16666666666666644e-02), -0.5);     // cos b - 1
+    cs = a.x + fmas3(a.x, cm, a.y * sb);
+    sn = a.y + fma3(a.y, cm, a.x * sb);
 }
 
 // PowerSpectrum::power (src/power_spectrum.cpp:225-261) for k2 = |k|^2 > 0, from the LDS image
@@ -509,7 +542,7 @@ __device__ __forceinline__ double genf_power(const GenConst &g, const double *T,
         const double2 *rec = reinterpret_cast<const double2 *>(seg + 6 * klo);
         const double2 q0 = rec[0], q1 = rec[1], q2 = rec[2];  // {x_lo, 1/h}, {y_lo, y_hi}, {c_lo, c_hi}
         const double b = (v - q0.x) * q0.y, a = 1.0 - b;
-        val = fma(a, q1.x, b * q1.y) + fma(fma(a * a, a, -a), q2.x, fma(b * b, b, -b) * q2.y);
+        val = fma3(a, q1.x, b * q1.y) + fma3(fmas3(a * a, a, a), q2.x, fmas3(b * b, b, b) * q2.y);
     }
     return fexp(fma(-k2, g.pk_smooth2, val), T) * g.pk_norm;
 }
@@ -537,19 +570,14 @@ __device__ __forceinline__ void cmac(double &ar, double &ai, double c, double dr
 }
 
 template <int ZR, int KIND, bool PLAW>
-__global__ __launch_bounds__(GEN_BX) void k_genf(GenConst g, GenJumps J, StoreLayout S, int zW, int ky0, int kyl0, int nky,
-                                                 int L, int residue, const cplx *__restrict__ twN,
-                                                 cplx *__restrict__ Y) {
+__device__ __forceinline__ void genf_tile(const GenConst &g, const GenJumps &J, const StoreLayout &S, const double *T, int zW,
+                                          int ky0, int kyl, int nky, int L, int residue, int bx, int by,
+                                          const cplx *__restrict__ twN, cplx *__restrict__ Y) {
     constexpr int NACC = KIND == GENF_DENS ? 1 : (KIND == GENF_ZA ? 3 : 7);
     const int N = g.N, half = g.half, R = N / L;
-    const int x   = blockIdx.x * GEN_BX + threadIdx.x;
-    const int k20 = blockIdx.y * ZR;
-    const int kyl = kyl0 + blockIdx.z;
+    const int x   = bx * GEN_BX + threadIdx.x;
+    const int k20 = by * ZR;
     const int ky  = ky0 + kyl;  // >= 1
-    extern __shared__ __attribute__((aligned(16))) double T[];  // GenfTab image
-    for (int i = threadIdx.x; i < g.genf_n / 2; i += GEN_BX)
-        reinterpret_cast<double2 *>(T)[i] = reinterpret_cast<const double2 *>(g.genf_tab)[i];
-    __syncthreads();
     if (x >= N) return;
     const int kx = x > half ? x - N : x;
     if (S.prune & 1) {  // see k_gen: skip columns whose k_zfft tiles (self and shifted twin) are all zero
@@ -574,6 +602,7 @@ __global__ __launch_bounds__(GEN_BX) void k_genf(GenConst g, GenJumps J, StoreLa
         const uint64_t off = 2ULL * ((uint64_t) (kz0 & 65535) * 65536ULL + (uint64_t) (kx & 65535)) + 1ULL;
         s = advance_bits(g.row_state[ky], off);
     }
+    const zdpcg::Affine fwd0 = J.fwd[0], fwdf0 = J.fwd_full[0];
 #pragma unroll 1
     for (int zi = 0; zi < ZR; zi++) {
         const int k2 = k20 + zi;
@@ -586,33 +615,34 @@ __global__ __launch_bounds__(GEN_BX) void k_genf(GenConst g, GenJumps J, StoreLa
             const int kz = z > half ? z - N : z;
             const int k2i = kxy2 + kz * kz;
             const bool live = !dead && (kz < 0 ? -kz : kz) != g.kmax && (g.corner_modes || k2i < g.k2i_cut);
-            int sel;
-            const zdpcg::Affine *m, *mf;
-            if (k1 + 1 < R) {
-                sel = (z > half) != (z + L > half);
-                m   = &J.fwd[sel];
-                mf  = &J.fwd_full[sel];
-            } else {
-                sel = (z > half) != (k2 + 1 > half);
-                m   = &J.back[sel];
-                mf  = &J.back_full[sel];
-            }
-            if (!__any(live)) {  // all 64 modes zeroed: their draws are not needed, only the walk moves on
-                s = zdpcg::apply(*mf, s);
+            // the walk's next move: L rows on inside the fold (the common case keeps its map in SGPRs), else back to
+            // the first term of the next k2; index 1 = the move crosses the z = N/2 wrap of the counter
+            const bool last = k1 + 1 >= R;
+            const int sel   = (z > half) != ((last ? k2 + 1 : z + L) > half);
+            const bool any  = __any(live);
+            zdpcg::Affine m;
+            if (!last && !sel)
+                m = any ? fwd0 : fwdf0;
+            else if (!last)
+                m = any ? J.fwd[1] : J.fwd_full[1];
+            else
+                m = any ? J.back[sel] : J.back_full[sel];
+            if (!any) {  // all 64 modes zeroed: their draws are not needed, only the walk moves on
+                s = zdpcg::apply(m, s);
                 continue;
             }
             const uint64_t r1 = zdpcg::output(s);
             const u128 s2     = zdpcg::step(s);
             const uint64_t r2 = zdpcg::output(s2);
-            s = zdpcg::apply(*m, s2);
-            if (!live) continue;
-            // ---- cgauss<2> (power_spectrum.cpp:338-359) ----
+            s = zdpcg::apply(m, s2);
+            // ---- cgauss<2> (power_spectrum.cpp:338-359); zeroed lanes of a live wave ride along with amplitude 0 ----
             const double k2v = (double) k2i * g.fundamental2;
             const double P   = (g.ablate & 16) ? 1e-9 * k2v : genf_power<PLAW>(g, T, k2v);  // bit 4: tuning ablation
             const double ik2 = frcp(k2v);
             const uint64_t m1 = r1 + 1ULL;  // one_rand<2>: u = (r + 1) 2^-64, and 1.0 for r = 2^64 - 1 (m = 0)
             double v = P;
-            if (!g.fixed_power) v = m1 == 0 ? 0.0 : -P * flog(u64_to_double(m1), 64, T);
+            if (!g.fixed_power) v = -P * flog(u64_to_double(m1), 64, T);
+            v = (m1 == 0 && !g.fixed_power) || !live ? 0.0 : v;
             const double amp = sqrt_pos(v);
             double sn, cs;
             sincos_u01(u64_to_double(r2 + 1ULL), T, sn, cs);  // m = 0 (theta = 1) lands on direction 0 like theta = 0
@@ -635,9 +665,9 @@ __global__ __launch_bounds__(GEN_BX) void k_genf(GenConst g, GenJumps J, StoreLa
                 double e[4];
                 const EigAxis eaz = eig_axis(g, eig_index_z(g, kz));
                 get_eigenmode_dev(g, kx, ky, kz, eax, eay, eaz, e);
-                const double f = (sqrt(1. + 24 * e[3] * g.f_cluster) - 1) * .25;
+                const double f = (sqrt_pos(1. + 24 * e[3] * g.f_cluster) - 1) * .25;
                 double rescale = 1.0;
-                if (g.qPLTrescale) rescale = exp(g.ln_growth_ratio * (g.target_f - f));
+                if (g.qPLTrescale) rescale = fexp(g.ln_growth_ratio * (g.target_f - f), T);
                 const double sx = rescale * e[0] * g.fundamental * ik2;
                 const double sy = rescale * e[1] * g.fundamental * ik2;
                 const double sz = rescale * e[2] * g.fundamental * ik2;
@@ -683,6 +713,30 @@ __global__ __launch_bounds__(GEN_BX) void k_genf(GenConst g, GenJumps J, StoreLa
                 put(6, accr[6] - acci[5], acci[6] + accr[5]);      // JOB_D_TWIN  f( s_z + i s_y) D
             }
         }
+    }
+}
+
+// Persistent launch: `gridDim.x` workgroups pull tiles (x block, k2 chunk, row) from an atomic counter.  The grid
+// is sized to a few workgroups per CU (zd_plan: gen_wgs_per_cu) so that the HBM-bound k_zfft of the previous
+// slab, running on the second stream, always finds registers and LDS next to the generator's waves.
+template <int ZR, int KIND, bool PLAW>
+__global__ __launch_bounds__(GEN_BX) void k_genf(GenConst g, GenJumps J, StoreLayout S, int zW, int ky0, int kyl0, int nky,
+                                                 int nrows, int L, int residue, const cplx *__restrict__ twN,
+                                                 cplx *__restrict__ Y, unsigned *__restrict__ tile_ctr) {
+    extern __shared__ __attribute__((aligned(16))) double T[];  // GenfTab image (+ one slot for the tile index)
+    for (int i = threadIdx.x; i < g.genf_n / 2; i += GEN_BX)
+        reinterpret_cast<double2 *>(T)[i] = reinterpret_cast<const double2 *>(g.genf_tab)[i];
+    unsigned *slot = reinterpret_cast<unsigned *>(T + g.genf_n);
+    const int gx = (g.N + GEN_BX - 1) / GEN_BX, gy = L / ZR;
+    const unsigned ntiles = (unsigned) (gx * gy * nrows);
+    for (;;) {
+        __syncthreads();  // table image complete / previous tile index consumed
+        if (threadIdx.x == 0) *slot = atomicAdd(tile_ctr, 1u);
+        __syncthreads();
+        const unsigned tile = *slot;
+        if (tile >= ntiles) break;
+        const int bx = tile % gx, by = (tile / gx) % gy, bz = tile / (gx * gy);
+        genf_tile<ZR, KIND, PLAW>(g, J, S, T, zW, ky0, kyl0 + bz, nky, L, residue, bx, by, twN, Y);
     }
 }
 
@@ -790,7 +844,13 @@ __global__ __launch_bounds__(W *N / E, MINW) void k_yfft(StoreLayout S, const cp
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int T = PL::T;
     const int w = threadIdx.x % W, t = threadIdx.x / W;
-    const int x = blockIdx.x * W + w;
+    // Tiles narrower than a 128-byte line (W < 8) share their lines with G - 1 neighbours.  Workgroups go to the
+    // XCDs round-robin by blockIdx.x, so neighbours would sit behind different L2s and every line would be fetched
+    // (and written back in pieces) G times: give the G tiles of a line to workgroups b, b + 8, ... of ONE XCD.
+    constexpr int G = W >= 8 ? 1 : 8 / W;
+    int tile = blockIdx.x;
+    if constexpr (G > 1 && (N / W) % (8 * G) == 0) tile = ((tile / (8 * G)) * 8 + (tile % 8)) * G + ((tile / 8) % G);
+    const int x = tile * W + w;
     const int zl = blockIdx.z, a = blockIdx.y;
     const int kxs = x > N / 2 ? x - N : x;
     double re[E], im[E];
@@ -1188,19 +1248,21 @@ static int launch_gen_t(const GenConst &g, const GenJumps &J, const JobList &job
 }
 template <int KIND, bool PLAW>
 static int launch_genf_t(const GenConst &g, const GenJumps &J, const StoreLayout &S, int ky0, int kyl0, int nky, int nrows,
-                         int L, int residue, const void *twN, void *Y, hipStream_t st) {
+                         int L, int residue, const void *twN, void *Y, unsigned *tile_ctr, int max_wgs, hipStream_t st) {
     const int N = g.N;
-    dim3 grid((N + GEN_BX - 1) / GEN_BX, L / GEN_ZR, nrows), block(GEN_BX);
-    hipLaunchKernelGGL((k_genf<GEN_ZR, KIND, PLAW>), grid, block, sizeof(double) * (size_t) g.genf_n, st, g, J, S,
-                       zfft_tile_width(L), ky0, kyl0, nky, L, residue, (const cplx *) twN, (cplx *) Y);
+    const long long ntiles = (long long) ((N + GEN_BX - 1) / GEN_BX) * (L / GEN_ZR) * nrows;
+    dim3 grid((unsigned) std::min<long long>(ntiles, max_wgs)), block(GEN_BX);
+    hipLaunchKernelGGL((k_genf<GEN_ZR, KIND, PLAW>), grid, block, sizeof(double) * (size_t) (g.genf_n + 2), st, g, J, S,
+                       zfft_tile_width(L), ky0, kyl0, nky, nrows, L, residue, (const cplx *) twN, (cplx *) Y, tile_ctr);
     ZD_LAUNCH_CHECK();
     return 0;
 }
 template <int KIND>
 static int launch_genf_k(const GenConst &g, const GenJumps &J, const StoreLayout &S, int ky0, int kyl0, int nky, int nrows,
-                         int L, int residue, const void *twN, void *Y, hipStream_t st) {
-    if (g.is_powerlaw) return launch_genf_t<KIND, true>(g, J, S, ky0, kyl0, nky, nrows, L, residue, twN, Y, st);
-    return launch_genf_t<KIND, false>(g, J, S, ky0, kyl0, nky, nrows, L, residue, twN, Y, st);
+                         int L, int residue, const void *twN, void *Y, unsigned *tile_ctr, int max_wgs, hipStream_t st) {
+    if (g.is_powerlaw)
+        return launch_genf_t<KIND, true>(g, J, S, ky0, kyl0, nky, nrows, L, residue, twN, Y, tile_ctr, max_wgs, st);
+    return launch_genf_t<KIND, false>(g, J, S, ky0, kyl0, nky, nrows, L, residue, twN, Y, tile_ctr, max_wgs, st);
 }
 // the job order k_genf writes (= the order zd_plan builds)
 static bool genf_jobs_ok(const JobList &jobs) {
@@ -1212,11 +1274,11 @@ static bool genf_jobs_ok(const JobList &jobs) {
     return true;
 }
 int launch_gen(const GenConst &g, const GenJumps &J, const JobList &jobs, const StoreLayout &S, int ky0, int nky, int L,
-               int residue, const void *twN, void *Y, hipStream_t st) {
+               int residue, const void *twN, void *Y, unsigned *tile_ctr, int max_wgs, hipStream_t st) {
     if (L % GEN_ZR != 0) return 2;
     static const bool force_general = getenv("ZD_GEN_GENERAL") != nullptr;
     // rows ky >= 1 of a production run go through k_genf; everything else through the general kernel
-    const bool fast = g.genf_tab && !g.phik && !g.gen_phi && !g.qonemode && !(g.ablate & 15) && !force_general && genf_jobs_ok(jobs)
+    const bool fast = g.genf_tab && tile_ctr && !g.phik && !g.gen_phi && !g.qonemode && !(g.ablate & 15) && !force_general && genf_jobs_ok(jobs)
                       && (jobs.n == 1 || (jobs.n == 7) == (g.qPLT != 0));
     int general_rows = nky;
     if (fast) {
@@ -1225,11 +1287,11 @@ int launch_gen(const GenConst &g, const GenJumps &J, const JobList &jobs, const 
         if (nrows > 0) {
             int rc;
             if (jobs.n == 1)
-                rc = launch_genf_k<GENF_DENS>(g, J, S, ky0, kyl0, nky, nrows, L, residue, twN, Y, st);
+                rc = launch_genf_k<GENF_DENS>(g, J, S, ky0, kyl0, nky, nrows, L, residue, twN, Y, tile_ctr, max_wgs, st);
             else if (jobs.n == 4)
-                rc = launch_genf_k<GENF_ZA>(g, J, S, ky0, kyl0, nky, nrows, L, residue, twN, Y, st);
+                rc = launch_genf_k<GENF_ZA>(g, J, S, ky0, kyl0, nky, nrows, L, residue, twN, Y, tile_ctr, max_wgs, st);
             else
-                rc = launch_genf_k<GENF_PLT>(g, J, S, ky0, kyl0, nky, nrows, L, residue, twN, Y, st);
+                rc = launch_genf_k<GENF_PLT>(g, J, S, ky0, kyl0, nky, nrows, L, residue, twN, Y, tile_ctr, max_wgs, st);
             if (rc) return rc;
         }
         if (general_rows == 0) return 0;
