@@ -83,8 +83,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--ppd", type=int, default=int(os.environ.get("ZD_BENCH_PPD", "2048")))
-    ap.add_argument("--plt", type=int, default=int(os.environ.get("ZD_BENCH_PLT", "1")))
+    # default workload = the configuration BASELINE.json's metric is quoted on: PPD=4096 (configs[3], ZA, NumBlock=64);
+    # it runs on ONE GPU through z-residue streaming (R=8).  --ppd 2048 --plt 1 is configs[2].
+    ap.add_argument("--ppd", type=int, default=int(os.environ.get("ZD_BENCH_PPD", "4096")))
+    ap.add_argument("--plt", type=int, default=int(os.environ.get("ZD_BENCH_PLT", "0")))
+    ap.add_argument("--no-isolated", action="store_true", help="skip the extra untimed pass that times every kernel alone")
     ap.add_argument("--format", default="RVZel")
     ap.add_argument("--stream", type=int, default=0, help="z-residue stream factor R (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -155,6 +158,19 @@ def main():
         dt = float(t.item())
     st = plan.stats()
 
+    # one extra UNTIMED pass with the two-stream overlap of the Z stage switched off: every kernel alone on the chip
+    # (in the timed region k_gen and k_zfft share it, so their hipEvent spans there include each other)
+    iso = None
+    if world == 1 and not args.no_isolated:
+        os.environ["ZD_NO_OVERLAP"] = "1"
+        plan_iso = zd.Plan(p, ps, eig=eig, rank=0, nranks=1)
+        del os.environ["ZD_NO_OVERLAP"]
+        pipe.e = HipEngine(plan_iso, N)
+        pipe.run()
+        torch.cuda.synchronize()
+        iso = plan_iso.stats()
+        plan_iso.close()
+
     if rank == 0:
         particles = float(N) ** 3
         value = particles * args.steps / dt
@@ -169,11 +185,22 @@ def main():
         per_kernel = {k: {"alg_GBps": alg[k] * particles * args.steps / world / (kms[k] * 1e-3) / 1e9 if kms[k] > 0 else None,
                           "ms_per_step": kms[k] / args.steps, "launches_per_step": kl[k] / args.steps,
                           "alg_bytes_per_particle": alg[k]} for k in alg}
+        per_kernel["k_gen"] = {"alg_GBps": None, "ms_per_step": kms["k_gen"] / args.steps,
+                               "launches_per_step": kl["k_gen"] / args.steps, "alg_bytes_per_particle": 0.0,
+                               "bound": "fp64/int VALU: 2 pcg64 steps + Box-Muller + P(k) per mode, regenerated for each of the R residue passes"}
+        isolated = None
+        if iso is not None:
+            ims = iso["kernel_ms"]
+            isolated = {k: {"ms_per_step": ims[k],
+                            "alg_GBps": (alg[k] * particles / (ims[k] * 1e-3) / 1e9) if k in alg and ims[k] > 0 else None}
+                        for k in ims}
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(dom)
+                tj = json.load(open(tfile))
+                if tj.get("workload") == "PPD=%d plt=%d" % (N, int(plt)):
+                    traffic = tj.get("bytes_per_launch", {}).get(dom)
             except Exception:
                 traffic = None
         out = {
@@ -193,8 +220,11 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches": launches,
                          "alg_bytes_per_particle": alg[dom],
-                         "note": "k_gen and k_zfft run concurrently on two streams, so their hipEvent spans overlap"},
+                         "note": "k_gen (VALU-bound) and k_zfft (HBM-bound) run concurrently on two streams: their "
+                                 "hipEvent spans in the timed region include each other; `kernels_isolated` has "
+                                 "every kernel alone on the chip (one extra untimed pass)"},
             "kernels": per_kernel,
+            "kernels_isolated": isolated,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -114,8 +114,16 @@ int zd_plan_create(const zd_params *p, const zd_pk *pk, const double *eig, int64
                    int nranks, zd_plan **out);
 void zd_plan_destroy(zd_plan *plan);
 
-int32_t zd_plan_narray(const zd_plan *plan);       /* 1, 2 or 4 (src/zeldovich.cpp:871-876) */
-int32_t zd_plan_stream_factor(const zd_plan *plan);/* R */
+int32_t zd_plan_narray(const zd_plan *plan);       /* arrays of the store: 1, 2 or 4 (src/zeldovich.cpp:871-876), or 3:
+                                                     * without ZD_qdensity the density field is not transformed and the
+                                                     * remaining 3 (ZA) / 6 (PLT) real fields are packed into 3 arrays —
+                                                     * ZA packs TWO z-residues per pass (qy+i qz of each, qx_r0 + i qx_r1),
+                                                     * PLT packs qx+i vx | qy+i qz | vy+i vz; density_variance then comes
+                                                     * from sum |D(k)|^2 (Parseval) */
+int32_t zd_plan_stream_factor(const zd_plan *plan);/* R: z-residue classes */
+int32_t zd_plan_passes(const zd_plan *plan);       /* passes per run: R, or R/2 when a pass carries two residues */
+int32_t zd_plan_plane_step(const zd_plan *plan);   /* 1, or 2 when a pass carries two residues: stage_x plane ranges
+                                                     * must be multiples of it */
 int32_t zd_plan_record_size(const zd_plan *plan);  /* bytes per particle record */
 int64_t zd_plan_exchange_bytes(const zd_plan *plan); /* bytes of the send (= receive) buffer per pass */
 int64_t zd_plan_local_planes(const zd_plan *plan);   /* Zq: z planes this rank finishes per pass */

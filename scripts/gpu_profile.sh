@@ -1,0 +1,49 @@
+# rocprofv3 evidence for the default bench workload (run through gpurun from the repo root):
+#   1. --kernel-trace --stats of `bench.py --steps 2 --warmup 1`      -> gpurun_out/prof_<TAG>/…kernel_stats.csv
+#   2. separate --pmc FETCH_SIZE / WRITE_SIZE passes (one step each)    -> per-kernel HBM bytes per launch
+#   3. a plain `python bench.py` (no profiler)                          -> gpurun_out/bench_<TAG>.json
+# Summaries are copied to profiles/ by hand afterwards (profiles/README.md).
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+TAG=${TAG:-r01b}
+ARGS=${ARGS:-}
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-isolated $ARGS > $R/gpurun_out/prof_${TAG}_bench.log 2>&1 || { tail -5 $R/gpurun_out/prof_${TAG}_bench.log; exit 1; }
+tail -1 $R/gpurun_out/prof_${TAG}_bench.log | cut -c1-300
+for c in FETCH_SIZE WRITE_SIZE; do
+rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${TAG}_$c -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-isolated $ARGS > $R/gpurun_out/pmc_${TAG}_$c.log 2>&1 || { tail -5 $R/gpurun_out/pmc_${TAG}_$c.log; exit 1; }
+done
+cd $R
+python3 - <<PY
+import csv, glob, collections, os, json
+R=os.environ['GRAFT_REPO_ROOT']; TAG="$TAG"
+res=collections.defaultdict(dict)
+for c in ("FETCH_SIZE","WRITE_SIZE"):
+    f=glob.glob(f"{R}/gpurun_out/pmc_{TAG}_{c}/**/*counter_collection.csv", recursive=True)
+    agg=collections.defaultdict(lambda:[0,0.0])
+    with open(f[0]) as fh:
+        for row in csv.DictReader(fh):
+            if row.get("Counter_Name")!=c: continue
+            k=row["Kernel_Name"].split("<")[0].replace("void ","").strip()
+            agg[k][0]+=1; agg[k][1]+=float(row["Counter_Value"])
+    with open(f"{R}/gpurun_out/pmc_{TAG}_{c}_summary.csv","w") as o:
+        o.write("kernel,launches,sum_%s_KB\n"%c)
+        for k,(n,v) in agg.items():
+            res[k][c]={"launches":n,"total_KB":v}; o.write('"%s",%d,%.1f\n'%(k,n,v))
+line=json.loads([l for l in open(f"{R}/gpurun_out/pmc_{TAG}_FETCH_SIZE.log").read().splitlines() if l.startswith('{"metric"')][-1])
+wl=line["config"]["workload"]
+out={"workload": "PPD=%s plt=%d" % (wl.split()[0].split("=")[1], 1 if "qPLT=1" in wl else 0), "bytes_per_launch": {},
+     "note": "(2*FETCH_SIZE + WRITE_SIZE)*1024/launches: gfx950 FETCH_SIZE counts half of wide coalesced reads (MI355X_MICROARCH.md, HBM)"}
+for k,v in res.items():
+    if not k.startswith("k_") or "FETCH_SIZE" not in v or "WRITE_SIZE" not in v: continue
+    n=v["FETCH_SIZE"]["launches"]
+    fetch=2*v["FETCH_SIZE"]["total_KB"]*1024; write=v["WRITE_SIZE"]["total_KB"]*1024
+    name={"k_genf":"k_gen"}.get(k,k)
+    out["bytes_per_launch"][name]=out["bytes_per_launch"].get(name,0)+(fetch+write)/n
+    print(k,"launches",n,"fetch GB (x2)",round(fetch/1e9,1),"write GB",round(write/1e9,1),"per launch MB",round((fetch+write)/n/1e6,1))
+json.dump(out,open(f"{R}/gpurun_out/traffic_{TAG}.json","w"),indent=1)
+PY
+cat $(find $R/gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1) | head -8 | cut -c1-200
+cp gpurun_out/traffic_$TAG.json profiles/traffic_latest.json
+timeout 900 python bench.py $ARGS 2>&1 | tail -1 > gpurun_out/bench_$TAG.json; python3 -c "
+import json;d=json.load(open('gpurun_out/bench_$TAG.json'));print(d['value'],d['ms_per_step'],d['roofline_path_frac']);print(d['cpu_baseline']);print(d['roofline']);print(d['kernels_isolated'])"

@@ -183,13 +183,13 @@ def test_oneslab(zd, oracle, ps, opk):
     assert abs(got["density_variance"] - ref["density_variance"]) <= TOL * ref["density_variance"]
 
 
-@pytest.mark.parametrize("world,R,plt", [(2, 1, False), (4, 2, False), (2, 2, True)])
+@pytest.mark.parametrize("world,R,plt", [(2, 1, False), (4, 2, False), (2, 4, False), (2, 2, True)])
 def test_multirank_layout_on_one_gpu(zd, oracle, ps, opk, world, R, plt):
     """the N>1 data path with the REAL kernels: `world` rank plans share this GPU, the all-to-all is
     emulated by chunk copies (chunk d of rank s's send buffer -> chunk s of rank d's receive buffer,
     i.e. all_to_all_single semantics); results must equal the single-process oracle."""
     import torch
-    n = 64
+    n = 64 if R < 4 else 128  # the folded z FFT needs N/R >= 32
     eig = oracle.synthetic_eigenmodes(32) if plt else None
     kw = dict(qPLT=1, qPLTrescale=1, PLT_target_z=5.0, f_cluster=0.97) if plt else {}
     fmt = "RVdoubleZel"
@@ -200,7 +200,8 @@ def test_multirank_layout_on_one_gpu(zd, oracle, ps, opk, world, R, plt):
     Zq = plans[0].local_planes
     dt = zd.RECORD_DTYPES[fmt]
     rec = np.zeros((n, n * n), dtype=dt)
-    for residue in range(R):
+    assert plans[0].R == R
+    for residue in range(plans[0].passes):  # R, or R/2 when the packed ZA store carries two residues per pass
         send = [torch.zeros(nb, dtype=torch.uint8, device="cuda") for _ in range(world)]
         recv = [torch.zeros(nb, dtype=torch.uint8, device="cuda") for _ in range(world)]
         for r in range(world):
@@ -231,6 +232,31 @@ def test_multirank_layout_on_one_gpu(zd, oracle, ps, opk, world, R, plt):
     assert _rel(md, ref["max_disp"]) < TOL
     for p in plans:
         p.close()
+
+
+@pytest.mark.parametrize("plt", [False, True])
+def test_packed_store_matches_reference_arrays(zd, oracle, ps, monkeypatch, plt):
+    """without ZD_qdensity the density field is not transformed (3 packed arrays; ZA: two residues per pass;
+    density_variance from sum |D|^2): records and statistics equal those of the reference's 2 / 4 arrays"""
+    n = 128
+    eig = oracle.synthetic_eigenmodes(32) if plt else None
+    kw = dict(qPLT=1, qPLTrescale=1, PLT_target_z=5.0, f_cluster=0.97) if plt else {}
+    p = zd.make_params(n, icformat="RVdoubleZel", stream_factor=4, **kw)
+    plan = zd.Plan(p, ps, eig=eig)
+    assert plan.narray == 3 and plan.plane_step == (1 if plt else 2) and plan.passes == (4 if plt else 2)
+    plan.close()
+    a = zd.generate(p, ps, eig=eig)
+    monkeypatch.setenv("ZD_NO_PACK", "1")
+    plan = zd.Plan(p, ps, eig=eig)
+    assert plan.narray == (4 if plt else 2) and plan.plane_step == 1 and plan.passes == 4
+    plan.close()
+    b = zd.generate(p, ps, eig=eig)
+    assert sorted(a["planes_seen"]) == list(range(n)) == sorted(b["planes_seen"])
+    assert np.array_equal(a["records"]["ijk"], b["records"]["ijk"])
+    for f in ("d", "v"):
+        assert _rel(a["records"][f], b["records"][f]) < 1e-13
+    assert abs(a["density_variance"] - b["density_variance"]) < 1e-12 * b["density_variance"]
+    assert _rel(a["max_disp"], b["max_disp"]) < 1e-13
 
 
 def test_bench_pipeline_driver(zd, oracle, ps, opk):

@@ -70,7 +70,7 @@ SLAB_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c
 # every symbol include/zeldovich_hip.h declares (checked by tests/test_capi_symbols.py)
 EXPORTED_SYMBOLS = [
     "zd_generate", "zd_choose_stream_factor", "zd_plan_create", "zd_plan_destroy", "zd_plan_narray",
-    "zd_plan_stream_factor", "zd_plan_record_size", "zd_plan_exchange_bytes", "zd_plan_local_planes",
+    "zd_plan_stream_factor", "zd_plan_passes", "zd_plan_plane_step", "zd_plan_record_size", "zd_plan_exchange_bytes", "zd_plan_local_planes",
     "zd_plan_plane_z", "zd_plan_stage_z", "zd_plan_stage_y", "zd_plan_stage_x", "zd_plan_stats",
     "zd_params_from_file", "zd_pk_create_from_file", "zd_pk_create_powerlaw", "zd_pk_power",
     "zd_pk_sigmaR", "zd_pk_destroy", "zd_load_eigmodes", "zd_free", "zd_test_draws", "zd_test_modes",
@@ -102,7 +102,7 @@ def load_library():
     L.zd_plan_create.argtypes = [C.POINTER(ZdParams), C.POINTER(ZdPk), vp, i64, C.c_int, C.c_int, C.POINTER(vp)]
     L.zd_plan_destroy.argtypes = [vp]
     L.zd_plan_destroy.restype = None
-    for name in ("zd_plan_narray", "zd_plan_stream_factor", "zd_plan_record_size"):
+    for name in ("zd_plan_narray", "zd_plan_stream_factor", "zd_plan_record_size", "zd_plan_passes", "zd_plan_plane_step"):
         getattr(L, name).argtypes = [vp]
         getattr(L, name).restype = i32
     for name in ("zd_plan_exchange_bytes", "zd_plan_local_planes"):
@@ -290,6 +290,8 @@ class Plan:
         self.rank, self.nranks = rank, nranks
         self.narray = self.L.zd_plan_narray(h)
         self.R = self.L.zd_plan_stream_factor(h)
+        self.passes = self.L.zd_plan_passes(h)          # R, or R/2 when a pass carries two z-residues
+        self.plane_step = self.L.zd_plan_plane_step(h)  # stage_x plane ranges are multiples of it
         self.record_size = self.L.zd_plan_record_size(h)
         self.exchange_bytes = self.L.zd_plan_exchange_bytes(h)
         self.local_planes = self.L.zd_plan_local_planes(h)

@@ -110,6 +110,9 @@ struct zd_plan {
     zd_params p;
     int rank = 0, nranks = 1;
     int N = 0, half = 0, narray = 0, R = 1, L = 0, Hq = 0, Zq = 0;
+    int pack = zd::PACK_NONE;  // what the store holds (zd_device.h PACK_*)
+    int npass = 1, pstep = 1;  // passes per run; planes a store plane delivers (2 with PACK_ZAPAIR)
+    bool var_pending = true;   // packed stores: the next Z stage accumulates sum |D|^2
     zd::GenConst g;
     zd::GenJumps J;
     zd::JobList jobs;
@@ -191,13 +194,30 @@ zdpcg::Affine row_jump_full(long long drows) {  // 2*65536*drows draws
 
 extern "C" {
 
+// Packed stores (zd_device.h PACK_*): without ZD_qdensity the density field is not transformed.
+static int pack_mode(const zd_params *p, int R) {
+    if (getenv("ZD_NO_PACK")) return zd::PACK_NONE;
+    if (p->qdensity != 0 || p->f_NL != 0.) return zd::PACK_NONE;
+    if (p->qoneslab >= 0) return zd::PACK_NONE;  // density_variance is then the sum over that one slab (output.cpp:197)
+    if (p->ppd > 4096) return zd::PACK_NONE;  // the x pass of 3 arrays at PPD=8192 needs > 160 KB of LDS
+    if (p->qPLT) return zd::PACK_PLT3;
+    return R >= 2 ? zd::PACK_ZAPAIR : zd::PACK_NONE;
+}
+static int store_arrays(const zd_params *p, int R) {
+    if (pack_mode(p, R) != zd::PACK_NONE) return 3;
+    return p->qdensity == 2 ? 1 : (p->qPLT ? 4 : 2);
+}
+
 int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes) {
-    const int64_t N  = p->ppd;
-    const int narray = p->qdensity == 2 ? 1 : (p->qPLT ? 4 : 2);
-    for (int R = 1; N / R >= 32; R *= 2) {
+    const int64_t N = p->ppd;
+    // ZA without density: two residues share a pass (3 arrays of N/R planes < 2 arrays of 2N/R planes), so R = 2 is
+    // preferred over R = 1 whenever the z FFT is long enough
+    int R0 = 1;
+    if (!p->qPLT && pack_mode(p, 2) == zd::PACK_ZAPAIR && N / 2 >= 32 && (N / 2) % nranks == 0) R0 = 2;
+    for (int R = R0; N / R >= 32; R *= 2) {
         if ((N / R) % nranks) break;
         if (N / R > 4096) continue;  // z-FFT kernels exist up to length 4096
-        int64_t store = N * (N + store_row_pad(N)) * (N / R) / nranks * 16 * narray;
+        int64_t store = N * (N + store_row_pad(N)) * (N / R) / nranks * 16 * store_arrays(p, R);
         if (nranks > 1) store *= 2;  // separate send and receive buffers
         if (store <= budget_bytes) return R;
     }
@@ -244,6 +264,10 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
     pl->N       = (int) N;
     pl->half    = (int) (N / 2);
     pl->narray  = (phi_mode == 1 || p->qdensity == 2) ? 1 : (p->qPLT ? 4 : 2);  // zeldovich.cpp:871-876
+    if (phi_mode == 0 && phik == nullptr && pl->narray >= 2) pl->pack = pack_mode(p, R);
+    if (pl->pack != zd::PACK_NONE) pl->narray = 3;
+    pl->pstep   = pl->pack == zd::PACK_ZAPAIR ? 2 : 1;
+    pl->npass   = R / pl->pstep;
     pl->R       = R;
     pl->L       = (int) (N / R);
     pl->Hq      = pl->half / nranks;
@@ -417,18 +441,43 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
     PLCHECK(hipMemset(pl->d_red, 0, sizeof(zd::Reduce)));
 
     // ---- jobs of the z stage ----
-    pl->jobs.n = 0;
-    if (pl->narray == 1) {
-        pl->jobs.kind[pl->jobs.n++] = zd::JOB_DENS;
-    } else {
-        pl->jobs.kind[pl->jobs.n++] = zd::JOB_A_SELF;
-        pl->jobs.kind[pl->jobs.n++] = zd::JOB_A_TWIN;
-        pl->jobs.kind[pl->jobs.n++] = zd::JOB_B_SELF;
-        pl->jobs.kind[pl->jobs.n++] = zd::JOB_B_TWIN;
-        if (pl->narray == 4) {
-            pl->jobs.kind[pl->jobs.n++] = zd::JOB_C_BOTH;
-            pl->jobs.kind[pl->jobs.n++] = zd::JOB_D_SELF;
-            pl->jobs.kind[pl->jobs.n++] = zd::JOB_D_TWIN;
+    {
+        zd::JobList &jl = pl->jobs;
+        memset(&jl, 0, sizeof(jl));
+        jl.pack = pl->pack;
+        auto add = [&](int kind, int arr, int twin, int res) {
+            jl.kind[jl.n] = kind;
+            jl.arr[jl.n]  = arr;
+            jl.twin[jl.n] = twin;
+            jl.res[jl.n]  = res;
+            jl.n++;
+        };
+        if (pl->pack == zd::PACK_ZAPAIR) {  // (qy + i qz)_r0 | (qy + i qz)_r1 | qx_r0 + i qx_r1
+            add(zd::JOB_B_SELF, 0, 0, 0);
+            add(zd::JOB_B_TWIN, 0, 1, 0);
+            add(zd::JOB_B_SELF, 1, 0, 1);
+            add(zd::JOB_B_TWIN, 1, 1, 1);
+            add(zd::JOB_FX, 2, 0, 0);  // generator output slot 4 = X_self, slot 5 = X_twin input (k_gen/k_genf combine F_x(r0), F_x(r1))
+            add(zd::JOB_FX, 2, 1, 1);
+        } else if (pl->pack == zd::PACK_PLT3) {  // qx + i vx | qy + i qz | vy + i vz
+            add(zd::JOB_XV_SELF, 0, 0, 0);
+            add(zd::JOB_XV_TWIN, 0, 1, 0);
+            add(zd::JOB_B_SELF, 1, 0, 0);
+            add(zd::JOB_B_TWIN, 1, 1, 0);
+            add(zd::JOB_D_SELF, 2, 0, 0);
+            add(zd::JOB_D_TWIN, 2, 1, 0);
+        } else if (pl->narray == 1) {
+            add(zd::JOB_DENS, 0, 0, 0);
+        } else {
+            add(zd::JOB_A_SELF, 0, 0, 0);
+            add(zd::JOB_A_TWIN, 0, 1, 0);
+            add(zd::JOB_B_SELF, 1, 0, 0);
+            add(zd::JOB_B_TWIN, 1, 1, 0);
+            if (pl->narray == 4) {
+                add(zd::JOB_C_BOTH, 2, 0, 0);
+                add(zd::JOB_D_SELF, 3, 0, 0);
+                add(zd::JOB_D_TWIN, 3, 1, 0);
+            }
         }
     }
     // ---- block store layout (zd_device.h StoreLayout): chunks per peer rank, ~2 MB tiles inside ----
@@ -440,6 +489,7 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
     while ((1 << S.lHq) < pl->Hq) S.lHq++;
     S.narray = pl->narray;
     S.prune     = getenv("ZD_PRUNE") ? atoi(getenv("ZD_PRUNE")) : 7;  // bit 0 k_gen, 1 k_zfft, 2 k_yfft
+    S.nt = getenv("ZD_NT") ? atoi(getenv("ZD_NT")) : 0;
     if (phik) S.prune = 0;  // f_NL second pass: every mode carries power (the zero rule is bypassed)
     S.kmax      = g.kmax;
     S.fund2     = g.fundamental2;
@@ -479,6 +529,9 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
     pl->ec.qPLT     = p->qPLT;
     pl->ec.qdensity = p->qdensity;
     pl->ec.vnorm    = p->qPLT ? 1.0 : (sqrt(1. + 24 * p->f_cluster) - 1) * .25;  // output.cpp:78-82
+    pl->ec.pack     = pl->pack;
+    pl->ec.z_pair   = R / 2;
+    g.var_slots     = pl->d_red->sumsq;
 
     // ---- folded-input slabs (two, for the gen||zfft overlap): enough rows per launch to fill the chip ----
     {
@@ -551,14 +604,21 @@ int32_t zd_plan_record_size(const zd_plan *pl) { return pl->ec.recsize; }
 int64_t zd_plan_exchange_bytes(const zd_plan *pl) {
     return (int64_t) pl->S.chunk_rows * pl->S.pitch * pl->nranks * 16;
 }
-int64_t zd_plan_local_planes(const zd_plan *pl) { return pl->Zq; }
-int64_t zd_plan_plane_z(const zd_plan *pl, int residue, int64_t local_plane) {
-    return residue + (int64_t) pl->R * ((int64_t) pl->rank * pl->Zq + local_plane);
+int32_t zd_plan_passes(const zd_plan *pl) { return pl->npass; }
+int32_t zd_plan_plane_step(const zd_plan *pl) { return pl->pstep; }
+int64_t zd_plan_local_planes(const zd_plan *pl) { return (int64_t) pl->Zq * pl->pstep; }
+int64_t zd_plan_plane_z(const zd_plan *pl, int pass, int64_t local_plane) {
+    // PACK_ZAPAIR: store plane zl of pass p carries z-residues p (delivered plane 2 zl) and p + R/2 (plane 2 zl + 1)
+    const int64_t zl = local_plane / pl->pstep, which = local_plane % pl->pstep;
+    return (pass + which * (pl->R / 2)) + (int64_t) pl->R * ((int64_t) pl->rank * pl->Zq + zl);
 }
 
 int zd_plan_stage_z(zd_plan *pl, int residue, void *d_send, void *hip_stream) {
     hipStream_t st = (hipStream_t) hip_stream;
-    if (residue < 0 || residue >= pl->R) return 1;
+    if (residue < 0 || residue >= pl->npass) return 1;
+    const int residue2 = pl->pack == zd::PACK_ZAPAIR ? residue + pl->R / 2 : residue;
+    pl->g.accum_var = (pl->pack != zd::PACK_NONE && pl->var_pending) ? 1 : 0;  // once per run: every pass sees every mode
+    pl->var_pending = false;
     const int ky_first = pl->rank * pl->Hq;
     if (!pl->overlap) {
         HIPCHECK(hipMemsetAsync(pl->d_tilectr, 0, sizeof(unsigned) * pl->n_tilectr, st));
@@ -566,7 +626,7 @@ int zd_plan_stage_z(zd_plan *pl, int residue, void *d_send, void *hip_stream) {
         for (int r0 = 0; r0 < pl->Hq; r0 += pl->slab_rows, slab++) {
             const int nky = std::min(pl->slab_rows, pl->Hq - r0);
             tick(pl, ZD_K_GEN, st, true);
-            if (zd::launch_gen(pl->g, pl->J, pl->jobs, pl->S, ky_first + r0, nky, pl->L, residue, pl->d_twN, pl->d_Y[0],
+            if (zd::launch_gen(pl->g, pl->J, pl->jobs, pl->S, ky_first + r0, nky, pl->L, residue, residue2, pl->d_twN, pl->d_Y[0],
                                pl->d_tilectr + slab, pl->gen_max_wgs, st))
                 return 1;
             tick(pl, ZD_K_GEN, st, false);
@@ -589,7 +649,7 @@ int zd_plan_stage_z(zd_plan *pl, int residue, void *d_send, void *hip_stream) {
         // k_gen may overwrite Y[b] only after the k_zfft that read it (two slabs ago) has finished
         if (slab >= 2) HIPCHECK(hipStreamWaitEvent(pl->s_gen, pl->ev_fft[b], 0));
         tick(pl, ZD_K_GEN, pl->s_gen, true);
-        if (zd::launch_gen(pl->g, pl->J, pl->jobs, pl->S, ky_first + r0, nky, pl->L, residue, pl->d_twN, pl->d_Y[b],
+        if (zd::launch_gen(pl->g, pl->J, pl->jobs, pl->S, ky_first + r0, nky, pl->L, residue, residue2, pl->d_twN, pl->d_Y[b],
                            pl->d_tilectr + slab, pl->gen_max_wgs, pl->s_gen))
             return 1;
         tick(pl, ZD_K_GEN, pl->s_gen, false);
@@ -618,10 +678,16 @@ int zd_plan_stage_y(zd_plan *pl, void *d_recv, void *hip_stream) {
 int zd_plan_stage_x(zd_plan *pl, int residue, const void *d_recv, int64_t plane0, int64_t nplanes, void *d_records,
                     float *d_density, void *hip_stream) {
     hipStream_t st = (hipStream_t) hip_stream;
-    if (plane0 < 0 || nplanes < 1 || plane0 + nplanes > pl->Zq) return 1;
+    const int ps = pl->pstep;
+    if (plane0 < 0 || nplanes < 1 || plane0 + nplanes > (int64_t) pl->Zq * ps || plane0 % ps || nplanes % ps) {
+        fprintf(stderr, "zeldovich_hip: stage_x plane range [%lld, +%lld) invalid (multiples of %d inside [0, %lld))\n",
+                (long long) plane0, (long long) nplanes, ps, (long long) pl->Zq * ps);
+        return 1;
+    }
+    if (d_density && pl->pack != zd::PACK_NONE) return 1;  // packed stores carry no density field
     const int z_first = (int) zd_plan_plane_z(pl, residue, plane0);
     tick(pl, ZD_K_XFFT, st, true);
-    if (zd::launch_xfft(pl->S, pl->ec, pl->d_twN, d_recv, (int) plane0, (int) nplanes, z_first, pl->R, d_records,
+    if (zd::launch_xfft(pl->S, pl->ec, pl->d_twN, d_recv, (int) (plane0 / ps), (int) (nplanes / ps), z_first, pl->R, d_records,
                         d_density, pl->d_red, st))
         return 1;
     tick(pl, ZD_K_XFFT, st, false);
@@ -637,7 +703,9 @@ int zd_plan_stats(zd_plan *pl, zd_stats *out) {
     memset(out, 0, sizeof(*out));
     double ss = 0;
     for (int i = 0; i < zd::NSLOT; i++) ss += h.sumsq[i];
-    out->density_variance = ss;
+    // packed stores: ss = sum over the full k cube of |D(k)|^2 (generator); sum_x delta^2 = N^3 sum_k |D|^2
+    out->density_variance = pl->pack != zd::PACK_NONE ? ss * (double) pl->N * (double) pl->N * (double) pl->N : ss;
+    pl->var_pending       = true;
     for (int j = 0; j < 3; j++) {
         double mp = 0, mn = 0;
         for (int i = 0; i < zd::NSLOT; i++) {
@@ -726,7 +794,8 @@ int zd_generate(const zd_params *p_in, const zd_pk *pk, const double *eig, int64
         hipFree(d_phik);
         return 1;
     }
-    const int R = pl->R, Zq = pl->Zq, recsize = pl->ec.recsize;
+    const int R = pl->R, recsize = pl->ec.recsize, npass = pl->npass, pstep = pl->pstep;
+    const int64_t Pp = zd_plan_local_planes(pl);  // planes delivered per pass
     const bool want_rec = pl->narray >= 2, want_dens = p.qdensity != 0;
 
     void *d_store = nullptr, *d_rec = nullptr;
@@ -735,9 +804,10 @@ int zd_generate(const zd_params *p_in, const zd_pk *pk, const double *eig, int64
     float *h_dens = nullptr;
     int rc = 1;
     hipStream_t st = 0;
-    // planes handed over per x-stage launch
+    // planes handed over per x-stage launch (a multiple of the plane step)
     const int64_t plane_b = N * N * (int64_t) (want_rec ? recsize : 0) + (want_dens ? N * N * 4 : 0);
-    int chunk = (int) std::max<int64_t>(1, std::min<int64_t>(Zq, ((int64_t) 512 << 20) / std::max<int64_t>(plane_b, 1)));
+    int chunk = (int) std::max<int64_t>(1, std::min<int64_t>(Pp, ((int64_t) 512 << 20) / std::max<int64_t>(plane_b, 1)));
+    chunk     = std::max(pstep, chunk / pstep * pstep);
     std::chrono::steady_clock::time_point t0;
     do {
         if (hipMalloc(&d_store, (size_t) zd_plan_exchange_bytes(pl)) != hipSuccess) {
@@ -753,19 +823,26 @@ int zd_generate(const zd_params *p_in, const zd_pk *pk, const double *eig, int64
         if (hipDeviceSynchronize() != hipSuccess) break;
         t0 = std::chrono::steady_clock::now();
         bool fail = false;
-        for (int r = 0; r < R && !fail; r++) {
-            if (p.qoneslab >= 0 && (p.qoneslab % R) != r) continue;  // zeldovich.cpp:669: only that slab is wanted
+        // ZD_qoneslab (zeldovich.cpp:669): only that slab is wanted -> only its pass and its store plane are finished
+        int want_pass = -1;
+        int64_t want_plane = -1;
+        if (p.qoneslab >= 0) {
+            const int r = p.qoneslab % R;
+            want_pass   = r % npass;
+            want_plane  = (int64_t) (p.qoneslab / R) * pstep + r / npass;
+        }
+        for (int r = 0; r < npass && !fail; r++) {
+            if (want_pass >= 0 && r != want_pass) continue;
             if (zd_plan_stage_z(pl, r, d_store, st) || zd_plan_stage_y(pl, d_store, st)) {
                 fail = true;
                 break;
             }
-            for (int64_t pl0 = 0; pl0 < Zq && !fail; pl0 += chunk) {
-                int64_t first = pl0, n = std::min<int64_t>(chunk, Zq - pl0);
-                if (p.qoneslab >= 0) {
-                    const int64_t want = (p.qoneslab - r) / R;
-                    if (want < pl0 || want >= pl0 + n) continue;
-                    first = want;
-                    n     = 1;
+            for (int64_t pl0 = 0; pl0 < Pp && !fail; pl0 += chunk) {
+                int64_t first = pl0, n = std::min<int64_t>(chunk, Pp - pl0);
+                if (want_plane >= 0) {
+                    if (want_plane < pl0 || want_plane >= pl0 + n) continue;
+                    first = want_plane / pstep * pstep;
+                    n     = pstep;
                 }
                 if (zd_plan_stage_x(pl, r, d_store, first, n, d_rec, d_dens, st)) {
                     fail = true;
@@ -776,6 +853,7 @@ int zd_generate(const zd_params *p_in, const zd_pk *pk, const double *eig, int64
                     if (want_dens && hipMemcpyAsync(h_dens, d_dens, (size_t) n * N * N * 4, hipMemcpyDeviceToHost, st) != hipSuccess) fail = true;
                     if (hipStreamSynchronize(st) != hipSuccess) fail = true;
                     for (int64_t i = 0; i < n && !fail; i++) {
+                        if (want_plane >= 0 && first + i != want_plane) continue;
                         const int64_t z = zd_plan_plane_z(pl, r, first + i);
                         if (cb(user, z, N * N, want_rec ? h_rec + (size_t) i * N * N * recsize : nullptr,
                                want_dens ? h_dens + (size_t) i * N * N : nullptr))
@@ -906,7 +984,7 @@ int zd_test_yfft_variant(int32_t n, int32_t variant, int32_t narray, int32_t npl
         lBk = (lt + 1) / 2; lBz = lt - lBk;
         while ((1 << lBz) > nplanes) lBz--;
     }
-    S.lBk = lBk; S.lBz = lBz; S.rows_outer = 0; S.one_block = 0; S.pitch = n; S.prune = 0; S.kmax = 0; S.fund2 = 0; S.k2_cutoff = 0;
+    S.lBk = lBk; S.lBz = lBz; S.rows_outer = 0; S.one_block = 0; S.pitch = n; S.prune = 0; S.nt = 0; S.kmax = 0; S.fund2 = 0; S.k2_cutoff = 0;
     S.a_rows = (1 << lBk) << lBz;
     S.zb_rows = S.a_rows * narray;
     S.kb_rows = S.zb_rows * (nplanes >> lBz);

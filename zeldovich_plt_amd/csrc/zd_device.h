@@ -42,6 +42,9 @@ struct GenConst {
     const zdfft::cplx *phik;  // non-NULL: D = phik[ky][z][x] * M (second pass; the zero rule is bypassed)
     const double *fnl_M;      // M by integer kx^2+ky^2+kz^2
     double fnl_pre, fnl_den, primordial_norm, n_s;
+    // sum |D|^2 (Parseval form of output.cpp:197 density_variance) for the packed stores: NSLOT replicated slots
+    double *var_slots;
+    int accum_var;
     // RNG: state at the start of each ky plane (== reference v2rng[ky], power_spectrum.cpp:30-36)
     const zdpcg::u128 *row_state;
 };
@@ -84,6 +87,7 @@ struct StoreLayout {
     // identically zero after the z FFT; it is neither written by the z stage nor read by the y stage
     int prune, kmax;
     double fund2, k2_cutoff;
+    int nt;  // tuning (ZD_NT): non-temporal accesses, bit 0 y loads, 1 y stores, 2 x loads, 3 z stores, 4 z loads
 };
 
 // true iff every mode of column (kx, ky) (signed wavenumbers) is zero for all kz
@@ -136,15 +140,33 @@ enum JobKind {
     JOB_C_BOTH  = 4,  // (-f sx) D -> array 2 self; -conj -> array 2 twin
     JOB_D_SELF  = 5,  // f(-sz + i sy) D           -> array 3
     JOB_D_TWIN  = 6,  // conj FFT[f(sz + i sy) D]  -> array 3 twin
-    JOB_DENS    = 7   // D -> array 0 self; conj -> twin         (qdensity == 2)
+    JOB_DENS    = 7,  // D -> array 0 self; conj -> twin         (qdensity == 2)
+    // packed stores (no density field, see PACK_*):
+    JOB_XV_SELF = 8,  // (i - f) sx D = F_x + i f F_x            (qx + i vx)
+    JOB_XV_TWIN = 9,  // conj FFT[(i + f) sx D]
+    JOB_FX      = 10  // i sx D of one residue; the two residues of a pass are combined into qx_r0 + i qx_r1
 };
+// What the store holds.  The reference always transforms the density (Re of its array 0) although only
+// ZD_qdensity writes it out and only its sum of squares is reported; without ZD_qdensity the density is not
+// transformed here (sum delta^2 = N^3 sum |D(k)|^2 comes from the generator), which leaves 3 (ZA) / 6 (PLT) real
+// fields = 1.5 / 3 packed complex arrays instead of 2 / 4:
+//   PACK_PLT3    arrays  qx + i vx | qy + i qz | vy + i vz
+//   PACK_ZAPAIR  one pass carries TWO z-residues r0, r1 (the y/x transforms act per plane, so fields of
+//                different planes pack into one complex array):  (qy + i qz)_r0 | (qy + i qz)_r1 | qx_r0 + i qx_r1
+enum { PACK_NONE = 0, PACK_ZAPAIR = 1, PACK_PLT3 = 2 };
 struct JobList {
     int n;
+    int pack;
     int kind[8];
+    int arr[8];   // destination array of the store
+    int twin[8];  // 1: output goes (conjugated) to row N-ky, column N-kx only
+    int res[8];   // PACK_ZAPAIR: which residue of the pass (0/1) the job's fold uses
 };
 
 struct EpiConst {
     int N, narray, icformat, recsize;
+    int pack;      // PACK_*: field order of the store
+    int z_pair;    // PACK_ZAPAIR: z distance between the two planes a store plane carries (R/2)
     int qPLT, qdensity;
     double vnorm;  // (sqrt(1+24 f_cluster)-1)/4 without PLT, 1 with   output.cpp:78-82
 };

@@ -23,6 +23,25 @@ using zdpcg::u128;
 
 __constant__ zdpcg::BitTable c_bits;
 
+// streaming (non-temporal) 16-byte accesses for data that is touched once per pass: tuning knob ZD_NT
+typedef double zd_d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cplx ld_stream(const cplx *p, bool nt) {
+    if (nt) {
+        const zd_d2v q = __builtin_nontemporal_load(reinterpret_cast<const zd_d2v *>(p));
+        return cplx{q.x, q.y};
+    }
+    return *p;
+}
+__device__ __forceinline__ void st_stream(cplx *p, cplx v, bool nt) {
+    if (nt) {
+        zd_d2v q;
+        q.x = v.x;
+        q.y = v.y;
+        __builtin_nontemporal_store(q, reinterpret_cast<zd_d2v *>(p));
+    } else
+        *p = v;
+}
+
 extern "C" int zdk_upload_bit_table(const zdpcg::BitTable *host) {
     return (int) hipMemcpyToSymbol(HIP_SYMBOL(c_bits), host, sizeof(zdpcg::BitTable));
 }
@@ -228,8 +247,8 @@ __global__ void k_pk_table(GenConst g, int n, double2 *__restrict__ tab) {
 // grid: (ceil(N/GEN_BX), L/ZR, nky)  block: GEN_BX
 template <int ZR, int NJ, bool PLT, bool PLAW>
 __global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, JobList jobs, StoreLayout S, int zW, int ky0,
-                                                int nky, int L, int residue, const cplx *__restrict__ twN,
-                                                cplx *__restrict__ Y) {
+                                                int nky, int L, int residue, int residue2,
+                                                const cplx *__restrict__ twN, cplx *__restrict__ Y) {
     const int N = g.N, half = g.half, R = N / L;
     const int x   = blockIdx.x * GEN_BX + threadIdx.x;
     const int k20 = blockIdx.y * ZR;
@@ -253,6 +272,7 @@ __global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, JobList 
         eax = eig_axis(g, eig_index_x(g, kx));
         eay = eig_axis(g, ky);
     }
+    double vsum = 0.0;  // sum |D|^2 over the positions this thread visits (packed stores only)
     u128 s = 0;
     if (ky != 0) {  // state one step ahead of the first mode's counter
         const int kz0 = k20 > half ? k20 - N : k20;  // k20 > N/2 only happens when R = 1
@@ -363,9 +383,17 @@ __global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, JobList 
                 sy = -sy;
                 sz = -sz;
             }
+            vsum += dr * dr + di * di;
+            double d2r = dr, d2i = di;  // PACK_ZAPAIR: the same mode folded for the second residue of the pass
             if (R > 1) {  // W_R^{k1 r}
                 const cplx w = twN[(int) (((long long) k1 * residue * L) & (N - 1))];
                 const double a = dr * w.x - di * w.y, b = dr * w.y + di * w.x;
+                if (jobs.pack == PACK_ZAPAIR) {
+                    const cplx w2 = twN[(int) (((long long) k1 * residue2 * L) & (N - 1))];
+                    const double a2 = dr * w2.x - di * w2.y, b2 = dr * w2.y + di * w2.x;
+                    d2r = a2;
+                    d2i = b2;
+                }
                 dr = a;
                 di = b;
             }
@@ -380,25 +408,51 @@ __global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, JobList 
                     case JOB_C_BOTH: cr = -f * sx; ci = 0.0; break;
                     case JOB_D_SELF: cr = -f * sz; ci = f * sy; break;
                     case JOB_D_TWIN: cr = f * sz; ci = f * sy; break;
+                    case JOB_XV_SELF: cr = -f * sx; ci = sx; break;
+                    case JOB_XV_TWIN: cr = f * sx; ci = sx; break;
+                    case JOB_FX: cr = 0.0; ci = sx; break;
                     default: cr = 1.0; ci = 0.0; break;
                 }
-                accr[j] += cr * dr - ci * di;
-                acci[j] += cr * di + ci * dr;
+                const double ur = jobs.res[j] ? d2r : dr, ui = jobs.res[j] ? d2i : di;
+                accr[j] += cr * ur - ci * ui;
+                acci[j] += cr * ui + ci * ur;
             }
         }
-        double pr = 1.0, pi = 0.0;  // W_N^{k2 r}
+        double pr = 1.0, pi = 0.0, qr = 1.0, qi = 0.0;  // W_N^{k2 r}, and the same for the second residue
         if (R > 1) {
             const cplx w = twN[(int) (((long long) k2 * residue) & (N - 1))];
             pr = w.x;
             pi = w.y;
+            const cplx w2 = twN[(int) (((long long) k2 * residue2) & (N - 1))];
+            qr = w2.x;
+            qi = w2.y;
+        }
+        double outr[NJ], outi[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const double tr = jobs.res[j] ? qr : pr, ti = jobs.res[j] ? qi : pi;
+            outr[j] = accr[j] * tr - acci[j] * ti;
+            outi[j] = accr[j] * ti + acci[j] * tr;
+        }
+        if constexpr (NJ == 6) {
+            if (jobs.pack == PACK_ZAPAIR) {  // jobs 4, 5 hold F_x of residue 0 / 1: X_self = F0 + i F1, X_twin input = F0 - i F1
+                const double f0r = outr[4], f0i = outi[4], f1r = outr[5], f1i = outi[5];
+                outr[4] = f0r - f1i;
+                outi[4] = f0i + f1r;
+                outr[5] = f0r + f1i;
+                outi[5] = f0i - f1r;
+            }
         }
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
             // a slab holds < 2^31 elements (1.5 GB / 16 B): 32-bit index arithmetic
             const unsigned idx = (unsigned) (((j * nky + kyl) * L + k2) * N + x);
-            Y[idx] = cplx{accr[j] * pr - acci[j] * pi, accr[j] * pi + acci[j] * pr};
+            Y[idx] = cplx{outr[j], outi[j]};
         }
     }
+    // full-space sum: a half-space row ky >= 1 stands for itself and its Hermitian twin.  (Per-thread atomics: with
+    // k_genf active this kernel only sees the ky = 0 plane.)
+    if (g.accum_var && vsum != 0.0) atomicAdd(&g.var_slots[(threadIdx.x + 5 * blockIdx.y) % NSLOT], vsum * (ky != 0 ? 2.0 : 1.0));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -562,7 +616,7 @@ __device__ __forceinline__ double genf_power(const GenConst &g, const double *T,
 //     where S0 = sum D w, SE = sum (fund/k^2) D w, SZ = sum kz (fund/k^2) D w   (3 accumulators for the
 //     4 ZA jobs; PLT keeps 7 because its eigenvectors differ mode by mode).
 // grid: (ceil(N/GEN_BX), L/ZR, nrows)  block: GEN_BX          row kyl = kyl0 + blockIdx.z of the slab
-enum { GENF_DENS = 0, GENF_ZA = 1, GENF_PLT = 2 };
+enum { GENF_DENS = 0, GENF_ZA = 1, GENF_PLT = 2, GENF_ZAP = 3 /* PACK_ZAPAIR */, GENF_PLTN = 4 /* PACK_PLT3 */ };
 
 __device__ __forceinline__ void cmac(double &ar, double &ai, double c, double dr, double di) {
     ar = fma(c, dr, ar);
@@ -570,15 +624,19 @@ __device__ __forceinline__ void cmac(double &ar, double &ai, double c, double dr
 }
 
 template <int ZR, int KIND, bool PLAW>
-__device__ __forceinline__ void genf_tile(const GenConst &g, const GenJumps &J, const StoreLayout &S, const double *T, int zW,
-                                          int ky0, int kyl, int nky, int L, int residue, int bx, int by,
-                                          const cplx *__restrict__ twN, cplx *__restrict__ Y) {
-    constexpr int NACC = KIND == GENF_DENS ? 1 : (KIND == GENF_ZA ? 3 : 7);
+__device__ __forceinline__ double genf_tile(const GenConst &g, const GenJumps &J, const StoreLayout &S, const double *T, int zW,
+                                            int ky0, int kyl, int nky, int L, int residue, int residue2, int bx, int by,
+                                            const cplx *__restrict__ twN, cplx *__restrict__ Y) {
+    // field sums per k2:  DENS {S0}  ZA {S0, SE, SZ}  PLT {S0, X, Y, Z, fX, fY, fZ}  ZAP {SE, SZ}(r0), {SE, SZ}(r1)
+    //                     PLTN {X, Y, Z, fX, fY, fZ}
+    constexpr int NACC = KIND == GENF_DENS ? 1 : KIND == GENF_ZA ? 3 : KIND == GENF_PLT ? 7 : KIND == GENF_ZAP ? 4 : 6;
+    constexpr bool IS_PLT = KIND == GENF_PLT || KIND == GENF_PLTN;
+    double vsum = 0.0;  // sum |D|^2 of this thread's modes (packed stores: density_variance by Parseval)
     const int N = g.N, half = g.half, R = N / L;
     const int x   = bx * GEN_BX + threadIdx.x;
     const int k20 = by * ZR;
     const int ky  = ky0 + kyl;  // >= 1
-    if (x >= N) return;
+    if (x >= N) return 0.0;
     const int kx = x > half ? x - N : x;
     if (S.prune & 1) {  // see k_gen: skip columns whose k_zfft tiles (self and shifted twin) are all zero
         bool all_zero = true;
@@ -587,12 +645,12 @@ __device__ __forceinline__ void genf_tile(const GenConst &g, const GenJumps &J, 
             const int xi = (xt0 + i) & (N - 1);
             all_zero = all_zero && column_is_zero(S, xi > half ? xi - N : xi, ky);
         }
-        if (all_zero) return;
+        if (all_zero) return 0.0;
     }
     const int kxy2  = kx * kx + ky * ky;
     const bool dead = (kx < 0 ? -kx : kx) == g.kmax || ky == g.kmax;  // zeldovich.cpp:350
     EigAxis eax = {0, 0, 0.0}, eay = {0, 0, 0.0};
-    if constexpr (KIND == GENF_PLT) {
+    if constexpr (IS_PLT) {
         eax = eig_axis(g, eig_index_x(g, kx));
         eay = eig_axis(g, ky);
     }
@@ -647,21 +705,40 @@ __device__ __forceinline__ void genf_tile(const GenConst &g, const GenJumps &J, 
             double sn, cs;
             sincos_u01(u64_to_double(r2 + 1ULL), T, sn, cs);  // m = 0 (theta = 1) lands on direction 0 like theta = 0
             double dr = amp * cs, di = amp * sn;
+            vsum = fma(dr, dr, fma(di, di, vsum));
+            double d2r = dr, d2i = di;  // ZAP: the mode folded for the second residue of the pass
             if (R > 1) {  // W_R^{k1 r}
                 const cplx w = twN[(int) (((long long) k1 * residue * L) & (N - 1))];
                 const double a = dr * w.x - di * w.y, b = dr * w.y + di * w.x;
+                if constexpr (KIND == GENF_ZAP) {
+                    const cplx w2 = twN[(int) (((long long) k1 * residue2 * L) & (N - 1))];
+                    d2r = dr * w2.x - di * w2.y;
+                    d2i = dr * w2.y + di * w2.x;
+                }
                 dr = a;
                 di = b;
             }
-            accr[0] += dr;
-            acci[0] += di;
+            if constexpr (KIND == GENF_DENS || KIND == GENF_ZA || KIND == GENF_PLT) {
+                accr[0] += dr;
+                acci[0] += di;
+            }
             if constexpr (KIND == GENF_ZA) {
                 const double q  = g.fundamental * ik2;
                 const double er = q * dr, ei = q * di;
                 accr[1] += er;
                 acci[1] += ei;
                 cmac(accr[2], acci[2], (double) kz, er, ei);
-            } else if constexpr (KIND == GENF_PLT) {
+            } else if constexpr (KIND == GENF_ZAP) {
+                const double q  = g.fundamental * ik2, dkz = (double) kz;
+                const double er = q * dr, ei = q * di, e2r = q * d2r, e2i = q * d2i;
+                accr[0] += er;
+                acci[0] += ei;
+                cmac(accr[1], acci[1], dkz, er, ei);
+                accr[2] += e2r;
+                acci[2] += e2i;
+                cmac(accr[3], acci[3], dkz, e2r, e2i);
+            } else if constexpr (IS_PLT) {
+                constexpr int B = KIND == GENF_PLT ? 1 : 0;  // index of the X sum
                 double e[4];
                 const EigAxis eaz = eig_axis(g, eig_index_z(g, kz));
                 get_eigenmode_dev(g, kx, ky, kz, eax, eay, eaz, e);
@@ -671,27 +748,54 @@ __device__ __forceinline__ void genf_tile(const GenConst &g, const GenJumps &J, 
                 const double sx = rescale * e[0] * g.fundamental * ik2;
                 const double sy = rescale * e[1] * g.fundamental * ik2;
                 const double sz = rescale * e[2] * g.fundamental * ik2;
-                cmac(accr[1], acci[1], sx, dr, di);
-                cmac(accr[2], acci[2], sy, dr, di);
-                cmac(accr[3], acci[3], sz, dr, di);
-                cmac(accr[4], acci[4], f * sx, dr, di);
-                cmac(accr[5], acci[5], f * sy, dr, di);
-                cmac(accr[6], acci[6], f * sz, dr, di);
+                cmac(accr[B + 0], acci[B + 0], sx, dr, di);
+                cmac(accr[B + 1], acci[B + 1], sy, dr, di);
+                cmac(accr[B + 2], acci[B + 2], sz, dr, di);
+                cmac(accr[B + 3], acci[B + 3], f * sx, dr, di);
+                cmac(accr[B + 4], acci[B + 4], f * sy, dr, di);
+                cmac(accr[B + 5], acci[B + 5], f * sz, dr, di);
             }
         }
         // ---- job inputs from the field sums, times W_N^{k2 r}; Y[((j*nky + kyl)*L + k2)*N + x] ----
-        double pr = 1.0, pi = 0.0;
+        double pr = 1.0, pi = 0.0, qr = 1.0, qi = 0.0;
         if (R > 1) {
             const cplx w = twN[(int) (((long long) k2 * residue) & (N - 1))];
             pr = w.x;
             pi = w.y;
+            if constexpr (KIND == GENF_ZAP) {
+                const cplx w2 = twN[(int) (((long long) k2 * residue2) & (N - 1))];
+                qr = w2.x;
+                qi = w2.y;
+            }
         }
         auto put = [&](int j, double vr, double vi) {
             const unsigned idx = (unsigned) (((j * nky + kyl) * L + k2) * N + x);
-            Y[idx] = cplx{vr * pr - vi * pi, vr * pi + vi * pr};
+            Y[idx] = cplx{vr, vi};
         };
+        auto putp = [&](int j, double vr, double vi) { put(j, vr * pr - vi * pi, vr * pi + vi * pr); };
         if constexpr (KIND == GENF_DENS) {
-            put(0, accr[0], acci[0]);
+            putp(0, accr[0], acci[0]);
+        } else if constexpr (KIND == GENF_ZAP) {
+            const double dkx = (double) kx, dky = (double) ky;
+            // residue r0: B jobs and F_x = i kx SE, all times W_N^{k2 r0}
+            const double y0r = dky * accr[0], y0i = dky * acci[0], y1r = dky * accr[2], y1i = dky * acci[2];
+            putp(0, -accr[1] - y0i, -acci[1] + y0r);  // JOB_B_SELF (r0)
+            putp(1, accr[1] - y0i, acci[1] + y0r);    // JOB_B_TWIN (r0)
+            auto putq = [&](int j, double vr, double vi) { put(j, vr * qr - vi * qi, vr * qi + vi * qr); };
+            putq(2, -accr[3] - y1i, -acci[3] + y1r);  // JOB_B_SELF (r1)
+            putq(3, accr[3] - y1i, acci[3] + y1r);    // JOB_B_TWIN (r1)
+            const double g0r = -dkx * acci[0], g0i = dkx * accr[0], g1r = -dkx * acci[2], g1i = dkx * accr[2];
+            const double f0r = g0r * pr - g0i * pi, f0i = g0r * pi + g0i * pr;  // F_x(r0) W_N^{k2 r0}
+            const double f1r = g1r * qr - g1i * qi, f1i = g1r * qi + g1i * qr;  // F_x(r1) W_N^{k2 r1}
+            put(4, f0r - f1i, f0i + f1r);  // X_self       = F_x(r0) + i F_x(r1)
+            put(5, f0r + f1i, f0i - f1r);  // X_twin input = F_x(r0) - i F_x(r1)
+        } else if constexpr (KIND == GENF_PLTN) {
+            putp(0, -acci[0] - accr[3], accr[0] - acci[3]);   // JOB_XV_SELF (i - f) s_x D = i X - fX
+            putp(1, -acci[0] + accr[3], accr[0] + acci[3]);   // JOB_XV_TWIN (i + f) s_x D = i X + fX
+            putp(2, -accr[2] - acci[1], -acci[2] + accr[1]);  // JOB_B_SELF  -Z + i Y
+            putp(3, accr[2] - acci[1], acci[2] + accr[1]);    // JOB_B_TWIN   Z + i Y
+            putp(4, -accr[5] - acci[4], -acci[5] + accr[4]);  // JOB_D_SELF  -fZ + i fY
+            putp(5, accr[5] - acci[4], acci[5] + accr[4]);    // JOB_D_TWIN   fZ + i fY
         } else {
             double xr, xi, yr, yi, zr, zi2;
             if constexpr (KIND == GENF_ZA) {
@@ -703,17 +807,18 @@ __device__ __forceinline__ void genf_tile(const GenConst &g, const GenJumps &J, 
                 yr = accr[2]; yi = acci[2];
                 zr = accr[3]; zi2 = acci[3];
             }
-            put(0, accr[0] - xr, acci[0] - xi);   // JOB_A_SELF  (1 - s_x) D
-            put(1, accr[0] + xr, acci[0] + xi);   // JOB_A_TWIN  (1 + s_x) D
-            put(2, -zr - yi, -zi2 + yr);          // JOB_B_SELF  (-s_z + i s_y) D
-            put(3, zr - yi, zi2 + yr);            // JOB_B_TWIN  ( s_z + i s_y) D
+            putp(0, accr[0] - xr, acci[0] - xi);   // JOB_A_SELF  (1 - s_x) D
+            putp(1, accr[0] + xr, acci[0] + xi);   // JOB_A_TWIN  (1 + s_x) D
+            putp(2, -zr - yi, -zi2 + yr);          // JOB_B_SELF  (-s_z + i s_y) D
+            putp(3, zr - yi, zi2 + yr);            // JOB_B_TWIN  ( s_z + i s_y) D
             if constexpr (KIND == GENF_PLT) {
-                put(4, -accr[4], -acci[4]);                        // JOB_C_BOTH  -f s_x D
-                put(5, -accr[6] - acci[5], -acci[6] + accr[5]);    // JOB_D_SELF  f(-s_z + i s_y) D
-                put(6, accr[6] - acci[5], acci[6] + accr[5]);      // JOB_D_TWIN  f( s_z + i s_y) D
+                putp(4, -accr[4], -acci[4]);                        // JOB_C_BOTH  -f s_x D
+                putp(5, -accr[6] - acci[5], -acci[6] + accr[5]);    // JOB_D_SELF  f(-s_z + i s_y) D
+                putp(6, accr[6] - acci[5], acci[6] + accr[5]);      // JOB_D_TWIN  f( s_z + i s_y) D
             }
         }
     }
+    return vsum;
 }
 
 // Persistent launch: `gridDim.x` workgroups pull tiles (x block, k2 chunk, row) from an atomic counter.  The grid
@@ -721,14 +826,16 @@ __device__ __forceinline__ void genf_tile(const GenConst &g, const GenJumps &J, 
 // slab, running on the second stream, always finds registers and LDS next to the generator's waves.
 template <int ZR, int KIND, bool PLAW>
 __global__ __launch_bounds__(GEN_BX) void k_genf(GenConst g, GenJumps J, StoreLayout S, int zW, int ky0, int kyl0, int nky,
-                                                 int nrows, int L, int residue, const cplx *__restrict__ twN,
-                                                 cplx *__restrict__ Y, unsigned *__restrict__ tile_ctr) {
+                                                 int nrows, int L, int residue, int residue2,
+                                                 const cplx *__restrict__ twN, cplx *__restrict__ Y,
+                                                 unsigned *__restrict__ tile_ctr) {
     extern __shared__ __attribute__((aligned(16))) double T[];  // GenfTab image (+ one slot for the tile index)
     for (int i = threadIdx.x; i < g.genf_n / 2; i += GEN_BX)
         reinterpret_cast<double2 *>(T)[i] = reinterpret_cast<const double2 *>(g.genf_tab)[i];
     unsigned *slot = reinterpret_cast<unsigned *>(T + g.genf_n);
     const int gx = (g.N + GEN_BX - 1) / GEN_BX, gy = L / ZR;
     const unsigned ntiles = (unsigned) (gx * gy * nrows);
+    double vsum = 0.0;
     for (;;) {
         __syncthreads();  // table image complete / previous tile index consumed
         if (threadIdx.x == 0) *slot = atomicAdd(tile_ctr, 1u);
@@ -736,7 +843,12 @@ __global__ __launch_bounds__(GEN_BX) void k_genf(GenConst g, GenJumps J, StoreLa
         const unsigned tile = *slot;
         if (tile >= ntiles) break;
         const int bx = tile % gx, by = (tile / gx) % gy, bz = tile / (gx * gy);
-        genf_tile<ZR, KIND, PLAW>(g, J, S, T, zW, ky0, kyl0 + bz, nky, L, residue, bx, by, twN, Y);
+        vsum += genf_tile<ZR, KIND, PLAW>(g, J, S, T, zW, ky0, kyl0 + bz, nky, L, residue, residue2, bx, by, twN, Y);
+    }
+    if (g.accum_var) {  // every lane is back here: wave sum, one atomic per wave; rows ky >= 1 stand for their twins too
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vsum += __shfl_down(vsum, off);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&g.var_slots[(blockIdx.x * (GEN_BX / 64) + (threadIdx.x >> 6)) % NSLOT], 2.0 * vsum);
     }
 }
 
@@ -789,7 +901,7 @@ __global__ __launch_bounds__(W *L / E) void k_zfft(JobList jobs, StoreLayout S, 
     const int kyl = blockIdx.y;
     const int ky  = ky0 + kyl;
     const int kind = jobs.kind[blockIdx.z];
-    const bool twin_only = (kind == JOB_A_TWIN || kind == JOB_B_TWIN || kind == JOB_D_TWIN);
+    const bool twin_only = jobs.twin[blockIdx.z] != 0;
     // twin columns are stored mirrored (column N-x): shifting the tile of twin-only jobs by one column
     // makes the mirrored run start on a tile boundary, i.e. whole 128-byte lines instead of 112 + 16 B
     const int x = (blockIdx.x * W + w + (twin_only ? 1 : 0)) & (N - 1);
@@ -805,17 +917,14 @@ __global__ __launch_bounds__(W *L / E) void k_zfft(JobList jobs, StoreLayout S, 
 #pragma unroll
     for (int e = 0; e < E; e++) {
         cplx v = cplx{1.0 + e, 2.0 * t};
-        if (!(S.prune & 8)) v = *reinterpret_cast<const cplx *>(src + ((unsigned) (t + T * e) * rb + xb));  // bit 3: ablation
+        if (!(S.prune & 8)) v = ld_stream(reinterpret_cast<const cplx *>(src + ((unsigned) (t + T * e) * rb + xb)), S.nt & 16);  // bit 3: ablation
         re[e] = v.x;
         im[e] = v.y;
     }
     zdfft::fft_line<PL, LDS>(re, im, t, w, lds, twL);
     if ((S.prune & 16) && re[0] != 123.456) return;  // bit 4: tuning ablation (skip stores)
 
-    const int arr = (kind == JOB_A_SELF || kind == JOB_A_TWIN || kind == JOB_DENS) ? 0
-                    : (kind == JOB_B_SELF || kind == JOB_B_TWIN)                    ? 1
-                    : (kind == JOB_C_BOTH)                                          ? 2
-                                                                                    : 3;
+    const int arr = jobs.arr[blockIdx.z];
     const bool st_self = !twin_only;
     const bool st_twin = (ky != 0) && (twin_only || kind == JOB_C_BOTH || kind == JOB_DENS);
     const double sgr = (kind == JOB_C_BOTH) ? -1.0 : 1.0, sgi = (kind == JOB_C_BOTH) ? 1.0 : -1.0;  // -conj / conj
@@ -830,8 +939,8 @@ __global__ __launch_bounds__(W *L / E) void k_zfft(JobList jobs, StoreLayout S, 
         const int z2  = t2 + T * e;
         const int dst = z2 >> lZq, zl = z2 & (Zq - 1);  // Zq = 2^lZq
         const int row = store_row(S, dst, zl, arr, loc_self);
-        if (st_self) out[(long long) row * S.pitch + x] = cplx{re[e], im[e]};
-        if (st_twin) out[(long long) (row + drow) * S.pitch + xt] = cplx{sgr * re[e], sgi * im[e]};
+        if (st_self) st_stream(out + ((long long) row * S.pitch + x), cplx{re[e], im[e]}, S.nt & 8);
+        if (st_twin) st_stream(out + ((long long) (row + drow) * S.pitch + xt), cplx{sgr * re[e], sgi * im[e]}, S.nt & 8);
     }
 }
 
@@ -865,7 +974,7 @@ __global__ __launch_bounds__(W *N / E, MINW) void k_yfft(StoreLayout S, const cp
             const bool skip = (ky == N / 2) || ((S.prune & 4) && column_is_zero(S, kxs, ky > N / 2 ? ky - N : ky));
             const unsigned slot = ky < N / 2 ? ky : N / 2 + (N - ky);
             cplx v = cplx{0.0, 0.0};
-            if (!skip) v = *reinterpret_cast<const cplx *>(base + (slot * pb + xb));
+            if (!skip) v = ld_stream(reinterpret_cast<const cplx *>(base + (slot * pb + xb)), S.nt & 1);
             re[e] = v.x;
             im[e] = v.y;
         }
@@ -878,7 +987,7 @@ __global__ __launch_bounds__(W *N / E, MINW) void k_yfft(StoreLayout S, const cp
         for (int e = 0; e < E; e++) {
             const int y = t2 + T * e;
             const unsigned slot = y < N / 2 ? y : (y == N / 2 ? N / 2 : N / 2 + (N - y));
-            *reinterpret_cast<cplx *>(base + (slot * pb + xb)) = cplx{re[e], im[e]};
+            st_stream(reinterpret_cast<cplx *>(base + (slot * pb + xb)), cplx{re[e], im[e]}, S.nt & 2);
         }
     } else {
         cplx *base = data + x;
@@ -912,6 +1021,51 @@ constexpr int XFFT_NH(int N, int NA, int ROWS) {
 
 __device__ __forceinline__ unsigned long long dbits(double v) { return (unsigned long long) __double_as_longlong(v); }
 
+// one particle record (include/output.h:19-49; WriteParticlesSlab output.cpp:128-141: i = z, j = y, k = x,
+// displ = (qz, qy, qx), vel = (vz, vy, vx)); pos/vel are in this code's x, y, z order
+__device__ __forceinline__ void emit_record(char *__restrict__ records, long long pidx, const EpiConst &ec, int z, int yy,
+                                            int xx, const double (&pos)[3], const double (&vel)[3]) {
+    char *rec = records + pidx * ec.recsize;
+    const unsigned int ij = ((unsigned int) z & 0xffffu) | (((unsigned int) yy & 0xffffu) << 16);
+    const unsigned int k0 = ((unsigned int) xx & 0xffffu);
+    if (ec.icformat == 1) {  // RVZel: u16 i,j,k + pad, float displ[3], vel[3]
+        uint4 q0, q1;
+        q0.x = ij;
+        q0.y = k0;
+        q0.z = __float_as_uint((float) pos[2]);
+        q0.w = __float_as_uint((float) pos[1]);
+        q1.x = __float_as_uint((float) pos[0]);
+        q1.y = __float_as_uint((float) vel[2]);
+        q1.z = __float_as_uint((float) vel[1]);
+        q1.w = __float_as_uint((float) vel[0]);
+        reinterpret_cast<uint4 *>(rec)[0] = q0;
+        reinterpret_cast<uint4 *>(rec)[1] = q1;
+    } else if (ec.icformat == 2) {  // RVdoubleZel: 56 B
+        unsigned long long *r8 = reinterpret_cast<unsigned long long *>(rec);
+        r8[0] = (unsigned long long) ij | ((unsigned long long) k0 << 32);
+        double *d = reinterpret_cast<double *>(rec + 8);
+        d[0] = pos[2];
+        d[1] = pos[1];
+        d[2] = pos[0];
+        d[3] = vel[2];
+        d[4] = vel[1];
+        d[5] = vel[0];
+    } else if (ec.icformat == 0) {  // Zeldovich: u16 i,j,k + pad, double displ[3]
+        double2 q0, q1;
+        q0.x = __longlong_as_double((long long) ((unsigned long long) ij | ((unsigned long long) k0 << 32)));
+        q0.y = pos[2];
+        q1.x = pos[1];
+        q1.y = pos[0];
+        reinterpret_cast<double2 *>(rec)[0] = q0;
+        reinterpret_cast<double2 *>(rec)[1] = q1;
+    } else {  // ZelSimple: float displ[3]
+        float *d = reinterpret_cast<float *>(rec);
+        d[0] = (float) pos[2];
+        d[1] = (float) pos[1];
+        d[2] = (float) pos[0];
+    }
+}
+
 template <int N, int E, int NA, int ROWS>
 __global__ __launch_bounds__(ROWS *NA *N / E, (ROWS * NA * N / E == 512 ? 4 : 1)) void k_xfft(StoreLayout S, EpiConst ec, const cplx *__restrict__ tw,
                                                          const cplx *__restrict__ data, int plane0,
@@ -930,7 +1084,7 @@ __global__ __launch_bounds__(ROWS *NA *N / E, (ROWS * NA * N / E == 512 ? 4 : 1)
     double re[E], im[E];
 #pragma unroll
     for (int e = 0; e < E; e++) {
-        const cplx v = src[t + T * e];
+        const cplx v = ld_stream(src + t + T * e, S.nt & 4);
         re[e] = v.x;
         im[e] = v.y;
     }
@@ -956,73 +1110,54 @@ __global__ __launch_bounds__(ROWS *NA *N / E, (ROWS * NA * N / E == 512 ? 4 : 1)
             fld[(row * 2 * NA + 2 * a + 1) * NXH + xl] = im[e];
         }
         __syncthreads();
+        // (Writing 32-byte records by lane pairs — 16 B per lane, 1 KB of consecutive bytes per wave — was measured
+        // 15 % SLOWER than one lane per record: the extra LDS reads cost more than the store pattern gains.)
         for (int i = threadIdx.x; i < ROWS * NXH; i += NT) {
             const int r = i / NXH, xl = i - r * NXH, xx = xl + h * NXH;
             const int yy = blockIdx.x * ROWS + r;
             const double *f = fld + (r * 2 * NA) * NXH + xl;
-            const double dens = f[0];
-            ssq += dens * dens;
-            const long long pidx = plane_rec0 + (long long) yy * N + xx;
-            if (density) density[pidx] = (float) dens;
-            if (NA >= 2) {
-                double pos[3], vel[3];
-                pos[0] = f[1 * NXH];
-                pos[1] = f[2 * NXH];
-                pos[2] = f[3 * NXH];
-                if (NA == 4) {
-                    vel[0] = f[5 * NXH] * ec.vnorm;
-                    vel[1] = f[6 * NXH] * ec.vnorm;
-                    vel[2] = f[7 * NXH] * ec.vnorm;
-                } else {
-                    vel[0] = pos[0] * ec.vnorm;
-                    vel[1] = pos[1] * ec.vnorm;
-                    vel[2] = pos[2] * ec.vnorm;
-                }
+            auto finish = [&](long long pidx, int zz, const double (&pos)[3], const double (&vel)[3]) {
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
                     mp[j] = fmax(mp[j], pos[j]);
                     mn[j] = fmax(mn[j], -pos[j]);
                 }
-                if (records) {
-                    char *rec = records + pidx * ec.recsize;
-                    const unsigned int ij = ((unsigned int) z & 0xffffu) | (((unsigned int) yy & 0xffffu) << 16);
-                    const unsigned int k0 = ((unsigned int) xx & 0xffffu);
-                    if (ec.icformat == 1) {  // RVZel: u16 i,j,k + pad, float displ[3], vel[3]
-                        uint4 q0, q1;
-                        q0.x = ij;
-                        q0.y = k0;
-                        q0.z = __float_as_uint((float) pos[2]);
-                        q0.w = __float_as_uint((float) pos[1]);
-                        q1.x = __float_as_uint((float) pos[0]);
-                        q1.y = __float_as_uint((float) vel[2]);
-                        q1.z = __float_as_uint((float) vel[1]);
-                        q1.w = __float_as_uint((float) vel[0]);
-                        reinterpret_cast<uint4 *>(rec)[0] = q0;
-                        reinterpret_cast<uint4 *>(rec)[1] = q1;
-                    } else if (ec.icformat == 2) {  // RVdoubleZel: 56 B
-                        unsigned long long *r8 = reinterpret_cast<unsigned long long *>(rec);
-                        r8[0] = (unsigned long long) ij | ((unsigned long long) k0 << 32);
-                        double *d = reinterpret_cast<double *>(rec + 8);
-                        d[0] = pos[2];
-                        d[1] = pos[1];
-                        d[2] = pos[0];
-                        d[3] = vel[2];
-                        d[4] = vel[1];
-                        d[5] = vel[0];
-                    } else if (ec.icformat == 0) {  // Zeldovich: u16 i,j,k + pad, double displ[3]
-                        double2 q0, q1;
-                        q0.x = __longlong_as_double((long long) ((unsigned long long) ij | ((unsigned long long) k0 << 32)));
-                        q0.y = pos[2];
-                        q1.x = pos[1];
-                        q1.y = pos[0];
-                        reinterpret_cast<double2 *>(rec)[0] = q0;
-                        reinterpret_cast<double2 *>(rec)[1] = q1;
-                    } else {  // ZelSimple: float displ[3]
-                        float *d = reinterpret_cast<float *>(rec);
-                        d[0] = (float) pos[2];
-                        d[1] = (float) pos[1];
-                        d[2] = (float) pos[0];
+                if (records) emit_record(records, pidx, ec, zz, yy, xx, pos, vel);
+            };
+            if constexpr (NA == 3) {
+                // packed stores (zd_device.h PACK_*): no density field
+                if (ec.pack == PACK_PLT3) {  // qx + i vx | qy + i qz | vy + i vz
+                    const double pos[3] = {f[0], f[2 * NXH], f[3 * NXH]};
+                    const double vel[3] = {f[1 * NXH] * ec.vnorm, f[4 * NXH] * ec.vnorm, f[5 * NXH] * ec.vnorm};
+                    finish(plane_rec0 + (long long) yy * N + xx, z, pos, vel);
+                } else {  // PACK_ZAPAIR: (qy + i qz)_r0 | (qy + i qz)_r1 | qx_r0 + i qx_r1 -> two planes, z and z + z_pair
+#pragma unroll
+                    for (int w2 = 0; w2 < 2; w2++) {
+                        const double pos[3] = {f[(4 + w2) * NXH], f[(2 * w2) * NXH], f[(2 * w2 + 1) * NXH]};
+                        const double vel[3] = {pos[0] * ec.vnorm, pos[1] * ec.vnorm, pos[2] * ec.vnorm};
+                        finish(2 * plane_rec0 + (long long) w2 * N * N + (long long) yy * N + xx, z + w2 * ec.z_pair, pos, vel);
                     }
+                }
+            } else {
+                const double dens = f[0];
+                const long long pidx = plane_rec0 + (long long) yy * N + xx;
+                ssq += dens * dens;
+                if (density) density[pidx] = (float) dens;
+                if (NA >= 2) {
+                    double pos[3], vel[3];
+                    pos[0] = f[1 * NXH];
+                    pos[1] = f[2 * NXH];
+                    pos[2] = f[3 * NXH];
+                    if (NA == 4) {
+                        vel[0] = f[5 * NXH] * ec.vnorm;
+                        vel[1] = f[6 * NXH] * ec.vnorm;
+                        vel[2] = f[7 * NXH] * ec.vnorm;
+                    } else {
+                        vel[0] = pos[0] * ec.vnorm;
+                        vel[1] = pos[1] * ec.vnorm;
+                        vel[2] = pos[2] * ec.vnorm;
+                    }
+                    finish(pidx, z, pos, vel);
                 }
             }
         }
@@ -1059,7 +1194,7 @@ __global__ __launch_bounds__(ROWS *NA *N / E, (ROWS * NA * N / E == 512 ? 4 : 1)
             }
         }
         const int slot = (blockIdx.x + blockIdx.y * 7) % NSLOT;
-        atomicAdd(&red->sumsq[slot], tot);
+        if (NA != 3) atomicAdd(&red->sumsq[slot], tot);
         if (NA >= 2) {
             for (int j = 0; j < 3; j++) {
                 atomicMax(&red->maxpos[j][slot], dbits(fabs(a3[j])));
@@ -1238,73 +1373,91 @@ int zfft_tile_width(int L);
 
 template <int NJ, bool PLT, bool PLAW>
 static int launch_gen_t(const GenConst &g, const GenJumps &J, const JobList &jobs, const StoreLayout &S, int ky0, int nky,
-                        int nrows, int L, int residue, const void *twN, void *Y, hipStream_t st) {
+                        int nrows, int L, int residue, int residue2, const void *twN, void *Y, hipStream_t st) {
     const int N = g.N;
     dim3 grid((N + GEN_BX - 1) / GEN_BX, L / GEN_ZR, nrows), block(GEN_BX);
     hipLaunchKernelGGL((k_gen<GEN_ZR, NJ, PLT, PLAW>), grid, block, 0, st, g, J, jobs, S, zfft_tile_width(L), ky0, nky,
-                       L, residue, (const cplx *) twN, (cplx *) Y);
+                       L, residue, residue2, (const cplx *) twN, (cplx *) Y);
     ZD_LAUNCH_CHECK();
     return 0;
 }
 template <int KIND, bool PLAW>
 static int launch_genf_t(const GenConst &g, const GenJumps &J, const StoreLayout &S, int ky0, int kyl0, int nky, int nrows,
-                         int L, int residue, const void *twN, void *Y, unsigned *tile_ctr, int max_wgs, hipStream_t st) {
+                         int L, int residue, int residue2, const void *twN, void *Y, unsigned *tile_ctr, int max_wgs,
+                         hipStream_t st) {
     const int N = g.N;
     const long long ntiles = (long long) ((N + GEN_BX - 1) / GEN_BX) * (L / GEN_ZR) * nrows;
     dim3 grid((unsigned) std::min<long long>(ntiles, max_wgs)), block(GEN_BX);
     hipLaunchKernelGGL((k_genf<GEN_ZR, KIND, PLAW>), grid, block, sizeof(double) * (size_t) (g.genf_n + 2), st, g, J, S,
-                       zfft_tile_width(L), ky0, kyl0, nky, nrows, L, residue, (const cplx *) twN, (cplx *) Y, tile_ctr);
+                       zfft_tile_width(L), ky0, kyl0, nky, nrows, L, residue, residue2, (const cplx *) twN, (cplx *) Y,
+                       tile_ctr);
     ZD_LAUNCH_CHECK();
     return 0;
 }
 template <int KIND>
 static int launch_genf_k(const GenConst &g, const GenJumps &J, const StoreLayout &S, int ky0, int kyl0, int nky, int nrows,
-                         int L, int residue, const void *twN, void *Y, unsigned *tile_ctr, int max_wgs, hipStream_t st) {
+                         int L, int residue, int residue2, const void *twN, void *Y, unsigned *tile_ctr, int max_wgs,
+                         hipStream_t st) {
     if (g.is_powerlaw)
-        return launch_genf_t<KIND, true>(g, J, S, ky0, kyl0, nky, nrows, L, residue, twN, Y, tile_ctr, max_wgs, st);
-    return launch_genf_t<KIND, false>(g, J, S, ky0, kyl0, nky, nrows, L, residue, twN, Y, tile_ctr, max_wgs, st);
+        return launch_genf_t<KIND, true>(g, J, S, ky0, kyl0, nky, nrows, L, residue, residue2, twN, Y, tile_ctr, max_wgs, st);
+    return launch_genf_t<KIND, false>(g, J, S, ky0, kyl0, nky, nrows, L, residue, residue2, twN, Y, tile_ctr, max_wgs, st);
 }
-// the job order k_genf writes (= the order zd_plan builds)
-static bool genf_jobs_ok(const JobList &jobs) {
-    static const int za[7] = {JOB_A_SELF, JOB_A_TWIN, JOB_B_SELF, JOB_B_TWIN, JOB_C_BOTH, JOB_D_SELF, JOB_D_TWIN};
-    if (jobs.n == 1) return jobs.kind[0] == JOB_DENS;
-    if (jobs.n != 4 && jobs.n != 7) return false;
-    for (int j = 0; j < jobs.n; j++)
-        if (jobs.kind[j] != za[j]) return false;
-    return true;
+// the job orders k_genf writes (= the orders zd_plan builds)
+static int genf_kind(const JobList &jobs, bool plt) {
+    static const int std7[7] = {JOB_A_SELF, JOB_A_TWIN, JOB_B_SELF, JOB_B_TWIN, JOB_C_BOTH, JOB_D_SELF, JOB_D_TWIN};
+    static const int zap[6]  = {JOB_B_SELF, JOB_B_TWIN, JOB_B_SELF, JOB_B_TWIN, JOB_FX, JOB_FX};
+    static const int pln[6]  = {JOB_XV_SELF, JOB_XV_TWIN, JOB_B_SELF, JOB_B_TWIN, JOB_D_SELF, JOB_D_TWIN};
+    auto same = [&](const int *ref, int n) {
+        if (jobs.n != n) return false;
+        for (int j = 0; j < n; j++)
+            if (jobs.kind[j] != ref[j]) return false;
+        return true;
+    };
+    if (jobs.n == 1 && jobs.kind[0] == JOB_DENS) return GENF_DENS;
+    if (jobs.pack == PACK_ZAPAIR) return (!plt && same(zap, 6)) ? GENF_ZAP : -1;
+    if (jobs.pack == PACK_PLT3) return (plt && same(pln, 6)) ? GENF_PLTN : -1;
+    if (!plt && same(std7, 4)) return GENF_ZA;
+    if (plt && same(std7, 7)) return GENF_PLT;
+    return -1;
 }
 int launch_gen(const GenConst &g, const GenJumps &J, const JobList &jobs, const StoreLayout &S, int ky0, int nky, int L,
-               int residue, const void *twN, void *Y, unsigned *tile_ctr, int max_wgs, hipStream_t st) {
+               int residue, int residue2, const void *twN, void *Y, unsigned *tile_ctr, int max_wgs, hipStream_t st) {
     if (L % GEN_ZR != 0) return 2;
     static const bool force_general = getenv("ZD_GEN_GENERAL") != nullptr;
     // rows ky >= 1 of a production run go through k_genf; everything else through the general kernel
-    const bool fast = g.genf_tab && tile_ctr && !g.phik && !g.gen_phi && !g.qonemode && !(g.ablate & 15) && !force_general && genf_jobs_ok(jobs)
-                      && (jobs.n == 1 || (jobs.n == 7) == (g.qPLT != 0));
+    const int kind = genf_kind(jobs, g.qPLT != 0);
+    const bool fast = g.genf_tab && tile_ctr && !g.phik && !g.gen_phi && !g.qonemode && !(g.ablate & 15) && !force_general
+                      && kind >= 0;
     int general_rows = nky;
     if (fast) {
         general_rows = ky0 == 0 ? 1 : 0;  // the ky = 0 plane (conjugate "loser" modes) stays with k_gen
         const int kyl0 = general_rows, nrows = nky - general_rows;
         if (nrows > 0) {
-            int rc;
-            if (jobs.n == 1)
-                rc = launch_genf_k<GENF_DENS>(g, J, S, ky0, kyl0, nky, nrows, L, residue, twN, Y, tile_ctr, max_wgs, st);
-            else if (jobs.n == 4)
-                rc = launch_genf_k<GENF_ZA>(g, J, S, ky0, kyl0, nky, nrows, L, residue, twN, Y, tile_ctr, max_wgs, st);
-            else
-                rc = launch_genf_k<GENF_PLT>(g, J, S, ky0, kyl0, nky, nrows, L, residue, twN, Y, tile_ctr, max_wgs, st);
+            int rc = 2;
+#define FCASE(K) \
+    if (kind == K) rc = launch_genf_k<K>(g, J, S, ky0, kyl0, nky, nrows, L, residue, residue2, twN, Y, tile_ctr, max_wgs, st);
+            FCASE(GENF_DENS)
+            FCASE(GENF_ZA)
+            FCASE(GENF_PLT)
+            FCASE(GENF_ZAP)
+            FCASE(GENF_PLTN)
+#undef FCASE
             if (rc) return rc;
         }
         if (general_rows == 0) return 0;
     }
 #define GCASE(nj, plt)                                                                                                      \
     if (jobs.n == nj && (g.qPLT != 0) == plt) {                                                                             \
-        if (g.is_powerlaw) return launch_gen_t<nj, plt, true>(g, J, jobs, S, ky0, nky, general_rows, L, residue, twN, Y, st); \
-        return launch_gen_t<nj, plt, false>(g, J, jobs, S, ky0, nky, general_rows, L, residue, twN, Y, st);                    \
+        if (g.is_powerlaw)                                                                                                  \
+            return launch_gen_t<nj, plt, true>(g, J, jobs, S, ky0, nky, general_rows, L, residue, residue2, twN, Y, st);      \
+        return launch_gen_t<nj, plt, false>(g, J, jobs, S, ky0, nky, general_rows, L, residue, residue2, twN, Y, st);         \
     }
     GCASE(1, false)
     GCASE(1, true)
     GCASE(4, false)
     GCASE(7, true)
+    GCASE(6, false)
+    GCASE(6, true)
 #undef GCASE
     return 2;
 }
@@ -1436,21 +1589,22 @@ static int launch_xfft_t(const StoreLayout &S, const EpiConst &ec, const void *t
 }
 int launch_xfft(const StoreLayout &S, const EpiConst &ec, const void *tw, const void *data, int plane0, int nplanes,
                 int z_first, int z_step, void *records, float *density, Reduce *red, hipStream_t st) {
-#define XCASE(n, e, rows1, rows2, rows4)                                                                              \
+#define XCASE(n, e, rows1, rows2, rows4, rows3)                                                                       \
     case n:                                                                                                           \
         if (S.narray == 1) return launch_xfft_t<n, e, 1, rows1>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, density, red, st); \
         if (S.narray == 2) return launch_xfft_t<n, e, 2, rows2>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, density, red, st); \
+        if (S.narray == 3) return launch_xfft_t<n, e, 3, rows3>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, density, red, st); \
         return launch_xfft_t<n, e, 4, rows4>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, density, red, st);
     switch (S.N) {
-        XCASE(32, 16, 32, 32, 16)
-        XCASE(64, 16, 32, 32, 16)
-        XCASE(128, 16, 32, 16, 8)
-        XCASE(256, 16, 16, 8, 4)
-        XCASE(512, 16, 8, 4, 2)
-        XCASE(1024, 16, 4, 2, 1)
-        XCASE(2048, 16, 2, 1, 1)
-        XCASE(4096, 16, 1, 1, 1)
-        XCASE(8192, 16, 1, 1, 1)
+        XCASE(32, 16, 32, 32, 16, 16)
+        XCASE(64, 16, 32, 32, 16, 16)
+        XCASE(128, 16, 32, 16, 8, 8)
+        XCASE(256, 16, 16, 8, 4, 4)
+        XCASE(512, 16, 8, 4, 2, 2)
+        XCASE(1024, 16, 4, 2, 1, 2)
+        XCASE(2048, 16, 2, 1, 1, 1)
+        XCASE(4096, 16, 1, 1, 1, 1)
+        XCASE(8192, 16, 1, 1, 1, 1)
     }
 #undef XCASE
     fprintf(stderr, "zeldovich_hip: unsupported PPD %d\n", S.N);

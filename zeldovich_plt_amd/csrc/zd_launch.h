@@ -9,8 +9,9 @@ constexpr int GEN_ZR = 16;   // z rows walked by one generator thread
 
 // tile_ctr: zeroed device counter for this launch (k_genf pulls its tiles from it; NULL -> general kernel only);
 // max_wgs: size of k_genf's persistent grid
+// residue2: second z-residue of the pass (PACK_ZAPAIR only)
 int launch_gen(const GenConst &g, const GenJumps &J, const JobList &jobs, const StoreLayout &S, int ky0, int nky, int L,
-               int residue, const void *twN, void *Y, unsigned *tile_ctr, int max_wgs, hipStream_t st);
+               int residue, int residue2, const void *twN, void *Y, unsigned *tile_ctr, int max_wgs, hipStream_t st);
 int launch_pk_table(const GenConst &g, int n, void *tab, hipStream_t st);
 int launch_test_modes(const GenConst &g, long long n, const int *kxyz, uint64_t *draws, double *D, hipStream_t st);
 int launch_zfft(int L, const JobList &jobs, const StoreLayout &S, int ky0, int kyloc0, int nky, int Zq, const void *Y,

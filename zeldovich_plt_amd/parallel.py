@@ -7,7 +7,7 @@ XY stage; the block exchange between the two is ONE all-to-all per pass (RCCL ov
 torch.distributed; gloo in the CPU tests).  No other collective is on the data path.
 
 `engine` is anything with the staged interface of include/zeldovich_hip.h:
-    engine.R, engine.local_planes, engine.exchange_bytes, engine.record_size
+    engine.R, engine.passes, engine.plane_step, engine.local_planes, engine.exchange_bytes, engine.record_size
     engine.stage_z(residue, send), engine.stage_y(recv), engine.stage_x(residue, recv, p0, n, out)
     engine.plane_z(residue, local_plane)
 On a GPU it is `HipEngine` (zeldovich_plt_amd.api.Plan on torch device buffers).
@@ -22,6 +22,8 @@ class HipEngine:
         self.plan = plan
         self.ppd = ppd
         self.R = plan.R
+        self.passes = plan.passes
+        self.plane_step = plan.plane_step
         self.local_planes = plan.local_planes
         self.exchange_bytes = plan.exchange_bytes
         self.record_size = plan.record_size
@@ -59,7 +61,8 @@ class SlabPipeline:
         self.send = torch.empty(nel, dtype=torch.float64, device=device)
         self.recv = torch.empty(nel, dtype=torch.float64, device=device) if world > 1 else self.send
         plane_b = ppd * ppd * max(engine.record_size, 1)
-        self.chunk = int(max(1, min(engine.local_planes, chunk_bytes // plane_b)))
+        step = getattr(engine, "plane_step", 1)  # a store plane may deliver two z planes (packed ZA store)
+        self.chunk = int(max(step, min(engine.local_planes, chunk_bytes // plane_b) // step * step))
         self.ring = torch.empty(self.chunk * plane_b, dtype=torch.uint8, device=device)
 
     def exchange(self):
@@ -81,5 +84,5 @@ class SlabPipeline:
                 consume([e.plane_z(residue, p0 + i) for i in range(n)], self.ring)
 
     def run(self, consume=None):
-        for r in range(self.e.R):
+        for r in range(getattr(self.e, "passes", self.e.R)):
             self.run_pass(r, consume)
