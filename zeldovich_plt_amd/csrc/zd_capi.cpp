@@ -132,10 +132,18 @@ struct zd_plan {
     zd::Reduce *d_red = nullptr;
     // folded FFT inputs of one slab of half-space rows: Y[job][row][k2][x]; double-buffered so that
     // k_gen (VALU-bound) of slab s+1 runs beside k_zfft (HBM-bound) of slab s on a second stream
-    cplx *d_Y[2] = {nullptr, nullptr};
-    int slab_rows = 0;  // rows generated per k_gen launch
+    // folded FFT inputs: a ring of slabs Y[job][row][k2][x].  Two slabs suffice for the gen || zfft overlap inside a
+    // pass; whatever HBM the store leaves free holds more of them, so that the (VALU-bound) generator of pass p+1
+    // runs ahead on its own stream while the (HBM-bound) y and x passes of pass p are still working
+    std::vector<cplx *> d_Y;
+    std::vector<hipEvent_t> ev_gen, ev_fft;
+    int slab_rows = 0;        // rows generated per k_gen launch
+    long long next_g = 0;     // running slab number: slab g lives in ring slot g % K
+    int ahead_pass = -1;      // pass whose first `ahead_n` slabs (numbers ahead_g0...) are already being generated
+    long long ahead_g0 = 0;
+    int ahead_n = 0;
     hipStream_t s_gen = nullptr, s_fft = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_gen[2] = {nullptr, nullptr}, ev_fft[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr;
     bool overlap = true;
     // timing
     std::vector<EventPair> events;
@@ -177,6 +185,8 @@ void collect_events(zd_plan *pl) {
 // the y pass pile onto a few HBM channels (PPD=4096: k_yfft 1.20 s -> 0.92 s with the pad, PPD=2048: 100 -> 93 ms).
 // 384 B of padding per row de-aliases them (128 B and 640 B do as well; 256 B does not at PPD=2048) for 0.6-5 % more memory.
 int store_row_pad(int64_t N) { return N >= 512 ? 24 : 0; }
+
+bool p_oneslab_off(const zd_plan *pl) { return pl->p.qoneslab < 0; }  // ZD_qoneslab runs finish a single pass
 
 int64_t y_bytes_per_row(const zd_plan *pl) { return (int64_t) pl->jobs.n * pl->L * pl->N * 16; }
 
@@ -553,15 +563,35 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
             int per_cu = pl->overlap ? 3 : 6;
             if (const char *env = getenv("ZD_GEN_WGS")) per_cu = atoi(env);
             pl->gen_max_wgs = std::max(1, per_cu) * std::max(1, ncu);
-            pl->n_tilectr   = pl->Hq / rows + 2;
+            pl->n_tilectr   = 2 * (pl->Hq / rows) + 2;  // per pass parity: the next pass's generator may already run
             PLCHECK(hipMalloc((void **) &pl->d_tilectr, sizeof(unsigned) * pl->n_tilectr));
         }
-        for (int i = 0; i < (pl->overlap ? 2 : 1); i++) PLCHECK(hipMalloc((void **) &pl->d_Y[i], (size_t) row_b * rows));
+        // ring size: 1 slab without the overlap, else 2 + what the store (allocated by the caller afterwards) leaves
+        int K = 1;
+        if (pl->overlap) {
+            K = 2;
+            const int nslab = pl->Hq / rows;
+            // Measured (PPD=4096 ZA, 60 slabs ahead): no gain — the generator's resident workgroups take LDS and
+            // registers from k_yfft (128 KB LDS per workgroup at PPD=4096), which slows down by what the z stage gains.
+            // The larger ring therefore stays an experiment: ZD_Y_AHEAD=1 sizes it from free HBM, ZD_Y_SLABS=n fixes it.
+            if (getenv("ZD_Y_AHEAD") && pl->npass > 1 && nslab > 2) {
+                size_t free_b = 0, total_b = 0;
+                hipMemGetInfo(&free_b, &total_b);
+                const int64_t reserve = zd_plan_exchange_bytes(pl) * (nranks > 1 ? 2 : 1) + ((int64_t) 8 << 30);
+                const int64_t spare   = (int64_t) free_b - reserve;
+                if (spare > 0) K = (int) std::max<int64_t>(2, std::min<int64_t>(nslab, spare / (row_b * rows)));
+            }
+            if (const char *env = getenv("ZD_Y_SLABS")) K = std::max(2, atoi(env));
+        }
+        pl->d_Y.assign(K, nullptr);
+        for (int i = 0; i < K; i++) PLCHECK(hipMalloc((void **) &pl->d_Y[i], (size_t) row_b * rows));
         if (pl->overlap) {
             PLCHECK(hipStreamCreateWithFlags(&pl->s_gen, hipStreamNonBlocking));
             PLCHECK(hipStreamCreateWithFlags(&pl->s_fft, hipStreamNonBlocking));
             PLCHECK(hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming));
-            for (int i = 0; i < 2; i++) {
+            pl->ev_gen.assign(K, nullptr);
+            pl->ev_fft.assign(K, nullptr);
+            for (int i = 0; i < K; i++) {
                 PLCHECK(hipEventCreateWithFlags(&pl->ev_gen[i], hipEventDisableTiming));
                 PLCHECK(hipEventCreateWithFlags(&pl->ev_fft[i], hipEventDisableTiming));
             }
@@ -586,15 +616,14 @@ void zd_plan_destroy(zd_plan *pl) {
     hipFree(pl->d_genf);
     hipFree(pl->d_tilectr);
     hipFree(pl->d_red);
-    hipFree(pl->d_Y[0]);
-    hipFree(pl->d_Y[1]);
+    for (cplx *y : pl->d_Y) hipFree(y);
     if (pl->s_gen) hipStreamDestroy(pl->s_gen);
     if (pl->s_fft) hipStreamDestroy(pl->s_fft);
     if (pl->ev_fork) hipEventDestroy(pl->ev_fork);
-    for (int i = 0; i < 2; i++) {
-        if (pl->ev_gen[i]) hipEventDestroy(pl->ev_gen[i]);
-        if (pl->ev_fft[i]) hipEventDestroy(pl->ev_fft[i]);
-    }
+    for (hipEvent_t e : pl->ev_gen)
+        if (e) hipEventDestroy(e);
+    for (hipEvent_t e : pl->ev_fft)
+        if (e) hipEventDestroy(e);
     delete pl;
 }
 
@@ -637,31 +666,59 @@ int zd_plan_stage_z(zd_plan *pl, int residue, void *d_send, void *hip_stream) {
         }
         return 0;
     }
-    // fork: both worker streams start after everything already queued on the caller's stream
+    // Two worker streams.  s_fft (k_zfft, writes the store) starts after everything already queued on the caller's
+    // stream; s_gen (generator, writes ring slots only) is ordered by the ring alone and may be a pass ahead.
+    const int K = (int) pl->d_Y.size(), nslab = pl->Hq / pl->slab_rows;
     HIPCHECK(hipEventRecord(pl->ev_fork, st));
-    HIPCHECK(hipStreamWaitEvent(pl->s_gen, pl->ev_fork, 0));
     HIPCHECK(hipStreamWaitEvent(pl->s_fft, pl->ev_fork, 0));
-    HIPCHECK(hipMemsetAsync(pl->d_tilectr, 0, sizeof(unsigned) * pl->n_tilectr, pl->s_gen));
-    int slab = 0;
-    for (int r0 = 0; r0 < pl->Hq; r0 += pl->slab_rows, slab++) {
-        const int nky = std::min(pl->slab_rows, pl->Hq - r0);
-        const int b   = slab & 1;
-        // k_gen may overwrite Y[b] only after the k_zfft that read it (two slabs ago) has finished
-        if (slab >= 2) HIPCHECK(hipStreamWaitEvent(pl->s_gen, pl->ev_fft[b], 0));
+    auto issue_gen = [&](int pass, int slab, long long gno, int accum) -> int {
+        const int slot = (int) (gno % K), r0 = slab * pl->slab_rows;
+        // the slot is free once the k_zfft that read its previous content (slab gno - K) has finished
+        if (gno >= K) HIPCHECK(hipStreamWaitEvent(pl->s_gen, pl->ev_fft[slot], 0));
+        unsigned *ctr = pl->d_tilectr + (pass & 1) * nslab;
+        if (slab == 0) HIPCHECK(hipMemsetAsync(ctr, 0, sizeof(unsigned) * nslab, pl->s_gen));
+        pl->g.accum_var = accum;
         tick(pl, ZD_K_GEN, pl->s_gen, true);
-        if (zd::launch_gen(pl->g, pl->J, pl->jobs, pl->S, ky_first + r0, nky, pl->L, residue, residue2, pl->d_twN, pl->d_Y[b],
-                           pl->d_tilectr + slab, pl->gen_max_wgs, pl->s_gen))
+        if (zd::launch_gen(pl->g, pl->J, pl->jobs, pl->S, ky_first + r0, pl->slab_rows, pl->L, pass,
+                           pl->pack == zd::PACK_ZAPAIR ? pass + pl->R / 2 : pass, pl->d_twN, pl->d_Y[slot], ctr + slab,
+                           pl->gen_max_wgs, pl->s_gen))
             return 1;
         tick(pl, ZD_K_GEN, pl->s_gen, false);
-        HIPCHECK(hipEventRecord(pl->ev_gen[b], pl->s_gen));
-        HIPCHECK(hipStreamWaitEvent(pl->s_fft, pl->ev_gen[b], 0));
+        HIPCHECK(hipEventRecord(pl->ev_gen[slot], pl->s_gen));
+        return 0;
+    };
+    const int accum = pl->g.accum_var;
+    if (pl->ahead_pass != residue) pl->ahead_n = 0;  // nothing (or something else) was started ahead
+    for (int slab = 0; slab < nslab; slab++) {
+        long long gno;
+        if (slab < pl->ahead_n)
+            gno = pl->ahead_g0 + slab;
+        else {
+            gno = pl->next_g++;
+            if (issue_gen(residue, slab, gno, accum)) return 1;
+        }
+        const int slot = (int) (gno % K), r0 = slab * pl->slab_rows;
+        HIPCHECK(hipStreamWaitEvent(pl->s_fft, pl->ev_gen[slot], 0));
         tick(pl, ZD_K_ZFFT, pl->s_fft, true);
-        if (zd::launch_zfft(pl->L, pl->jobs, pl->S, ky_first + r0, r0, nky, pl->Zq, pl->d_Y[b], pl->d_twL, d_send, pl->s_fft))
+        if (zd::launch_zfft(pl->L, pl->jobs, pl->S, ky_first + r0, r0, pl->slab_rows, pl->Zq, pl->d_Y[slot], pl->d_twL, d_send,
+                            pl->s_fft))
             return 1;
         tick(pl, ZD_K_ZFFT, pl->s_fft, false);
-        HIPCHECK(hipEventRecord(pl->ev_fft[b], pl->s_fft));
+        HIPCHECK(hipEventRecord(pl->ev_fft[slot], pl->s_fft));
     }
-    // join: the caller's stream continues after the last k_zfft (which is after every k_gen)
+    pl->ahead_pass = -1;
+    pl->ahead_n    = 0;
+    // run ahead: the first slabs of the next pass go into the ring now; they execute while the caller's stream does
+    // this pass's y and x transforms
+    if (K > 2 && residue + 1 < pl->npass && p_oneslab_off(pl)) {
+        const int n = std::min(nslab, K);
+        pl->ahead_pass = residue + 1;
+        pl->ahead_g0   = pl->next_g;
+        for (int slab = 0; slab < n; slab++)
+            if (issue_gen(residue + 1, slab, pl->next_g++, 0)) return 1;
+        pl->ahead_n = n;
+    }
+    // join: the caller's stream continues after the last k_zfft of this pass
     HIPCHECK(hipEventRecord(pl->ev_fork, pl->s_fft));
     HIPCHECK(hipStreamWaitEvent(st, pl->ev_fork, 0));
     return 0;
