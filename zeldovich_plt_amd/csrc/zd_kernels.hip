@@ -1589,22 +1589,25 @@ static int launch_xfft_t(const StoreLayout &S, const EpiConst &ec, const void *t
 }
 int launch_xfft(const StoreLayout &S, const EpiConst &ec, const void *tw, const void *data, int plane0, int nplanes,
                 int z_first, int z_step, void *records, float *density, Reduce *red, hipStream_t st) {
-#define XCASE(n, e, rows1, rows2, rows4, rows3)                                                                       \
+#define XCASE(n, e, rows1, rows2, rows4, rows3z, rows3p)                                                              \
     case n:                                                                                                           \
         if (S.narray == 1) return launch_xfft_t<n, e, 1, rows1>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, density, red, st); \
         if (S.narray == 2) return launch_xfft_t<n, e, 2, rows2>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, density, red, st); \
-        if (S.narray == 3) return launch_xfft_t<n, e, 3, rows3>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, density, red, st); \
+        if (S.narray == 3 && ec.pack == PACK_ZAPAIR)                                                                  \
+            return launch_xfft_t<n, e, 3, rows3z>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, density, red, st); \
+        if (S.narray == 3) return launch_xfft_t<n, e, 3, rows3p>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, density, red, st); \
         return launch_xfft_t<n, e, 4, rows4>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, density, red, st);
+    // rows per workgroup for 1 / 2 / 4 arrays and for the packed stores (ZA pairs / PLT), measured
     switch (S.N) {
-        XCASE(32, 16, 32, 32, 16, 16)
-        XCASE(64, 16, 32, 32, 16, 16)
-        XCASE(128, 16, 32, 16, 8, 8)
-        XCASE(256, 16, 16, 8, 4, 4)
-        XCASE(512, 16, 8, 4, 2, 2)
-        XCASE(1024, 16, 4, 2, 1, 2)
-        XCASE(2048, 16, 2, 1, 1, 1)
-        XCASE(4096, 16, 1, 1, 1, 1)
-        XCASE(8192, 16, 1, 1, 1, 1)
+        XCASE(32, 16, 32, 32, 16, 16, 16)
+        XCASE(64, 16, 32, 32, 16, 16, 16)
+        XCASE(128, 16, 32, 16, 8, 8, 8)
+        XCASE(256, 16, 16, 8, 4, 4, 4)
+        XCASE(512, 16, 8, 4, 2, 2, 2)
+        XCASE(1024, 16, 4, 2, 1, 2, 2)
+        XCASE(2048, 16, 2, 1, 1, 1, 2)
+        XCASE(4096, 16, 1, 1, 1, 1, 1)
+        XCASE(8192, 16, 1, 1, 1, 1, 1)
     }
 #undef XCASE
     fprintf(stderr, "zeldovich_hip: unsupported PPD %d\n", S.N);
