@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "build", "libzeldovich_hip.so")
+# ZD_LIB_PATH: A/B-testing another build of the same library (tuning only)
+LIB_PATH = os.environ.get("ZD_LIB_PATH") or os.path.join(_HERE, "csrc", "build", "libzeldovich_hip.so")
 
 ICFORMATS = {"Zeldovich": 0, "RVZel": 1, "RVdoubleZel": 2, "ZelSimple": 3}
 RECORD_DTYPES = {

@@ -477,11 +477,16 @@ struct GenfTab {  // offsets in doubles inside the LDS image (zd_capi.cpp: build
 };
 
 // a*b + c as the three-address VOP3 form.  Left to itself the compiler picks the two-address v_fmac_f64 for the
-// Horner steps below and then has to copy every coefficient into the destination first (a quarter of the loop's
-// vector instructions were such v_mov_b64).  CAUTION (hipcc 7.2): with these asm statements inside a lane-divergent
-// `if (...) continue` region of the mode loop the PLT kernel produced wrong displacements (15 % off; parity tests
-// caught it) — k_genf therefore keeps zeroed lanes in the arithmetic with amplitude 0 instead of branching around
-// it.  -DZD_NO_FMA_ASM builds the plain fma() version.
+// Horner steps below and then copies every coefficient into the destination first (a quarter of the loop's vector
+// instructions were such v_mov_b64; the asm form makes the generator ~7 % faster).
+// HAZARD: the compiler's hazard recognizer does not look at the operands of asm statements.  gfx950 needs a wait
+// state between a transcendental VALU op (v_rcp_f64, v_rsq_f64, ...) and the first read of its result; with an asm
+// v_fma_f64 as that first reader the wait state was missing whenever the scheduler happened to put the two back to
+// back: 1/k^2 (frcp) came out wrong and with it the displacements — 15 % off in the PLT kernel when the mode loop had
+// a lane-divergent `continue`, NaN in the packed ZA kernel after an if/else was added around the draw — while
+// every compiler-emitted path (density, sum |D|^2) stayed right; the parity tests caught both.  Rule: the FIRST
+// consumer of a __builtin_amdgcn_rcp / rsq result is a plain fma()/multiply (frcp, sqrt_pos below).
+// -DZD_NO_FMA_ASM builds the plain-fma() version of everything.
 __device__ __forceinline__ double fma3(double a, double b, double c) {
 #ifdef ZD_NO_FMA_ASM
     return fma(a, b, c);
@@ -549,7 +554,10 @@ __device__ __forceinline__ double fexp(double x, const double *T) {
 
 __device__ __forceinline__ double frcp(double d) {
     double r = __builtin_amdgcn_rcp(d);
-    r = fma3(fnma3(d, r, 1.0), r, r);
+    // plain fma: v_rcp_f64 is a transcendental op and gfx950 needs a wait state before its result is read; the
+    // compiler inserts it for its own instructions but does not look inside asm statements (see fma3)
+    const double e = fma(-d, r, 1.0);
+    r = fma3(e, r, r);
     return fma3(fnma3(d, r, 1.0), r, r);
 }
 
