@@ -159,6 +159,45 @@ def test_plt_streaming(zd, oracle, ps, opk):
     _compare(zd, oracle, ps, opk, 128, eig=eig, qPLT=1, stream_factor=2)
 
 
+@pytest.mark.parametrize("n,kw", [
+    (128, dict(stream_factor=2, k_cutoff=2.0)),                       # packed ZA pair + pruned tiles
+    (128, dict(stream_factor=4, corner_modes=1)),                     # two passes of two residues, CornerModes
+    (256, dict(stream_factor=8, fmt="RVZel")),                        # four passes, float records
+    (128, dict(stream_factor=2, fmt="Zeldovich")),
+    (64, dict(stream_factor=2, fmt="ZelSimple", k_cutoff=4.0)),
+])
+def test_packed_za_pairs_sweep(zd, oracle, ps, opk, n, kw):
+    """ZA without ZD_qdensity and R >= 2: two z-residues per pass in 3 arrays, density_variance from sum |D|^2"""
+    kw = dict(kw)
+    fmt = kw.pop("fmt", "RVdoubleZel")
+    plan = zd.Plan(zd.make_params(n, icformat=fmt, **kw), ps)
+    assert plan.narray == 3 and plan.plane_step == 2
+    plan.close()
+    got, _ = _compare(zd, oracle, ps, opk, n, fmt=fmt, **kw)
+    assert sorted(got["planes_seen"]) == list(range(n))
+
+
+@pytest.mark.parametrize("R,ppd_e,resc", [(1, 64, 1), (4, 24, 0), (2, 128, 1)])
+def test_packed_plt_sweep(zd, oracle, ps, opk, R, ppd_e, resc):
+    """PLT without ZD_qdensity: qx + i vx | qy + i qz | vy + i vz, any R; exact-stride and interpolated eigenmodes"""
+    eig = oracle.synthetic_eigenmodes(ppd_e)
+    kw = dict(qPLT=1, qPLTrescale=resc, PLT_target_z=3.0, f_cluster=0.95, stream_factor=R)
+    plan = zd.Plan(zd.make_params(128, **kw), ps, eig=eig)
+    assert plan.narray == 3 and plan.plane_step == 1 and plan.passes == R
+    plan.close()
+    _compare(zd, oracle, ps, opk, 128, eig=eig, **kw)
+
+
+def test_packed_powerlaw_and_fixed_amplitudes(zd, oracle):
+    """the table-driven generator on a power-law spectrum (no spline) and with ZD_qPk_fix_to_mean"""
+    ps2 = zd.PowerSpectrum.from_powerlaw(-1.5, 720.0, fix_to_mean=1)
+    opk2 = oracle.pk_from_powerlaw(-1.5, 720.0, fix_to_mean=1)
+    _compare(zd, oracle, ps2, opk2, 64, stream_factor=2)
+    ps3 = zd.PowerSpectrum.from_powerlaw(-2.0, 720.0, Pk_smooth=2.0)
+    opk3 = oracle.pk_from_powerlaw(-2.0, 720.0, Pk_smooth=2.0)
+    _compare(zd, oracle, ps3, opk3, 64)
+
+
 def test_k_cutoff_and_density(zd, oracle, ps, opk):
     _compare(zd, oracle, ps, opk, 64, k_cutoff=2.0, qdensity=1)
 
