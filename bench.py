@@ -211,7 +211,8 @@ def main():
                 ", synthetic ppd_e=128 PLT eigenmodes" if plt else ""),
             "config": {"workload": "PPD=%d %s ICFormat=%s seed=12346 BoxSize=720" % (
                 N, "ZD_qPLT=1 ZD_qPLT_rescale=1" if plt else "ZA (ZD_qPLT=0)", fmt),
-                "stream_factor": R, "modes_cached": st["modes_cached"], "narray": narray,
+                "stream_factor": R, "modes_cached": st["modes_cached"], "narray": narray,  # the reference's array count (SURVEY §8d prices the roofline with it)
+                "store_arrays": plan.narray, "passes": plan.passes,
                 "block_store_GB": plan.exchange_bytes / 1e9, "parallelism": "ky/z slabs x%d" % world},
             "hbm_GBps_path": (64.0 * narray + recsize) * value / 1e9,
             "roofline_path_frac": (64.0 * narray + recsize) * value / 1e9 / (HBM_PEAK_GBS * world),
@@ -226,6 +227,9 @@ def main():
             "kernels": per_kernel,
             "kernels_isolated": isolated,
         }
+        if isolated and isolated.get(dom, {}).get("alg_GBps"):
+            out["roofline"]["isolated_achieved"] = isolated[dom]["alg_GBps"]
+            out["roofline"]["isolated_frac"] = isolated[dom]["alg_GBps"] / HBM_PEAK_GBS
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(N, plt, fmt, eig)
