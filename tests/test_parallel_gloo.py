@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, R, outdir):
+def _worker(rank, world, port, n, R, outdir, max_msg=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -35,6 +35,8 @@ def _worker(rank, world, port, n, R, outdir):
     cube = zdo.mode_cube(zdo.make_params(n, numblock=2), pk)
     eng = NumpyEngine(cube, n, R, rank, world)
     pipe = SlabPipeline(eng, n, world=world, dist=dist, device="cpu", chunk_bytes=3 * n * n * eng.record_size)
+    if max_msg:
+        pipe.MAX_MSG_ELEMS = max_msg  # force the multi-round form of the exchange
     got = {}
 
     def consume(zs, ring):
@@ -49,11 +51,11 @@ def _worker(rank, world, port, n, R, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("R", [1, 2])
-def test_two_rank_pipeline_matches_oracle(tmp_path, oracle, R):
+@pytest.mark.parametrize("R,max_msg", [(1, None), (2, None), (2, 700)])
+def test_two_rank_pipeline_matches_oracle(tmp_path, oracle, R, max_msg):
     n, world = 16, 2
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, n, R, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, n, R, str(tmp_path), max_msg), nprocs=world, join=True)
     pk = oracle.pk_from_file(WMAP, 720.0)
     ref = oracle.run(oracle.make_params(n, numblock=2), pk, want_planes=True)["planes"]  # [z][a][y][x]
     seen = {}

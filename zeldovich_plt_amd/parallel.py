@@ -65,11 +65,37 @@ class SlabPipeline:
         self.chunk = int(max(step, min(engine.local_planes, chunk_bytes // plane_b) // step * step))
         self.ring = torch.empty(self.chunk * plane_b, dtype=torch.uint8, device=device)
 
+    # largest single message of the exchange, in float64 elements: at PPD=4096 on 2 ranks a peer's chunk is
+    # 52 GB = 6.5e9 elements — past what a 32-bit element count anywhere inside a collective library could hold.
+    # Below the limit (e.g. 8 ranks: 1.6e9) the exchange is ONE all_to_all_single.
+    MAX_MSG_ELEMS = (1 << 31) - 1
+
     def exchange(self):
-        if self.world > 1:
-            # chunk d of `send` goes to rank d and arrives as chunk <my rank> there: exactly the
-            # y-slab-owner -> z-slab-owner block move of StoreBlock/LoadBlock
+        if self.world <= 1:
+            return
+        # chunk d of `send` goes to rank d and arrives as chunk <my rank> there: exactly the
+        # y-slab-owner -> z-slab-owner block move of StoreBlock/LoadBlock
+        per = self.send.numel() // self.world
+        if per <= self.MAX_MSG_ELEMS:
             self.dist.all_to_all_single(self.recv, self.send)
+            return
+        # same move in k rounds of equal contiguous pieces (piece i of every peer chunk per round)
+        k = -(-per // self.MAX_MSG_ELEMS)
+        while per % k:
+            k += 1
+        part = per // k
+        sv, rv = self.send.view(self.world, k, part), self.recv.view(self.world, k, part)
+        me = self.dist.get_rank()
+        for i in range(k):
+            ops = []
+            for d in range(self.world):
+                if d == me:
+                    rv[d, i].copy_(sv[d, i])
+                else:
+                    ops.append(self.dist.P2POp(self.dist.isend, sv[d, i], d))
+                    ops.append(self.dist.P2POp(self.dist.irecv, rv[d, i], d))
+            for req in self.dist.batch_isend_irecv(ops):
+                req.wait()
 
     def run_pass(self, residue, consume=None):
         """consume(z_list, ring_tensor) is called once per plane chunk with the global z of each plane"""
