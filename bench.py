@@ -125,6 +125,10 @@ def main():
     R = args.stream
     if R <= 0:
         budget = int(free_b) - (12 << 30)  # tables, ~1 GB folded-input slab, record ring, runtime
+        if world > 1:  # every rank must arrive at the same R: use the smallest budget of the job
+            t = torch.tensor([budget], dtype=torch.int64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            budget = int(t.item())
         import ctypes
         R = zd.load_library().zd_choose_stream_factor(ctypes.byref(p), world, budget)
         if R < 0:
