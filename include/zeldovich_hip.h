@@ -102,8 +102,9 @@ int zd_generate(const zd_params *p, const zd_pk *pk, const double *eig, int64_t 
 int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes);
 
 /* ---- staged API (device pointers) for one-process-per-GPU drivers and for tests ---------------
- * Rank `rank` of `nranks` owns half-space rows ky in [rank*H, (rank+1)*H), H = ppd/2/nranks, plus
- * their Hermitian twins, during the Z stage, and z planes [rank*Zq, (rank+1)*Zq) of every residue
+ * Rank `rank` of `nranks` (a power of two) owns the half-space rows ky = rank, rank + nranks, ... (H = ppd/2/nranks
+ * of them; cyclic, because the rows near ky = 0 carry most of the non-zero modes), plus their Hermitian twins,
+ * during the Z stage, and z planes [rank*Zq, (rank+1)*Zq) of every residue
  * pass (Zq = ppd/R/nranks) during the XY stage.  Between the two, the caller exchanges equal
  * chunks (all-to-all): chunk d of the send buffer goes to rank d and is received as chunk `rank`…
  * of the receive buffer (exactly torch.distributed.all_to_all_single / ncclAllToAll semantics).

@@ -497,6 +497,9 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
     S.Hq     = pl->Hq;
     S.lHq    = 0;
     while ((1 << S.lHq) < pl->Hq) S.lHq++;
+    S.lG = 0;
+    while ((1 << S.lG) < nranks) S.lG++;
+    S.ky_stride = nranks;
     S.narray = pl->narray;
     S.prune     = getenv("ZD_PRUNE") ? atoi(getenv("ZD_PRUNE")) : 7;  // bit 0 k_gen, 1 k_zfft, 2 k_yfft
     S.nt = getenv("ZD_NT") ? atoi(getenv("ZD_NT")) : 0;
@@ -648,19 +651,19 @@ int zd_plan_stage_z(zd_plan *pl, int residue, void *d_send, void *hip_stream) {
     const int residue2 = pl->pack == zd::PACK_ZAPAIR ? residue + pl->R / 2 : residue;
     pl->g.accum_var = (pl->pack != zd::PACK_NONE && pl->var_pending) ? 1 : 0;  // once per run: every pass sees every mode
     pl->var_pending = false;
-    const int ky_first = pl->rank * pl->Hq;
+    const int ky_first = pl->rank, G = pl->nranks;  // this rank's half-space rows: rank, rank + G, ... (cyclic)
     if (!pl->overlap) {
         HIPCHECK(hipMemsetAsync(pl->d_tilectr, 0, sizeof(unsigned) * pl->n_tilectr, st));
         int slab = 0;
         for (int r0 = 0; r0 < pl->Hq; r0 += pl->slab_rows, slab++) {
             const int nky = std::min(pl->slab_rows, pl->Hq - r0);
             tick(pl, ZD_K_GEN, st, true);
-            if (zd::launch_gen(pl->g, pl->J, pl->jobs, pl->S, ky_first + r0, nky, pl->L, residue, residue2, pl->d_twN, pl->d_Y[0],
+            if (zd::launch_gen(pl->g, pl->J, pl->jobs, pl->S, ky_first + G * r0, nky, pl->L, residue, residue2, pl->d_twN, pl->d_Y[0],
                                pl->d_tilectr + slab, pl->gen_max_wgs, st))
                 return 1;
             tick(pl, ZD_K_GEN, st, false);
             tick(pl, ZD_K_ZFFT, st, true);
-            if (zd::launch_zfft(pl->L, pl->jobs, pl->S, ky_first + r0, r0, nky, pl->Zq, pl->d_Y[0], pl->d_twL, d_send, st))
+            if (zd::launch_zfft(pl->L, pl->jobs, pl->S, ky_first + G * r0, r0, nky, pl->Zq, pl->d_Y[0], pl->d_twL, d_send, st))
                 return 1;
             tick(pl, ZD_K_ZFFT, st, false);
         }
@@ -679,7 +682,7 @@ int zd_plan_stage_z(zd_plan *pl, int residue, void *d_send, void *hip_stream) {
         if (slab == 0) HIPCHECK(hipMemsetAsync(ctr, 0, sizeof(unsigned) * nslab, pl->s_gen));
         pl->g.accum_var = accum;
         tick(pl, ZD_K_GEN, pl->s_gen, true);
-        if (zd::launch_gen(pl->g, pl->J, pl->jobs, pl->S, ky_first + r0, pl->slab_rows, pl->L, pass,
+        if (zd::launch_gen(pl->g, pl->J, pl->jobs, pl->S, ky_first + G * r0, pl->slab_rows, pl->L, pass,
                            pl->pack == zd::PACK_ZAPAIR ? pass + pl->R / 2 : pass, pl->d_twN, pl->d_Y[slot], ctr + slab,
                            pl->gen_max_wgs, pl->s_gen))
             return 1;
@@ -700,7 +703,7 @@ int zd_plan_stage_z(zd_plan *pl, int residue, void *d_send, void *hip_stream) {
         const int slot = (int) (gno % K), r0 = slab * pl->slab_rows;
         HIPCHECK(hipStreamWaitEvent(pl->s_fft, pl->ev_gen[slot], 0));
         tick(pl, ZD_K_ZFFT, pl->s_fft, true);
-        if (zd::launch_zfft(pl->L, pl->jobs, pl->S, ky_first + r0, r0, pl->slab_rows, pl->Zq, pl->d_Y[slot], pl->d_twL, d_send,
+        if (zd::launch_zfft(pl->L, pl->jobs, pl->S, ky_first + G * r0, r0, pl->slab_rows, pl->Zq, pl->d_Y[slot], pl->d_twL, d_send,
                             pl->s_fft))
             return 1;
         tick(pl, ZD_K_ZFFT, pl->s_fft, false);
@@ -1033,6 +1036,8 @@ int zd_test_yfft_variant(int32_t n, int32_t variant, int32_t narray, int32_t npl
     S.N = n; S.half = n / 2; S.Hq = n / 2; S.narray = narray;
     S.lHq = 0;
     while ((1 << S.lHq) < S.Hq) S.lHq++;
+    S.lG = 0;
+    S.ky_stride = 1;
     int lBk = 0, lBz = 0;
     if (tiled) {
         const long long target = std::max<long long>(1, ((long long) 2 << 20) / ((long long) n * 16));

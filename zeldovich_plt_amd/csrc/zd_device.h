@@ -63,7 +63,7 @@ struct GenJumps {
 
 // Addressing of the z-transformed block store ("BlockArray", include/block_array.h:26-35, re-laid
 // out for the GPU).  Rows are grouped by the rank that generated them: rank g holds half-space rows
-// [g*Hq,(g+1)*Hq) at slots 0..Hq-1 and their Hermitian twins at slots Hq..2Hq-1 — the reference's
+// g, g + G, g + 2G, ... at slots 0..Hq-1 and their Hermitian twins at slots Hq..2Hq-1 — the reference's
 // "displaced twin" storage (zeldovich.cpp:453-466, block_array.cpp:487-491); the unused twin slot of
 // ky = 0 is the Nyquist row ky = N/2, which is never read (treated as zero, zeldovich.cpp:644-650).
 //
@@ -76,6 +76,9 @@ struct GenJumps {
 struct StoreLayout {
     int N, half, Hq, narray;
     int lHq;         // log2(Hq): Hq, Zq, N are powers of two, so every division is a shift
+    int lG;          // log2(number of ranks): half-space row ky belongs to rank ky mod G (cyclic: the rows near ky = 0
+                     // carry most of the non-zero modes, contiguous blocks would leave rank 0 with up to 1.5x the work)
+    int ky_stride;   // = G: rows ky0, ky0 + G, ... of a generator / z-FFT launch
     int lBk, lBz;    // log2 of the block edge in row slots / planes
     int rows_outer;  // order inside a block: 0 = [plane][slot][x], 1 = [slot][plane][x]
     int one_block;   // 1: single rank and Bk = 2*Hq, Bz = 1 -> slot s of (plane, array) is row s of one contiguous region
@@ -111,8 +114,8 @@ ZD_HD void row_slot(const StoreLayout &L, int ky, int &chunk, int &slot) {
         kyh = L.N - ky;
         tw  = 1;
     }
-    chunk = kyh >> L.lHq;
-    slot  = (kyh & (L.Hq - 1)) + (tw << L.lHq);
+    chunk = kyh & ((1 << L.lG) - 1);
+    slot  = (kyh >> L.lG) + (tw << L.lHq);
 }
 // row index of (chunk, local plane zl, array a, row slot); element offset = row * pitch + x
 ZD_HD int store_row(const StoreLayout &L, int chunk, int zl, int a, int slot) {

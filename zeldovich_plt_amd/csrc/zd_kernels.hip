@@ -253,7 +253,7 @@ __global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, JobList 
     const int x   = blockIdx.x * GEN_BX + threadIdx.x;
     const int k20 = blockIdx.y * ZR;
     const int kyl = blockIdx.z;
-    const int ky  = ky0 + kyl;
+    const int ky  = ky0 + kyl * S.ky_stride;
     if (x >= N) return;
     const int kx = x > half ? x - N : x;
     if (S.prune & 1) {  // the whole k_zfft tile this column belongs to is identically zero: nothing to produce
@@ -643,7 +643,7 @@ __device__ __forceinline__ double genf_tile(const GenConst &g, const GenJumps &J
     const int N = g.N, half = g.half, R = N / L;
     const int x   = bx * GEN_BX + threadIdx.x;
     const int k20 = by * ZR;
-    const int ky  = ky0 + kyl;  // >= 1
+    const int ky  = ky0 + kyl * S.ky_stride;  // >= 1
     if (x >= N) return 0.0;
     const int kx = x > half ? x - N : x;
     if (S.prune & 1) {  // see k_gen: skip columns whose k_zfft tiles (self and shifted twin) are all zero
@@ -907,7 +907,7 @@ __global__ __launch_bounds__(W *L / E) void k_zfft(JobList jobs, StoreLayout S, 
     const int N = S.N;
     const int w = threadIdx.x % W, t = threadIdx.x / W;
     const int kyl = blockIdx.y;
-    const int ky  = ky0 + kyl;
+    const int ky  = ky0 + kyl * S.ky_stride;
     const int kind = jobs.kind[blockIdx.z];
     const bool twin_only = jobs.twin[blockIdx.z] != 0;
     // twin columns are stored mirrored (column N-x): shifting the tile of twin-only jobs by one column
