@@ -631,6 +631,69 @@ __device__ __forceinline__ void cmac(double &ar, double &ai, double c, double dr
     ai = fma(c, di, ai);
 }
 
+// get_eigenmode for k_genf: the (x, y) part of the lookup — table offsets of the 4 corner columns and the products
+// w_x w_y — depends on the thread's kx and the row's ky only and is prepared once per tile; per mode remain the two
+// z corners, 1/|e| by rsq + Newton and k^2/(k.e) by reciprocal (get_eigenmode_dev: sqrt + two divisions).
+// Accumulation order and weight association are those of get_eigenmode_dev / zeldovich.cpp:218-225.
+struct EigXY {
+    int base[4];   // ((cx*ep + cy)*halfppd)*2 in double2 units, corners (l,l), (l,h), (h,l), (h,h)
+    double w[4];   // w_x * w_y
+};
+__device__ __forceinline__ EigXY eig_xy(const GenConst &g, const EigAxis &ax, const EigAxis &ay) {
+    const int ep = (int) g.eig_ppd, halfppd = ep / 2 + 1;
+    EigXY q;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int cx = (c & 2) ? ax.h : ax.l, cy = (c & 1) ? ay.h : ay.l;
+        q.base[c] = ((cx * ep + cy) * halfppd) * 2;
+        q.w[c]    = ((c & 2) ? ax.f : 1 - ax.f) * ((c & 1) ? ay.f : 1 - ay.f);
+    }
+    return q;
+}
+__device__ __forceinline__ void eigenmode_fast(const GenConst &g, int kx, int ky, int kz, const EigXY &q, const EigAxis &az,
+                                               double (&out)[4]) {
+    const double2 *E = reinterpret_cast<const double2 *>(g.eig);
+    double eh[4];
+    if ((int) g.eig_ppd % g.N == 0) {
+        const int i = q.base[0] + az.l * 2;
+        const double2 q0 = E[i], q1 = E[i + 1];
+        eh[0] = q0.x;
+        eh[1] = q0.y;
+        eh[2] = q1.x;
+        eh[3] = q1.y;
+    } else {
+        eh[0] = eh[1] = eh[2] = eh[3] = 0.0;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const double wgt = q.w[c >> 1] * ((c & 1) ? az.f : 1 - az.f);
+            if (wgt != 0) {
+                const int i = q.base[c >> 1] + ((c & 1) ? az.h : az.l) * 2;
+                const double2 q0 = E[i], q1 = E[i + 1];
+                eh[0] += wgt * q0.x;
+                eh[1] += wgt * q0.y;
+                eh[2] += wgt * q1.x;
+                eh[3] += wgt * q1.y;
+            }
+        }
+    }
+    eh[2] *= (kz < 0 ? -1.0 : 1.0);
+    const double n2 = eh[0] * eh[0] + eh[1] * eh[1] + eh[2] * eh[2];
+    double r = __builtin_amdgcn_rsq(n2);
+    r = r * fma(-0.5 * n2, r * r, 1.5);  // plain arithmetic right after the transcendental op (see fma3)
+    r = r * fma(-0.5 * n2, r * r, 1.5);
+    eh[0] *= r;
+    eh[1] *= r;
+    eh[2] *= r;
+    const double k2  = (double) (kx * kx + ky * ky + kz * kz);
+    const double dot = kx * eh[0] + ky * eh[1] + kz * eh[2];
+    double norm = k2 * frcp(dot);
+    if (k2 == 0.0 || !isfinite(norm)) norm = 0.0;
+    out[0] = norm * eh[0];
+    out[1] = norm * eh[1];
+    out[2] = norm * eh[2];
+    out[3] = eh[3];
+}
+
 template <int ZR, int KIND, bool PLAW>
 __device__ __forceinline__ double genf_tile(const GenConst &g, const GenJumps &J, const StoreLayout &S, const double *T, int zW,
                                             int ky0, int kyl, int nky, int L, int residue, int residue2, int bx, int by,
@@ -657,11 +720,8 @@ __device__ __forceinline__ double genf_tile(const GenConst &g, const GenJumps &J
     }
     const int kxy2  = kx * kx + ky * ky;
     const bool dead = (kx < 0 ? -kx : kx) == g.kmax || ky == g.kmax;  // zeldovich.cpp:350
-    EigAxis eax = {0, 0, 0.0}, eay = {0, 0, 0.0};
-    if constexpr (IS_PLT) {
-        eax = eig_axis(g, eig_index_x(g, kx));
-        eay = eig_axis(g, ky);
-    }
+    EigXY exy = {};
+    if constexpr (IS_PLT) exy = eig_xy(g, eig_axis(g, eig_index_x(g, kx)), eig_axis(g, ky));
     u128 s;
     {  // state one step ahead of the first mode's counter
         const int kz0 = k20 > half ? k20 - N : k20;  // k20 > N/2 only happens when R = 1
@@ -748,8 +808,7 @@ __device__ __forceinline__ double genf_tile(const GenConst &g, const GenJumps &J
             } else if constexpr (IS_PLT) {
                 constexpr int B = KIND == GENF_PLT ? 1 : 0;  // index of the X sum
                 double e[4];
-                const EigAxis eaz = eig_axis(g, eig_index_z(g, kz));
-                get_eigenmode_dev(g, kx, ky, kz, eax, eay, eaz, e);
+                eigenmode_fast(g, kx, ky, kz, exy, eig_axis(g, eig_index_z(g, kz)), e);
                 const double f = (sqrt_pos(1. + 24 * e[3] * g.f_cluster) - 1) * .25;
                 double rescale = 1.0;
                 if (g.qPLTrescale) rescale = fexp(g.ln_growth_ratio * (g.target_f - f), T);
