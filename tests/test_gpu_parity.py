@@ -365,6 +365,23 @@ def test_parseval_oversampling_property(zd, ps):
     assert abs(b["density_variance"] / a["density_variance"] - 8.0) < 1e-12
 
 
+def test_full_size_properties_ppd4096_vs_2048(zd, ps, monkeypatch):
+    """BASELINE sizes through size-independent properties (no oracle run is feasible at 6.9e10 particles):
+    PPD=4096 with k_cutoff=2 is phase-matched to PPD=2048 (README :52-54 of the reference) -> exactly 8x the sum of
+    dens^2; the packed store (two residues per pass, Parseval) and the reference's two arrays agree at PPD=2048;
+    the rms pixel density matches sigma(R) like the reference's own printed check (zeldovich.cpp:987-996)"""
+    a = zd.generate(zd.make_params(2048, icformat="RVZel"), ps, collect=False)
+    b = zd.generate(zd.make_params(4096, k_cutoff=2.0, icformat="RVZel"), ps, collect=False)
+    assert abs(b["density_variance"] / a["density_variance"] - 8.0) < 1e-11
+    monkeypatch.setenv("ZD_NO_PACK", "1")
+    c = zd.generate(zd.make_params(2048, icformat="RVZel"), ps, collect=False)
+    assert abs(a["density_variance"] - c["density_variance"]) <= 1e-11 * c["density_variance"]
+    assert np.abs(a["max_disp"] - c["max_disp"]).max() <= 1e-11 * np.abs(c["max_disp"]).max()
+    rms = np.sqrt(a["density_variance"] / 2048.0 ** 3)
+    pred = ps.sigmaR(720.0 / 2048 / 4.0) * 720.0 ** 1.5
+    assert 0.5 < rms / pred < 1.5
+
+
 @pytest.mark.parametrize("n,kw", [(64, dict()), (64, dict(stream_factor=2)), (128, dict(k_cutoff=2.0))])
 def test_fnl_end_to_end(zd, oracle, ps, wmap_path, n, kw):
     """local primordial non-Gaussianity (next-row f.2): phi = D/M -> phi + f_NL phi^2 -> D = phi M, then the
