@@ -888,10 +888,187 @@ __device__ __forceinline__ double genf_tile(const GenConst &g, const GenJumps &J
     return vsum;
 }
 
+// genf_tile for the ZA kinds with the x mirror folded in: a thread owns the columns kx = +xh and kx = -xh (x = xh
+// and N - xh).  The two modes of a (ky, kz) share |k|^2, hence the zero rule, P(k) and 1/k^2 — a quarter of the
+// arithmetic of a mode; the two RNG walks, Box-Muller draws and field sums stay separate.  (The PLT kinds keep
+// genf_tile: their eigenvectors differ between +kx and -kx and their field sums already fill the registers.)
+template <int ZR, int KIND, bool PLAW>
+__device__ __forceinline__ double genf_tile_mirror(const GenConst &g, const GenJumps &J, const StoreLayout &S, const double *T,
+                                                   int zW, int ky0, int kyl, int nky, int L, int residue, int residue2, int bx,
+                                                   int by, const cplx *__restrict__ twN, cplx *__restrict__ Y) {
+    static_assert(KIND == GENF_DENS || KIND == GENF_ZA || KIND == GENF_ZAP, "ZA kinds only");
+    constexpr int NACC = KIND == GENF_DENS ? 1 : KIND == GENF_ZA ? 3 : 4;
+    double vsum = 0.0;
+    const int N = g.N, half = g.half, R = N / L;
+    const int xh  = bx * GEN_BX + threadIdx.x;  // 0 .. N/2
+    const int k20 = by * ZR;
+    const int ky  = ky0 + kyl * S.ky_stride;  // >= 1
+    if (xh > half) return 0.0;
+    const bool hasB = xh > 0 && xh < half;  // x = 0 and x = N/2 are their own mirrors
+    const int xA = xh, xB = hasB ? N - xh : xh;
+    auto tile_zero = [&](int x) {  // see k_gen: the k_zfft tiles (self and shifted twin) this column belongs to are all zero
+        bool all_zero = true;
+        const int xt0 = x - x % zW;
+        for (int i = -1; i <= zW; i++) {
+            const int xi = (xt0 + i) & (N - 1);
+            all_zero = all_zero && column_is_zero(S, xi > half ? xi - N : xi, ky);
+        }
+        return all_zero;
+    };
+    bool needA = true, needB = hasB;
+    if (S.prune & 1) {
+        needA = !tile_zero(xA);
+        needB = hasB && !tile_zero(xB);
+        if (!needA && !needB) return 0.0;
+    }
+    const int kxy2  = xh * xh + ky * ky;
+    const bool dead = xh == g.kmax || ky == g.kmax;  // zeldovich.cpp:350
+    u128 sA, sB;
+    {  // states one step ahead of the first modes' counters
+        const int kz0 = k20 > half ? k20 - N : k20;  // k20 > N/2 only happens when R = 1
+        const uint64_t offz = (uint64_t) (kz0 & 65535) * 65536ULL;
+        sA = advance_bits(g.row_state[ky], 2ULL * (offz + (uint64_t) (xh & 65535)) + 1ULL);
+        sB = advance_bits(g.row_state[ky], 2ULL * (offz + (uint64_t) ((hasB ? -xh : xh) & 65535)) + 1ULL);
+    }
+    const zdpcg::Affine fwd0 = J.fwd[0], fwdf0 = J.fwd_full[0];
+#pragma unroll 1
+    for (int zi = 0; zi < ZR; zi++) {
+        const int k2 = k20 + zi;
+        double aAr[NACC], aAi[NACC], aBr[NACC], aBi[NACC];
+#pragma unroll
+        for (int j = 0; j < NACC; j++) aAr[j] = aAi[j] = aBr[j] = aBi[j] = 0.0;
+#pragma unroll 1
+        for (int k1 = 0; k1 < R; k1++) {
+            const int z  = k2 + L * k1;
+            const int kz = z > half ? z - N : z;
+            const int k2i = kxy2 + kz * kz;
+            const bool live = !dead && (kz < 0 ? -kz : kz) != g.kmax && (g.corner_modes || k2i < g.k2i_cut);
+            const bool last = k1 + 1 >= R;
+            const int sel   = (z > half) != ((last ? k2 + 1 : z + L) > half);
+            const bool any  = __any(live);
+            zdpcg::Affine m;
+            if (!last && !sel)
+                m = any ? fwd0 : fwdf0;
+            else if (!last)
+                m = any ? J.fwd[1] : J.fwd_full[1];
+            else
+                m = any ? J.back[sel] : J.back_full[sel];
+            if (!any) {
+                sA = zdpcg::apply(m, sA);
+                sB = zdpcg::apply(m, sB);
+                continue;
+            }
+            const uint64_t r1A = zdpcg::output(sA), r1B = zdpcg::output(sB);
+            const u128 tA = zdpcg::step(sA), tB = zdpcg::step(sB);
+            const uint64_t r2A = zdpcg::output(tA), r2B = zdpcg::output(tB);
+            sA = zdpcg::apply(m, tA);
+            sB = zdpcg::apply(m, tB);
+            // ---- shared by the two modes: P(k), 1/k^2 ----
+            const double k2v = (double) k2i * g.fundamental2;
+            const double P   = genf_power<PLAW>(g, T, k2v);
+            const double q   = g.fundamental * frcp(k2v);
+            // W_R^{k1 r} (and the second residue's)
+            double wr = 1.0, wi = 0.0, w2r = 1.0, w2i = 0.0;
+            if (R > 1) {
+                const cplx w = twN[(int) (((long long) k1 * residue * L) & (N - 1))];
+                wr = w.x;
+                wi = w.y;
+                if constexpr (KIND == GENF_ZAP) {
+                    const cplx w2 = twN[(int) (((long long) k1 * residue2 * L) & (N - 1))];
+                    w2r = w2.x;
+                    w2i = w2.y;
+                }
+            }
+            const double dkz = (double) kz;
+            auto one = [&](uint64_t r1, uint64_t r2, double (&ar)[NACC], double (&ai)[NACC]) {
+                // cgauss<2> (power_spectrum.cpp:338-359); zeroed lanes of a live wave ride along with amplitude 0
+                const uint64_t m1 = r1 + 1ULL;
+                double v = P;
+                if (!g.fixed_power) v = -P * flog(u64_to_double(m1), 64, T);
+                v = (m1 == 0 && !g.fixed_power) || !live ? 0.0 : v;
+                const double amp = sqrt_pos(v);
+                double sn, cs;
+                sincos_u01(u64_to_double(r2 + 1ULL), T, sn, cs);
+                const double d0r = amp * cs, d0i = amp * sn;
+                vsum = fma(d0r, d0r, fma(d0i, d0i, vsum));
+                const double dr = d0r * wr - d0i * wi, di = d0r * wi + d0i * wr;
+                if constexpr (KIND == GENF_DENS) {
+                    ar[0] += dr;
+                    ai[0] += di;
+                } else if constexpr (KIND == GENF_ZA) {
+                    ar[0] += dr;
+                    ai[0] += di;
+                    const double er = q * dr, ei = q * di;
+                    ar[1] += er;
+                    ai[1] += ei;
+                    cmac(ar[2], ai[2], dkz, er, ei);
+                } else {
+                    const double er = q * dr, ei = q * di;
+                    ar[0] += er;
+                    ai[0] += ei;
+                    cmac(ar[1], ai[1], dkz, er, ei);
+                    const double d2r = d0r * w2r - d0i * w2i, d2i = d0r * w2i + d0i * w2r;
+                    const double e2r = q * d2r, e2i = q * d2i;
+                    ar[2] += e2r;
+                    ai[2] += e2i;
+                    cmac(ar[3], ai[3], dkz, e2r, e2i);
+                }
+            };
+            one(r1A, r2A, aAr, aAi);
+            one(r1B, r2B, aBr, aBi);
+        }
+        // ---- job inputs from the field sums (genf_tile), for column xA with kx = +xh and column xB with kx = -xh ----
+        double pr = 1.0, pi = 0.0, qr = 1.0, qi = 0.0;
+        if (R > 1) {
+            const cplx w = twN[(int) (((long long) k2 * residue) & (N - 1))];
+            pr = w.x;
+            pi = w.y;
+            if constexpr (KIND == GENF_ZAP) {
+                const cplx w2 = twN[(int) (((long long) k2 * residue2) & (N - 1))];
+                qr = w2.x;
+                qi = w2.y;
+            }
+        }
+        auto emit = [&](int x, double dkx, const double (&ar)[NACC], const double (&ai)[NACC]) {
+            auto put = [&](int j, double vr, double vi) {
+                const unsigned idx = (unsigned) (((j * nky + kyl) * L + k2) * N + x);
+                Y[idx] = cplx{vr, vi};
+            };
+            auto putp = [&](int j, double vr, double vi) { put(j, vr * pr - vi * pi, vr * pi + vi * pr); };
+            const double dky = (double) ky;
+            if constexpr (KIND == GENF_DENS) {
+                putp(0, ar[0], ai[0]);
+            } else if constexpr (KIND == GENF_ZA) {
+                const double xr = dkx * ar[1], xi = dkx * ai[1], yr = dky * ar[1], yi = dky * ai[1];
+                putp(0, ar[0] - xr, ai[0] - xi);       // JOB_A_SELF
+                putp(1, ar[0] + xr, ai[0] + xi);       // JOB_A_TWIN
+                putp(2, -ar[2] - yi, -ai[2] + yr);     // JOB_B_SELF
+                putp(3, ar[2] - yi, ai[2] + yr);       // JOB_B_TWIN
+            } else {
+                auto putq = [&](int j, double vr, double vi) { put(j, vr * qr - vi * qi, vr * qi + vi * qr); };
+                const double y0r = dky * ar[0], y0i = dky * ai[0], y1r = dky * ar[2], y1i = dky * ai[2];
+                putp(0, -ar[1] - y0i, -ai[1] + y0r);   // JOB_B_SELF (r0)
+                putp(1, ar[1] - y0i, ai[1] + y0r);     // JOB_B_TWIN (r0)
+                putq(2, -ar[3] - y1i, -ai[3] + y1r);   // JOB_B_SELF (r1)
+                putq(3, ar[3] - y1i, ai[3] + y1r);     // JOB_B_TWIN (r1)
+                const double g0r = -dkx * ai[0], g0i = dkx * ar[0], g1r = -dkx * ai[2], g1i = dkx * ar[2];
+                const double f0r = g0r * pr - g0i * pi, f0i = g0r * pi + g0i * pr;
+                const double f1r = g1r * qr - g1i * qi, f1i = g1r * qi + g1i * qr;
+                put(4, f0r - f1i, f0i + f1r);          // X_self       = F_x(r0) + i F_x(r1)
+                put(5, f0r + f1i, f0i - f1r);          // X_twin input = F_x(r0) - i F_x(r1)
+            }
+        };
+        if (needA) emit(xA, (double) xh, aAr, aAi);
+        if (needB) emit(xB, (double) -xh, aBr, aBi);
+    }
+    // a thread without a mirror column (x = 0, N/2) ran its second walk on a copy of the first: count its modes once
+    return hasB ? vsum : 0.5 * vsum;
+}
+
 // Persistent launch: `gridDim.x` workgroups pull tiles (x block, k2 chunk, row) from an atomic counter.  The grid
 // is sized to a few workgroups per CU (zd_plan: gen_wgs_per_cu) so that the HBM-bound k_zfft of the previous
 // slab, running on the second stream, always finds registers and LDS next to the generator's waves.
-template <int ZR, int KIND, bool PLAW>
+template <int ZR, int KIND, bool PLAW, bool MIRROR>
 __global__ __launch_bounds__(GEN_BX) void k_genf(GenConst g, GenJumps J, StoreLayout S, int zW, int ky0, int kyl0, int nky,
                                                  int nrows, int L, int residue, int residue2,
                                                  const cplx *__restrict__ twN, cplx *__restrict__ Y,
@@ -900,7 +1077,7 @@ __global__ __launch_bounds__(GEN_BX) void k_genf(GenConst g, GenJumps J, StoreLa
     for (int i = threadIdx.x; i < g.genf_n / 2; i += GEN_BX)
         reinterpret_cast<double2 *>(T)[i] = reinterpret_cast<const double2 *>(g.genf_tab)[i];
     unsigned *slot = reinterpret_cast<unsigned *>(T + g.genf_n);
-    const int gx = (g.N + GEN_BX - 1) / GEN_BX, gy = L / ZR;
+    const int gx = ((MIRROR ? g.N / 2 + 1 : g.N) + GEN_BX - 1) / GEN_BX, gy = L / ZR;
     const unsigned ntiles = (unsigned) (gx * gy * nrows);
     double vsum = 0.0;
     for (;;) {
@@ -910,7 +1087,10 @@ __global__ __launch_bounds__(GEN_BX) void k_genf(GenConst g, GenJumps J, StoreLa
         const unsigned tile = *slot;
         if (tile >= ntiles) break;
         const int bx = tile % gx, by = (tile / gx) % gy, bz = tile / (gx * gy);
-        vsum += genf_tile<ZR, KIND, PLAW>(g, J, S, T, zW, ky0, kyl0 + bz, nky, L, residue, residue2, bx, by, twN, Y);
+        if constexpr (MIRROR)
+            vsum += genf_tile_mirror<ZR, KIND, PLAW>(g, J, S, T, zW, ky0, kyl0 + bz, nky, L, residue, residue2, bx, by, twN, Y);
+        else
+            vsum += genf_tile<ZR, KIND, PLAW>(g, J, S, T, zW, ky0, kyl0 + bz, nky, L, residue, residue2, bx, by, twN, Y);
     }
     if (g.accum_var) {  // every lane is back here: wave sum, one atomic per wave; rows ky >= 1 stand for their twins too
 #pragma unroll
@@ -1453,11 +1633,23 @@ static int launch_genf_t(const GenConst &g, const GenJumps &J, const StoreLayout
                          int L, int residue, int residue2, const void *twN, void *Y, unsigned *tile_ctr, int max_wgs,
                          hipStream_t st) {
     const int N = g.N;
-    const long long ntiles = (long long) ((N + GEN_BX - 1) / GEN_BX) * (L / GEN_ZR) * nrows;
+    constexpr bool za = KIND == GENF_DENS || KIND == GENF_ZA || KIND == GENF_ZAP;
+    static const bool mirror_off = getenv("ZD_GEN_NO_MIRROR") != nullptr;
+    const bool mirror = za && !mirror_off;
+    const int gx = ((mirror ? N / 2 + 1 : N) + GEN_BX - 1) / GEN_BX;
+    const long long ntiles = (long long) gx * (L / GEN_ZR) * nrows;
     dim3 grid((unsigned) std::min<long long>(ntiles, max_wgs)), block(GEN_BX);
-    hipLaunchKernelGGL((k_genf<GEN_ZR, KIND, PLAW>), grid, block, sizeof(double) * (size_t) (g.genf_n + 2), st, g, J, S,
-                       zfft_tile_width(L), ky0, kyl0, nky, nrows, L, residue, residue2, (const cplx *) twN, (cplx *) Y,
-                       tile_ctr);
+    const size_t shmem = sizeof(double) * (size_t) (g.genf_n + 2);
+    if constexpr (za) {
+        if (mirror) {
+            hipLaunchKernelGGL((k_genf<GEN_ZR, KIND, PLAW, true>), grid, block, shmem, st, g, J, S, zfft_tile_width(L), ky0, kyl0,
+                               nky, nrows, L, residue, residue2, (const cplx *) twN, (cplx *) Y, tile_ctr);
+            ZD_LAUNCH_CHECK();
+            return 0;
+        }
+    }
+    hipLaunchKernelGGL((k_genf<GEN_ZR, KIND, PLAW, false>), grid, block, shmem, st, g, J, S, zfft_tile_width(L), ky0, kyl0, nky,
+                       nrows, L, residue, residue2, (const cplx *) twN, (cplx *) Y, tile_ctr);
     ZD_LAUNCH_CHECK();
     return 0;
 }
