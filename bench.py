@@ -124,7 +124,7 @@ def main():
     free_b, total_b = torch.cuda.mem_get_info()
     R = args.stream
     if R <= 0:
-        budget = int(free_b) - (12 << 30)  # tables, ~1 GB folded-input slab, record ring, runtime
+        budget = int(free_b) - (16 << 30)  # tables, ~3 GB of folded-input slabs, 8 GB record ring, runtime
         if world > 1:  # every rank must arrive at the same R: use the smallest budget of the job
             t = torch.tensor([budget], dtype=torch.int64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MIN)

@@ -798,8 +798,8 @@ int zd_generate(const zd_params *p_in, const zd_pk *pk, const double *eig, int64
     size_t free_b = 0, total_b = 0;
     HIPCHECK(hipMemGetInfo(&free_b, &total_b));
     if (p.stream_factor <= 0) {
-        // leave 12 GB for tables, the folded-input slab (~1 GB), the record ring and the runtime
-        const int64_t budget = (int64_t) free_b - ((int64_t) 12 << 30);
+        // leave 16 GB for tables, the folded-input slabs (~3 GB), the record ring (8 GB) and the runtime
+        const int64_t budget = (int64_t) free_b - ((int64_t) 16 << 30);
         const int R = zd_choose_stream_factor(&p, 1, budget);
         if (R < 0) {
             fprintf(stderr, "zeldovich_hip: PPD %lld does not fit in %.1f GB of free HBM at any stream factor\n",
@@ -841,7 +841,7 @@ int zd_generate(const zd_params *p_in, const zd_pk *pk, const double *eig, int64
         }
         HIPCHECK(hipMemGetInfo(&free_b, &total_b));
         if (p_in->stream_factor <= 0) {
-            const int R2 = zd_choose_stream_factor(&p, 1, (int64_t) free_b - ((int64_t) 12 << 30));
+            const int R2 = zd_choose_stream_factor(&p, 1, (int64_t) free_b - ((int64_t) 16 << 30));
             if (R2 < 0) {
                 hipFree(d_phik);
                 return 1;
@@ -866,7 +866,10 @@ int zd_generate(const zd_params *p_in, const zd_pk *pk, const double *eig, int64
     hipStream_t st = 0;
     // planes handed over per x-stage launch (a multiple of the plane step)
     const int64_t plane_b = N * N * (int64_t) (want_rec ? recsize : 0) + (want_dens ? N * N * 4 : 0);
-    int chunk = (int) std::max<int64_t>(1, std::min<int64_t>(Pp, ((int64_t) 512 << 20) / std::max<int64_t>(plane_b, 1)));
+    // (with a host callback the ring is mirrored in pinned host memory: 1 GB; the NULL sink takes 8 GB so that an
+    // x-stage launch covers several planes even at PPD=4096, where one plane of records is 537 MB)
+    const int64_t ring_b = cb ? ((int64_t) 1 << 30) : ((int64_t) 8 << 30);
+    int chunk = (int) std::max<int64_t>(1, std::min<int64_t>(Pp, ring_b / std::max<int64_t>(plane_b, 1)));
     chunk     = std::max(pstep, chunk / pstep * pstep);
     std::chrono::steady_clock::time_point t0;
     do {

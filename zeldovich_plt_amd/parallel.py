@@ -48,7 +48,10 @@ class HipEngine:
 class SlabPipeline:
     """Runs residue passes: Z stage -> all-to-all -> y FFT -> x FFT + epilogue in plane chunks."""
 
-    def __init__(self, engine, ppd, world=1, dist=None, device="cpu", chunk_bytes=512 << 20):
+    def __init__(self, engine, ppd, world=1, dist=None, device="cpu", chunk_bytes=8 << 30):
+        # chunk_bytes: size of the record ring = planes finished per x-stage launch.  At PPD=4096 one plane of RVZel
+        # records is 537 MB; launches of a single store plane (4096 workgroups, 16 per CU) lose 13 % to launch tails
+        # (k_xfft 0.89 -> 0.77 s per step with 8 GB).
         self.e = engine
         self.ppd = ppd
         self.world = world
