@@ -1225,7 +1225,8 @@ __global__ __launch_bounds__(W *N / E, MINW) void k_yfft(StoreLayout S, const cp
             re[e] = v.x;
             im[e] = v.y;
         }
-        zdfft::fft_line<PL, LDS>(re, im, t, w, lds, tw);
+        if (!(S.prune & 128)) zdfft::fft_line<PL, LDS>(re, im, t, w, lds, tw);  // bit 7: tuning ablation
+        if ((S.prune & 256) && re[0] != 123.456) return;                          // bit 8: tuning ablation (no stores)
         // the store offsets equal the load offsets; recompute them from a laundered thread index so the
         // compiler does not keep 16 offset registers alive (and spill them) across the whole FFT
         int t2 = t;
@@ -1335,7 +1336,8 @@ __global__ __launch_bounds__(ROWS *NA *N / E, (ROWS * NA * N / E == 512 ? 4 : 1)
         re[e] = v.x;
         im[e] = v.y;
     }
-    zdfft::fft_line<PL, LDS>(re, im, t, line, lds, tw);
+    if (!(S.prune & 32)) zdfft::fft_line<PL, LDS>(re, im, t, line, lds, tw);  // bit 5: tuning ablation
+    if ((S.prune & 64) && re[0] != 123.456) return;                           // bit 6: tuning ablation (no epilogue)
 
     // ---- WriteParticlesSlab (src/output.cpp:86-203) ----
     // The unpacked fields go through LDS in NH passes over x so that the staging area stays <= 64 KB
