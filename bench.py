@@ -231,6 +231,11 @@ def main():
             "kernels": per_kernel,
             "kernels_isolated": isolated,
         }
+        if isolated and all(isolated.get(k, {}).get("ms_per_step", 0) > 0 for k in alg):
+            # the FFT + displacement part of the pass (the three HBM-bound kernels alone), priced like the whole path
+            ms_fft = sum(isolated[k]["ms_per_step"] for k in alg)
+            rate = (64.0 * narray + recsize) * particles / (ms_fft * 1e-3) / 1e9
+            out["fft_passes_isolated"] = {"ms_per_step": ms_fft, "alg_GBps": rate, "frac": rate / HBM_PEAK_GBS}
         if isolated and isolated.get(dom, {}).get("alg_GBps"):
             out["roofline"]["isolated_achieved"] = isolated[dom]["alg_GBps"]
             out["roofline"]["isolated_frac"] = isolated[dom]["alg_GBps"] / HBM_PEAK_GBS
