@@ -382,6 +382,18 @@ def test_full_size_properties_ppd4096_vs_2048(zd, ps, monkeypatch):
     assert 0.5 < rms / pred < 1.5
 
 
+def test_large_plt_packed_vs_reference_arrays(zd, oracle, ps, monkeypatch):
+    """PPD=1024 PLT+rescale (interpolated eigenmodes, two passes): the packed 3-array store and the reference's 4
+    arrays give the same reductions"""
+    eig = oracle.synthetic_eigenmodes(64)
+    kw = dict(qPLT=1, qPLTrescale=1, PLT_target_z=5.0, z_initial=49.0, icformat="RVZel", stream_factor=2)
+    a = zd.generate(zd.make_params(1024, **kw), ps, eig=eig, collect=False)
+    monkeypatch.setenv("ZD_NO_PACK", "1")
+    b = zd.generate(zd.make_params(1024, **kw), ps, eig=eig, collect=False)
+    assert abs(a["density_variance"] - b["density_variance"]) <= 1e-11 * b["density_variance"]
+    assert np.abs(a["max_disp"] - b["max_disp"]).max() <= 1e-11 * np.abs(b["max_disp"]).max()
+
+
 @pytest.mark.parametrize("n,kw", [(64, dict()), (64, dict(stream_factor=2)), (128, dict(k_cutoff=2.0))])
 def test_fnl_end_to_end(zd, oracle, ps, wmap_path, n, kw):
     """local primordial non-Gaussianity (next-row f.2): phi = D/M -> phi + f_NL phi^2 -> D = phi M, then the
