@@ -166,9 +166,9 @@ def main():
     # (in the timed region k_gen and k_zfft share it, so their hipEvent spans there include each other)
     iso = None
     if world == 1 and not args.no_isolated:
-        os.environ["ZD_NO_OVERLAP"] = "1"
+        p.serial_z = 1
         plan_iso = zd.Plan(p, ps, eig=eig, rank=0, nranks=1)
-        del os.environ["ZD_NO_OVERLAP"]
+        p.serial_z = 0
         pipe.e = HipEngine(plan_iso, N)
         pipe.run()
         torch.cuda.synchronize()

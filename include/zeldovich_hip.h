@@ -48,9 +48,22 @@ typedef struct zd_params {
     /* --- optional MI355X knobs (0 = let the library decide); not present in the reference --- */
     int32_t stream_factor; /* R: number of z-residue passes (power of two) */
     int32_t profile;       /* 1: bracket every kernel with hipEvents and report per-kernel ms */
+    int32_t store_mode;    /* ZD_STORE_*: what the block store between the z and y passes holds (0 = best available) */
+    int32_t serial_z;      /* 1: generator and z FFT on ONE stream (per-kernel timing runs); 0: two overlapped streams */
+    int32_t ngpu;          /* ZD_NumGPU: GPUs of this node that zd_generate / the CLI drive (0 or 1 = one) */
     /* --- local primordial non-Gaussianity (include/parameters.h:56-58); f_NL = 0 disables the path --- */
     double f_NL, n_s, Omega_M;
 } zd_params;
+
+/* zd_params.store_mode */
+enum {
+    ZD_STORE_AUTO = 0,
+    ZD_STORE_REFERENCE = 1, /* the reference's 1 / 2 / 4 complex arrays (density transformed; include/block_array.h:26-35) */
+    ZD_STORE_PACKED = 2,    /* 3 arrays without the density field: ZA two z-residues per pass, PLT qx+i vx | qy+i qz | vy+i vz */
+    ZD_STORE_FIELDS = 3     /* ZA only: the two potentials E = sum D/k^2, Z = sum kz D/k^2 of two z-residues for the
+                             * half-space rows (no Hermitian twins), zero columns not stored; the y pass derives the
+                             * displacement arrays plane by plane */
+};
 
 /* PowerSpectrum state after InitFromFile/InitFromPowerLaw + Normalize (src/power_spectrum.cpp:130-223).
  * Tables are the (ln k, ln P, y'') arrays of SplineFunction (include/spline_function.h). */
@@ -183,12 +196,6 @@ int zd_test_modes(const zd_params *p, const zd_pk *pk, int64_t n, const int32_t 
 /* batch of `lines` independent length-n inverse FFTs, host in/out [lines][n] complex double;
  * axis_kind 0: the contiguous-line kernel path (x pass), 1: the strided-line path (y/z passes) */
 int zd_test_fft(int32_t n, int64_t lines, int32_t axis_kind, const double *in, double *out);
-/* tuning harness: ms per launch of y-pass tile variant `variant` on a synthetic store of nplanes planes */
-int zd_test_yfft_variant(int32_t n, int32_t variant, int32_t narray, int32_t nplanes, int32_t tiled, int32_t reps,
-                         double *ms_per_launch);
-/* device copy bandwidth probe: bytes moved per second by a 16 B/lane streaming copy of `bytes` */
-int zd_test_copy_bw(int64_t bytes, int32_t reps, double *gbps);
-
 #ifdef __cplusplus
 }
 #endif

@@ -50,3 +50,39 @@ def test_missing_library_fails_loudly(monkeypatch):
         assert "no CPU fallback" in str(e)
     else:
         raise AssertionError("load_library() must raise when the HIP library is missing")
+
+
+def test_product_library_has_no_tuning_switches():
+    """the ablation / tuning environment knobs and harness exports exist only in the -DZD_TUNING build"""
+    import subprocess
+    import zeldovich_plt_amd.api as api
+    blob = open(api.LIB_PATH, "rb").read()
+    for name in (b"ZD_ABLATE", b"ZD_PRUNE", b"ZD_NT", b"ZD_LAYOUT", b"ZD_PAD", b"ZD_SLAB_MB", b"ZD_GEN_WGS", b"ZD_Y_AHEAD",
+                 b"ZD_Y_SLABS", b"ZD_GEN_NO_MIRROR", b"ZD_GEN_GENERAL", b"ZD_NO_PKTAB", b"ZD_NO_PACK", b"ZD_NO_OVERLAP"):
+        assert name not in blob, name
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", api.LIB_PATH], text=True)
+    assert "zd_test_yfft_variant" not in syms and "zd_test_copy_bw" not in syms
+    assert "getenv" not in subprocess.check_output(["nm", "-D", "--undefined-only", api.LIB_PATH], text=True)
+
+
+def test_trans_hazard_checker_detects_back_to_back_use():
+    """check_trans_hazard.py (run on the shipped ISA by build()): flags a TRANS result read in the next issue slot,
+    accepts an intervening instruction or s_nop"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "check_trans_hazard", os.path.join(ROOT, "zeldovich_plt_amd", "csrc", "check_trans_hazard.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    bad = """
+0000000000001000 <k_demo>:
+	v_rcp_f64_e32 v[22:23], v[20:21]        // 000000001000: 7E2C4B14
+	v_fma_f64 v[6:7], v[70:71], v[22:23], v[6:7]   // 000000001004: D1CC0006
+	v_rsq_f64_e32 v[2:3], v[4:5]            // 00000000100C: 7E2C4B14
+	s_nop 0                                 // 000000001010: BF800000
+	v_mul_f64 v[8:9], v[2:3], v[2:3]        // 000000001014: D2810008
+	v_sqrt_f64_e32 v[30:31], v[4:5]         // 00000000101C: 7E2C4B14
+	v_add_f64 v[40:41], v[4:5], v[4:5]      // 000000001020: D2810008
+	v_mul_f64 v[8:9], v[30:31], v[2:3]      // 000000001028: D2810008
+"""
+    n, viol = m.check(bad)
+    assert n == 3 and len(viol) == 1 and "v_rcp_f64" in viol[0][1]

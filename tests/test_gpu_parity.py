@@ -34,12 +34,6 @@ def opk(oracle, wmap_path):
     return oracle.pk_from_file(wmap_path, 720.0)
 
 
-def test_copy_bandwidth_probe(zd):
-    bw = zd.copy_bandwidth(1 << 30, 5)
-    print("copy GB/s", bw)
-    assert bw > 500
-
-
 def test_draws_bit_exact(zd, oracle):
     """counter-addressed pcg64 draws == sequential reference stream"""
     import ctypes as C
@@ -274,7 +268,7 @@ def test_multirank_layout_on_one_gpu(zd, oracle, ps, opk, world, R, plt):
 
 
 @pytest.mark.parametrize("plt", [False, True])
-def test_packed_store_matches_reference_arrays(zd, oracle, ps, monkeypatch, plt):
+def test_packed_store_matches_reference_arrays(zd, oracle, ps, plt):
     """without ZD_qdensity the density field is not transformed (3 packed arrays; ZA: two residues per pass;
     density_variance from sum |D|^2): records and statistics equal those of the reference's 2 / 4 arrays"""
     n = 128
@@ -285,7 +279,7 @@ def test_packed_store_matches_reference_arrays(zd, oracle, ps, monkeypatch, plt)
     assert plan.narray == 3 and plan.plane_step == (1 if plt else 2) and plan.passes == (4 if plt else 2)
     plan.close()
     a = zd.generate(p, ps, eig=eig)
-    monkeypatch.setenv("ZD_NO_PACK", "1")
+    p = zd.make_params(n, icformat="RVdoubleZel", stream_factor=4, store_mode="reference", **kw)
     plan = zd.Plan(p, ps, eig=eig)
     assert plan.narray == (4 if plt else 2) and plan.plane_step == 1 and plan.passes == 4
     plan.close()
@@ -365,7 +359,7 @@ def test_parseval_oversampling_property(zd, ps):
     assert abs(b["density_variance"] / a["density_variance"] - 8.0) < 1e-12
 
 
-def test_full_size_properties_ppd4096_vs_2048(zd, ps, monkeypatch):
+def test_full_size_properties_ppd4096_vs_2048(zd, ps):
     """BASELINE sizes through size-independent properties (no oracle run is feasible at 6.9e10 particles):
     PPD=4096 with k_cutoff=2 is phase-matched to PPD=2048 (README :52-54 of the reference) -> exactly 8x the sum of
     dens^2; the packed store (two residues per pass, Parseval) and the reference's two arrays agree at PPD=2048;
@@ -373,8 +367,7 @@ def test_full_size_properties_ppd4096_vs_2048(zd, ps, monkeypatch):
     a = zd.generate(zd.make_params(2048, icformat="RVZel"), ps, collect=False)
     b = zd.generate(zd.make_params(4096, k_cutoff=2.0, icformat="RVZel"), ps, collect=False)
     assert abs(b["density_variance"] / a["density_variance"] - 8.0) < 1e-11
-    monkeypatch.setenv("ZD_NO_PACK", "1")
-    c = zd.generate(zd.make_params(2048, icformat="RVZel"), ps, collect=False)
+    c = zd.generate(zd.make_params(2048, icformat="RVZel", store_mode="reference"), ps, collect=False)
     assert abs(a["density_variance"] - c["density_variance"]) <= 1e-11 * c["density_variance"]
     assert np.abs(a["max_disp"] - c["max_disp"]).max() <= 1e-11 * np.abs(c["max_disp"]).max()
     rms = np.sqrt(a["density_variance"] / 2048.0 ** 3)
@@ -382,14 +375,13 @@ def test_full_size_properties_ppd4096_vs_2048(zd, ps, monkeypatch):
     assert 0.5 < rms / pred < 1.5
 
 
-def test_large_plt_packed_vs_reference_arrays(zd, oracle, ps, monkeypatch):
+def test_large_plt_packed_vs_reference_arrays(zd, oracle, ps):
     """PPD=1024 PLT+rescale (interpolated eigenmodes, two passes): the packed 3-array store and the reference's 4
     arrays give the same reductions"""
     eig = oracle.synthetic_eigenmodes(64)
     kw = dict(qPLT=1, qPLTrescale=1, PLT_target_z=5.0, z_initial=49.0, icformat="RVZel", stream_factor=2)
     a = zd.generate(zd.make_params(1024, **kw), ps, eig=eig, collect=False)
-    monkeypatch.setenv("ZD_NO_PACK", "1")
-    b = zd.generate(zd.make_params(1024, **kw), ps, eig=eig, collect=False)
+    b = zd.generate(zd.make_params(1024, store_mode="reference", **kw), ps, eig=eig, collect=False)
     assert abs(a["density_variance"] - b["density_variance"]) <= 1e-11 * b["density_variance"]
     assert np.abs(a["max_disp"] - b["max_disp"]).max() <= 1e-11 * np.abs(b["max_disp"]).max()
 

@@ -33,6 +33,7 @@ class ZdParams(C.Structure):
         ("qoneslab", C.c_int32), ("qonemode", C.c_int32), ("one_mode", C.c_int32 * 3),
         ("qPLT", C.c_int32), ("qPLTrescale", C.c_int32), ("icformat", C.c_int32),
         ("stream_factor", C.c_int32), ("profile", C.c_int32),
+        ("store_mode", C.c_int32), ("serial_z", C.c_int32), ("ngpu", C.c_int32),
         ("f_NL", C.c_double), ("n_s", C.c_double), ("Omega_M", C.c_double),
     ]
 
@@ -75,8 +76,9 @@ EXPORTED_SYMBOLS = [
     "zd_plan_plane_z", "zd_plan_stage_z", "zd_plan_stage_y", "zd_plan_stage_x", "zd_plan_stats",
     "zd_params_from_file", "zd_pk_create_from_file", "zd_pk_create_powerlaw", "zd_pk_power",
     "zd_pk_sigmaR", "zd_pk_destroy", "zd_load_eigmodes", "zd_free", "zd_test_draws", "zd_test_modes",
-    "zd_test_fft", "zd_test_yfft_variant", "zd_test_copy_bw",
+    "zd_test_fft",
 ]
+STORE_MODES = {"auto": 0, "reference": 1, "packed": 2, "fields": 3}  # zd_params.store_mode (ZD_STORE_*)
 
 _lib = None
 
@@ -130,8 +132,6 @@ def load_library():
     L.zd_test_draws.argtypes = [i64, i64, vp, vp]
     L.zd_test_modes.argtypes = [C.POINTER(ZdParams), C.POINTER(ZdPk), i64, vp, vp]
     L.zd_test_fft.argtypes = [i32, i64, i32, vp, vp]
-    L.zd_test_copy_bw.argtypes = [i64, i32, C.POINTER(dbl)]
-    L.zd_test_yfft_variant.argtypes = [i32, i32, i32, i32, i32, i32, C.POINTER(dbl)]
     _lib = L
     return L
 
@@ -139,7 +139,7 @@ def load_library():
 def make_params(ppd, numblock=2, boxsize=720.0, seed=12346, k_cutoff=1.0, qPLT=0, qPLTrescale=0,
                 PLT_target_z=0.0, z_initial=49.0, f_cluster=1.0, icformat="RVdoubleZel", qdensity=0,
                 qoneslab=-1, qonemode=0, one_mode=(0, 0, 0), corner_modes=0, cpd=None, stream_factor=0,
-                profile=0, f_NL=0.0, n_s=1.0, Omega_M=1.0):
+                profile=0, f_NL=0.0, n_s=1.0, Omega_M=1.0, store_mode="auto", serial_z=0, ngpu=0):
     """Parameters with the derived quantities of Parameters::setup (src/parameters.cpp:172-174)."""
     p = ZdParams()
     p.ppd = ppd
@@ -163,6 +163,9 @@ def make_params(ppd, numblock=2, boxsize=720.0, seed=12346, k_cutoff=1.0, qPLT=0
     p.icformat = ICFORMATS[icformat]
     p.stream_factor = stream_factor
     p.profile = profile
+    p.store_mode = STORE_MODES[store_mode] if isinstance(store_mode, str) else int(store_mode)
+    p.serial_z = serial_z
+    p.ngpu = ngpu
     p.f_NL, p.n_s, p.Omega_M = f_NL, n_s, Omega_M
     return p
 
@@ -365,11 +368,3 @@ def test_fft(x, axis_kind):
     if rc:
         raise RuntimeError("zd_test_fft failed")
     return out
-
-
-def copy_bandwidth(nbytes=1 << 30, reps=10):
-    L = load_library()
-    g = C.c_double()
-    if L.zd_test_copy_bw(nbytes, reps, C.byref(g)):
-        raise RuntimeError("zd_test_copy_bw failed")
-    return g.value

@@ -12,6 +12,10 @@
 #include "../../include/zeldovich_hip.h"
 #include "zd_device.h"
 #include "zd_launch.h"
+#include "zd_plan.h"
+#ifdef ZD_TUNING
+#include "zd_tuning.h"
+#endif
 
 using zdfft::cplx;
 using zdpcg::u128;
@@ -28,12 +32,17 @@ using zdpcg::u128;
 
 namespace {
 
-struct EventPair {
-    hipEvent_t a, b;
-    int kind;
-};
 
 bool is_pow2(int64_t n) { return n > 0 && (n & (n - 1)) == 0; }
+
+// Tuning / ablation knobs (environment variables ZD_ABLATE, ZD_PRUNE, ZD_NT, ZD_LAYOUT, ...) exist only in the
+// -DZD_TUNING build (make tuning -> build/libzeldovich_hip_tuning.so, used by scripts/ through ZD_LIB_PATH).
+// The product library never reads the environment: the names below do not even reach its binary.
+#ifdef ZD_TUNING
+const char *tune_env(const char *name) { return getenv(name); }
+#else
+#define tune_env(name) ((const char *) nullptr)
+#endif
 
 std::vector<cplx> make_twiddles(int n) {
     std::vector<cplx> tw(n);
@@ -106,52 +115,6 @@ int record_size(int icformat) {  // include/output.h:19-42
 
 }  // namespace
 
-struct zd_plan {
-    zd_params p;
-    int rank = 0, nranks = 1;
-    int N = 0, half = 0, narray = 0, R = 1, L = 0, Hq = 0, Zq = 0;
-    int pack = zd::PACK_NONE;  // what the store holds (zd_device.h PACK_*)
-    int npass = 1, pstep = 1;  // passes per run; planes a store plane delivers (2 with PACK_ZAPAIR)
-    bool var_pending = true;   // packed stores: the next Z stage accumulates sum |D|^2
-    zd::GenConst g;
-    zd::GenJumps J;
-    zd::JobList jobs;
-    zd::StoreLayout S;
-    zd::EpiConst ec;
-    // device tables
-    double *d_pk = nullptr;  // x | y | y2
-    int *d_lut = nullptr;
-    double *d_pktab = nullptr;
-    double *d_fnlM = nullptr;  // f_NL: M(k) by integer |k|^2
-    double *d_eig = nullptr;
-    u128 *d_rowstate = nullptr;
-    cplx *d_twN = nullptr, *d_twL = nullptr;
-    double *d_genf = nullptr;  // LDS image of k_genf
-    unsigned *d_tilectr = nullptr;  // one work counter per k_genf launch of a pass
-    int n_tilectr = 0, gen_max_wgs = 0;
-    zd::Reduce *d_red = nullptr;
-    // folded FFT inputs of one slab of half-space rows: Y[job][row][k2][x]; double-buffered so that
-    // k_gen (VALU-bound) of slab s+1 runs beside k_zfft (HBM-bound) of slab s on a second stream
-    // folded FFT inputs: a ring of slabs Y[job][row][k2][x].  Two slabs suffice for the gen || zfft overlap inside a
-    // pass; whatever HBM the store leaves free holds more of them, so that the (VALU-bound) generator of pass p+1
-    // runs ahead on its own stream while the (HBM-bound) y and x passes of pass p are still working
-    std::vector<cplx *> d_Y;
-    std::vector<hipEvent_t> ev_gen, ev_fft;
-    int slab_rows = 0;        // rows generated per k_gen launch
-    long long next_g = 0;     // running slab number: slab g lives in ring slot g % K
-    int ahead_pass = -1;      // pass whose first `ahead_n` slabs (numbers ahead_g0...) are already being generated
-    long long ahead_g0 = 0;
-    int ahead_n = 0;
-    hipStream_t s_gen = nullptr, s_fft = nullptr;
-    hipEvent_t ev_fork = nullptr;
-    bool overlap = true;
-    // timing
-    std::vector<EventPair> events;
-    std::vector<hipEvent_t> pool;
-    double kernel_ms[ZD_K_COUNT] = {0, 0, 0, 0};
-    int64_t launches[ZD_K_COUNT] = {0, 0, 0, 0};
-};
-
 namespace {
 
 void tick(zd_plan *pl, int kind, hipStream_t st, bool begin) {
@@ -206,10 +169,19 @@ extern "C" {
 
 // Packed stores (zd_device.h PACK_*): without ZD_qdensity the density field is not transformed.
 static int pack_mode(const zd_params *p, int R) {
-    if (getenv("ZD_NO_PACK")) return zd::PACK_NONE;
+    if (p->store_mode == ZD_STORE_REFERENCE) return zd::PACK_NONE;
     if (p->qdensity != 0 || p->f_NL != 0.) return zd::PACK_NONE;
     if (p->qoneslab >= 0) return zd::PACK_NONE;  // density_variance is then the sum over that one slab (output.cpp:197)
     if (p->ppd > 4096) return zd::PACK_NONE;  // the x pass of 3 arrays at PPD=8192 needs > 160 KB of LDS
+    {   // The packed stores treat every field as the transform of a REAL field (Hermitian modes) and take
+        // density_variance from sum |D|^2.  That needs every mode with a component on the Nyquist plane |k_i| = N/2 to
+        // be zero: the |k_i| == kmax rule does it when kmax == N/2 (k_cutoff = 1), the spherical cut when k_cutoff >= 1
+        // and CornerModes is off.  Otherwise (e.g. CornerModes with k_cutoff = 2) the reference keeps independent,
+        // non-Hermitian draws there and takes Re/Im of the mixed field (zeldovich.cpp:350-356): reference arrays.
+        const int half = (int) (p->ppd / 2), kmax = (int) ((double) half * (1.0 / p->k_cutoff) + .5);
+        const bool nyquist_dead = kmax == half || (!p->corner_modes && p->k_cutoff >= 1.0);
+        if (!nyquist_dead) return zd::PACK_NONE;
+    }
     if (p->qPLT) return zd::PACK_PLT3;
     return R >= 2 ? zd::PACK_ZAPAIR : zd::PACK_NONE;
 }
@@ -263,8 +235,9 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         fprintf(stderr, "zeldovich_hip: stream factor %d invalid for PPD %lld\n", R, (long long) N);
         return 1;
     }
-    if (nranks < 1 || rank < 0 || rank >= nranks || (N / 2) % nranks || (N / R) % nranks) {
-        fprintf(stderr, "zeldovich_hip: cannot split PPD %lld (R=%d) over %d ranks\n", (long long) N, R, nranks);
+    if (nranks < 1 || !is_pow2(nranks) || rank < 0 || rank >= nranks || (N / 2) % nranks || (N / R) % nranks) {
+        fprintf(stderr, "zeldovich_hip: cannot split PPD %lld (R=%d) over %d ranks (a power of two dividing PPD/2 and PPD/R is required)\n",
+                (long long) N, R, nranks);
         return 1;
     }
     zd_plan *pl = new zd_plan;
@@ -290,7 +263,7 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
     g.half         = pl->half;
     g.kmax         = (int) ((double) pl->half * (1.0 / p->k_cutoff) + .5);
     g.corner_modes = p->corner_modes;
-    g.ablate       = getenv("ZD_ABLATE") ? atoi(getenv("ZD_ABLATE")) : 0;
+    g.ablate       = tune_env("ZD_ABLATE") ? atoi(tune_env("ZD_ABLATE")) : 0;
     g.qonemode     = p->qonemode;
     for (int i = 0; i < 3; i++) g.one_mode[i] = p->one_mode[i];
     g.fundamental  = p->fundamental;
@@ -407,7 +380,7 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         // LDS image of k_genf (layout: GenfTab in zd_kernels.hip).  Spline tables beyond 512 segments do not
         // fit: such runs use the general generator.
         const int nseg = pk->is_powerlaw ? 0 : pk->n - 1;
-        if (nseg <= 512 && !getenv("ZD_GEN_GENERAL")) {
+        if (nseg <= 512 && !tune_env("ZD_GEN_GENERAL")) {
             std::vector<double> T = build_genf_table(pk, nseg, &g.glut_x0, &g.glut_inv_dx);
             PLCHECK(hipMalloc((void **) &pl->d_genf, sizeof(double) * T.size()));
             PLCHECK(hipMemcpy(pl->d_genf, T.data(), sizeof(double) * T.size(), hipMemcpyHostToDevice));
@@ -417,7 +390,7 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         }
     }
     // {P, 1/k^2} table over the integer |k|^2 that can carry power (zero rule of zeldovich.cpp:350-353)
-    if (!getenv("ZD_NO_PKTAB")) {
+    if (!tune_env("ZD_NO_PKTAB")) {
         const double half2 = (double) pl->half * pl->half;
         double nmax = p->corner_modes ? 3.0 * half2 : std::min(3.0 * half2, g.k2_cutoff / g.fundamental2 * (1 + 1e-9) + 2);
         const long long n = (long long) nmax + 2;
@@ -501,8 +474,8 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
     while ((1 << S.lG) < nranks) S.lG++;
     S.ky_stride = nranks;
     S.narray = pl->narray;
-    S.prune     = getenv("ZD_PRUNE") ? atoi(getenv("ZD_PRUNE")) : 7;  // bit 0 k_gen, 1 k_zfft, 2 k_yfft
-    S.nt = getenv("ZD_NT") ? atoi(getenv("ZD_NT")) : 0;
+    S.prune     = tune_env("ZD_PRUNE") ? atoi(tune_env("ZD_PRUNE")) : 7;  // bit 0 k_gen, 1 k_zfft, 2 k_yfft
+    S.nt = tune_env("ZD_NT") ? atoi(tune_env("ZD_NT")) : 0;
     if (phik) S.prune = 0;  // f_NL second pass: every mode carries power (the zero rule is bypassed)
     S.kmax      = g.kmax;
     S.fund2     = g.fundamental2;
@@ -514,7 +487,7 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         int lBk = (lt + 1) / 2, lBz = lt - lBk;
         S.rows_outer = 0;
         lBk = 20; lBz = 0;  // measured best on MI355X (profiles/r01_layout_sweep.txt): rows of one plane together
-        if (const char *env = getenv("ZD_LAYOUT")) {  // experimentation knob: "lBk,lBz,rows_outer"
+        if (const char *env = tune_env("ZD_LAYOUT")) {  // experimentation knob: "lBk,lBz,rows_outer"
             int a = lBk, b = lBz, o = 0;
             if (sscanf(env, "%d,%d,%d", &a, &b, &o) >= 2) {
                 lBk = a; lBz = b; S.rows_outer = o;
@@ -527,7 +500,7 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         S.lBz = lBz;
         S.one_block = (nranks == 1 && lBk == S.lHq + 1 && lBz == 0 && !S.rows_outer) ? 1 : 0;
         int row_pad = store_row_pad(pl->N);  // in complex elements
-        if (const char *env = getenv("ZD_PAD")) sscanf(env, "%d", &row_pad);
+        if (const char *env = tune_env("ZD_PAD")) sscanf(env, "%d", &row_pad);
         S.pitch      = pl->N + row_pad;
         S.a_rows     = (1 << lBk) << lBz;
         S.zb_rows    = S.a_rows * pl->narray;
@@ -550,12 +523,12 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
     {
         const int64_t row_b = y_bytes_per_row(pl);
         int64_t slab_b = (int64_t) 3 << 29;  // ~1.5 GB per buffer
-        if (const char *env = getenv("ZD_SLAB_MB")) slab_b = (int64_t) atoll(env) << 20;
+        if (const char *env = tune_env("ZD_SLAB_MB")) slab_b = (int64_t) atoll(env) << 20;
         int rows = (int) std::max<int64_t>(1, slab_b / row_b);
         rows     = std::min(rows, pl->Hq);
         while (pl->Hq % rows) rows--;
         pl->slab_rows = rows;
-        pl->overlap   = getenv("ZD_NO_OVERLAP") == nullptr;
+        pl->overlap   = p->serial_z == 0;
         // k_genf is a persistent kernel: a few workgroups per CU pull tiles from a counter (one per launch).  With
         // the second stream active the grid is kept small enough that a k_zfft workgroup (64 KB LDS, 2 waves/SIMD)
         // always fits beside the generator's waves on every CU.
@@ -564,7 +537,7 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
             hipGetDevice(&dev);
             hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
             int per_cu = pl->overlap ? 3 : 6;
-            if (const char *env = getenv("ZD_GEN_WGS")) per_cu = atoi(env);
+            if (const char *env = tune_env("ZD_GEN_WGS")) per_cu = atoi(env);
             pl->gen_max_wgs = std::max(1, per_cu) * std::max(1, ncu);
             pl->n_tilectr   = 2 * (pl->Hq / rows) + 2;  // per pass parity: the next pass's generator may already run
             PLCHECK(hipMalloc((void **) &pl->d_tilectr, sizeof(unsigned) * pl->n_tilectr));
@@ -577,14 +550,14 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
             // Measured (PPD=4096 ZA, 60 slabs ahead): no gain — the generator's resident workgroups take LDS and
             // registers from k_yfft (128 KB LDS per workgroup at PPD=4096), which slows down by what the z stage gains.
             // The larger ring therefore stays an experiment: ZD_Y_AHEAD=1 sizes it from free HBM, ZD_Y_SLABS=n fixes it.
-            if (getenv("ZD_Y_AHEAD") && pl->npass > 1 && nslab > 2) {
+            if (tune_env("ZD_Y_AHEAD") && pl->npass > 1 && nslab > 2) {
                 size_t free_b = 0, total_b = 0;
                 hipMemGetInfo(&free_b, &total_b);
                 const int64_t reserve = zd_plan_exchange_bytes(pl) * (nranks > 1 ? 2 : 1) + ((int64_t) 8 << 30);
                 const int64_t spare   = (int64_t) free_b - reserve;
                 if (spare > 0) K = (int) std::max<int64_t>(2, std::min<int64_t>(nslab, spare / (row_b * rows)));
             }
-            if (const char *env = getenv("ZD_Y_SLABS")) K = std::max(2, atoi(env));
+            if (const char *env = tune_env("ZD_Y_SLABS")) K = std::max(2, atoi(env));
         }
         pl->d_Y.assign(K, nullptr);
         for (int i = 0; i < K; i++) PLCHECK(hipMalloc((void **) &pl->d_Y[i], (size_t) row_b * rows));
@@ -1032,6 +1005,7 @@ int zd_test_fft(int32_t n, int64_t lines, int32_t axis_kind, const double *in, d
     return rc;
 }
 
+#ifdef ZD_TUNING
 // tuning harness (not part of the product path): time y-pass tile variants on a synthetic store
 int zd_test_yfft_variant(int32_t n, int32_t variant, int32_t narray, int32_t nplanes, int32_t tiled, int32_t reps,
                          double *ms_per_launch) {
@@ -1105,5 +1079,7 @@ int zd_test_copy_bw(int64_t bytes, int32_t reps, double *gbps) {
     hipFree(b);
     return rc;
 }
+
+#endif  // ZD_TUNING
 
 }  // extern "C"

@@ -7,6 +7,14 @@
 struct double2 { double x, y; };
 #endif
 
+// Ablation / tuning branches (GenConst::ablate, StoreLayout::prune bits >= 3, StoreLayout::nt) are compiled only
+// into the -DZD_TUNING library; in the product they fold to `false`.
+#ifdef ZD_TUNING
+#define ZD_TUNE(x) ((x) != 0)
+#else
+#define ZD_TUNE(x) (false)
+#endif
+
 namespace zd {
 
 constexpr int PK_LUT = 2048;

@@ -122,7 +122,7 @@ __device__ __forceinline__ void gauss_from_pk(const GenConst &g, double Pk, uint
                                               double &di) {
     double R           = zdpcg::u01(r1);
     const double theta = zdpcg::u01(r2);
-    if (g.ablate & 2) {
+    if ZD_TUNE(g.ablate & 2) {
         dr = R * Pk;
         di = theta * Pk;
         return;
@@ -139,7 +139,7 @@ __device__ __forceinline__ void gauss_from_pk(const GenConst &g, double Pk, uint
 template <bool PLAW>
 __device__ __forceinline__ void gauss_mode(const GenConst &g, double k2, uint64_t r1, uint64_t r2, double &dr,
                                            double &di) {
-    gauss_from_pk(g, (g.ablate & 1) ? 1e-9 * k2 : pk_power<PLAW>(g, k2), r1, r2, dr, di);
+    gauss_from_pk(g, ZD_TUNE(g.ablate & 1) ? 1e-9 * k2 : pk_power<PLAW>(g, k2), r1, r2, dr, di);
 }
 
 // interp_eigmode + get_eigenmode (src/zeldovich.cpp:154-276); out = e_x,e_y,e_z (weighted), lambda.
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, JobList 
             uint64_t r1, r2;
             if (ky != 0) {
                 r1 = zdpcg::output(s);
-                const u128 s2 = (g.ablate & 4) ? s + 12345 : zdpcg::step(s);
+                const u128 s2 = ZD_TUNE(g.ablate & 4) ? s + 12345 : zdpcg::step(s);
                 r2 = zdpcg::output(s2);
                 // next mode of the walk
                 int zb;
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, JobList 
                     zb = k2 + 1;
                     m  = &J.back[(z > half) != (zb > half)];
                 }
-                s = (g.ablate & 4) ? s2 + m->C : zdpcg::apply(*m, s2);
+                s = ZD_TUNE(g.ablate & 4) ? s2 + m->C : zdpcg::apply(*m, s2);
             } else {
                 if (z > half) {
                     zs = N - z;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, JobList 
                 if (g.pk_tab) {  // {P(k), 1/k^2} by integer k^2
                     const double2 pv = g.pk_tab[k2i];
                     ik2 = pv.y;
-                    gauss_from_pk(g, (g.ablate & 1) ? 1e-9 * k2v : pv.x, r1, r2, dr, di);
+                    gauss_from_pk(g, ZD_TUNE(g.ablate & 1) ? 1e-9 * k2v : pv.x, r1, r2, dr, di);
                 } else {
                     gauss_mode<PLAW>(g, k2v, r1, r2, dr, di);
                     ik2 = 1.0 / (k2v == 0.0 ? 1.0 : k2v);
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, JobList 
             double sx, sy, sz, f = 1.0;
             if constexpr (PLT) {
                 double e[4];
-                if (g.ablate & 8) {
+                if ZD_TUNE(g.ablate & 8) {
                     e[0] = kxm; e[1] = ky; e[2] = kzm; e[3] = 1.0 - 1e-9 * k2i;
                 } else {
                     const EigAxis eaz = eig_axis(g, eig_index_z(g, kzm));
@@ -482,11 +482,23 @@ struct GenfTab {  // offsets in doubles inside the LDS image (zd_capi.cpp: build
 // HAZARD: the compiler's hazard recognizer does not look at the operands of asm statements.  gfx950 needs a wait
 // state between a transcendental VALU op (v_rcp_f64, v_rsq_f64, ...) and the first read of its result; with an asm
 // v_fma_f64 as that first reader the wait state was missing whenever the scheduler happened to put the two back to
-// back: 1/k^2 (frcp) came out wrong and with it the displacements — 15 % off in the PLT kernel when the mode loop had
-// a lane-divergent `continue`, NaN in the packed ZA kernel after an if/else was added around the draw — while
-// every compiler-emitted path (density, sum |D|^2) stayed right; the parity tests caught both.  Rule: the FIRST
-// consumer of a __builtin_amdgcn_rcp / rsq result is a plain fma()/multiply (frcp, sqrt_pos below).
-// -DZD_NO_FMA_ASM builds the plain-fma() version of everything.
+// back (round 1: 1/k^2 wrong -> PLT displacements 15 % off, NaN in the packed ZA kernel; the parity tests caught both).
+// Two guards, neither by convention:
+//   * every transcendental builtin used next to asm FMAs goes through trans_rcp / trans_rsq below, which carry their
+//     own wait state (an `s_nop 0` tied to the result register: one issue cycle per reciprocal, ~3 per mode);
+//   * build() runs check_trans_hazard.py on the gfx950 ISA of this file: no instruction may read a TRANS result in
+//     the next issue slot.
+// -DZD_NO_FMA_ASM builds the plain-fma() version of everything (A/B parity runs).
+__device__ __forceinline__ double trans_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    asm volatile("s_nop 0" : "+v"(r));
+    return r;
+}
+__device__ __forceinline__ double trans_rsq(double d) {
+    double r = __builtin_amdgcn_rsq(d);
+    asm volatile("s_nop 0" : "+v"(r));
+    return r;
+}
 __device__ __forceinline__ double fma3(double a, double b, double c) {
 #ifdef ZD_NO_FMA_ASM
     return fma(a, b, c);
@@ -553,9 +565,7 @@ __device__ __forceinline__ double fexp(double x, const double *T) {
 }
 
 __device__ __forceinline__ double frcp(double d) {
-    double r = __builtin_amdgcn_rcp(d);
-    // plain fma: v_rcp_f64 is a transcendental op and gfx950 needs a wait state before its result is read; the
-    // compiler inserts it for its own instructions but does not look inside asm statements (see fma3)
+    double r = trans_rcp(d);
     const double e = fma(-d, r, 1.0);
     r = fma3(e, r, r);
     return fma3(fnma3(d, r, 1.0), r, r);
@@ -563,7 +573,7 @@ __device__ __forceinline__ double frcp(double d) {
 
 // sqrt(v) for v >= 0 (v = 0 -> 0); v is far from the subnormal range (P(k) |ln R| of a mode that carries power)
 __device__ __forceinline__ double sqrt_pos(double v) {
-    const double r = __builtin_amdgcn_rsq(v);
+    const double r = trans_rsq(v);
     double g = v * r, h = 0.5 * r;
     const double e = fnma3(h, g, 0.5);
     g = fma3(g, e, g);
@@ -678,8 +688,8 @@ __device__ __forceinline__ void eigenmode_fast(const GenConst &g, int kx, int ky
     }
     eh[2] *= (kz < 0 ? -1.0 : 1.0);
     const double n2 = eh[0] * eh[0] + eh[1] * eh[1] + eh[2] * eh[2];
-    double r = __builtin_amdgcn_rsq(n2);
-    r = r * fma(-0.5 * n2, r * r, 1.5);  // plain arithmetic right after the transcendental op (see fma3)
+    double r = trans_rsq(n2);
+    r = r * fma(-0.5 * n2, r * r, 1.5);
     r = r * fma(-0.5 * n2, r * r, 1.5);
     eh[0] *= r;
     eh[1] *= r;
@@ -763,7 +773,7 @@ __device__ __forceinline__ double genf_tile(const GenConst &g, const GenJumps &J
             s = zdpcg::apply(m, s2);
             // ---- cgauss<2> (power_spectrum.cpp:338-359); zeroed lanes of a live wave ride along with amplitude 0 ----
             const double k2v = (double) k2i * g.fundamental2;
-            const double P   = (g.ablate & 16) ? 1e-9 * k2v : genf_power<PLAW>(g, T, k2v);  // bit 4: tuning ablation
+            const double P   = ZD_TUNE(g.ablate & 16) ? 1e-9 * k2v : genf_power<PLAW>(g, T, k2v);  // bit 4: tuning ablation
             const double ik2 = frcp(k2v);
             const uint64_t m1 = r1 + 1ULL;  // one_rand<2>: u = (r + 1) 2^-64, and 1.0 for r = 2^64 - 1 (m = 0)
             double v = P;
@@ -1164,12 +1174,12 @@ __global__ __launch_bounds__(W *L / E) void k_zfft(JobList jobs, StoreLayout S, 
 #pragma unroll
     for (int e = 0; e < E; e++) {
         cplx v = cplx{1.0 + e, 2.0 * t};
-        if (!(S.prune & 8)) v = ld_stream(reinterpret_cast<const cplx *>(src + ((unsigned) (t + T * e) * rb + xb)), S.nt & 16);  // bit 3: ablation
+        if (!ZD_TUNE(S.prune & 8)) v = ld_stream(reinterpret_cast<const cplx *>(src + ((unsigned) (t + T * e) * rb + xb)), ZD_TUNE(S.nt & 16));  // bit 3: ablation
         re[e] = v.x;
         im[e] = v.y;
     }
     zdfft::fft_line<PL, LDS>(re, im, t, w, lds, twL);
-    if ((S.prune & 16) && re[0] != 123.456) return;  // bit 4: tuning ablation (skip stores)
+    if (ZD_TUNE(S.prune & 16) && re[0] != 123.456) return;  // bit 4: tuning ablation (skip stores)
 
     const int arr = jobs.arr[blockIdx.z];
     const bool st_self = !twin_only;
@@ -1186,8 +1196,8 @@ __global__ __launch_bounds__(W *L / E) void k_zfft(JobList jobs, StoreLayout S, 
         const int z2  = t2 + T * e;
         const int dst = z2 >> lZq, zl = z2 & (Zq - 1);  // Zq = 2^lZq
         const int row = store_row(S, dst, zl, arr, loc_self);
-        if (st_self) st_stream(out + ((long long) row * S.pitch + x), cplx{re[e], im[e]}, S.nt & 8);
-        if (st_twin) st_stream(out + ((long long) (row + drow) * S.pitch + xt), cplx{sgr * re[e], sgi * im[e]}, S.nt & 8);
+        if (st_self) st_stream(out + ((long long) row * S.pitch + x), cplx{re[e], im[e]}, ZD_TUNE(S.nt & 8));
+        if (st_twin) st_stream(out + ((long long) (row + drow) * S.pitch + xt), cplx{sgr * re[e], sgi * im[e]}, ZD_TUNE(S.nt & 8));
     }
 }
 
@@ -1221,12 +1231,12 @@ __global__ __launch_bounds__(W *N / E, MINW) void k_yfft(StoreLayout S, const cp
             const bool skip = (ky == N / 2) || ((S.prune & 4) && column_is_zero(S, kxs, ky > N / 2 ? ky - N : ky));
             const unsigned slot = ky < N / 2 ? ky : N / 2 + (N - ky);
             cplx v = cplx{0.0, 0.0};
-            if (!skip) v = ld_stream(reinterpret_cast<const cplx *>(base + (slot * pb + xb)), S.nt & 1);
+            if (!skip) v = ld_stream(reinterpret_cast<const cplx *>(base + (slot * pb + xb)), ZD_TUNE(S.nt & 1));
             re[e] = v.x;
             im[e] = v.y;
         }
-        if (!(S.prune & 128)) zdfft::fft_line<PL, LDS>(re, im, t, w, lds, tw);  // bit 7: tuning ablation
-        if ((S.prune & 256) && re[0] != 123.456) return;                          // bit 8: tuning ablation (no stores)
+        if (!ZD_TUNE(S.prune & 128)) zdfft::fft_line<PL, LDS>(re, im, t, w, lds, tw);  // bit 7: tuning ablation
+        if (ZD_TUNE(S.prune & 256) && re[0] != 123.456) return;                          // bit 8: tuning ablation (no stores)
         // the store offsets equal the load offsets; recompute them from a laundered thread index so the
         // compiler does not keep 16 offset registers alive (and spill them) across the whole FFT
         int t2 = t;
@@ -1235,7 +1245,7 @@ __global__ __launch_bounds__(W *N / E, MINW) void k_yfft(StoreLayout S, const cp
         for (int e = 0; e < E; e++) {
             const int y = t2 + T * e;
             const unsigned slot = y < N / 2 ? y : (y == N / 2 ? N / 2 : N / 2 + (N - y));
-            st_stream(reinterpret_cast<cplx *>(base + (slot * pb + xb)), cplx{re[e], im[e]}, S.nt & 2);
+            st_stream(reinterpret_cast<cplx *>(base + (slot * pb + xb)), cplx{re[e], im[e]}, ZD_TUNE(S.nt & 2));
         }
     } else {
         cplx *base = data + x;
@@ -1332,12 +1342,12 @@ __global__ __launch_bounds__(ROWS *NA *N / E, (ROWS * NA * N / E == 512 ? 4 : 1)
     double re[E], im[E];
 #pragma unroll
     for (int e = 0; e < E; e++) {
-        const cplx v = ld_stream(src + t + T * e, S.nt & 4);
+        const cplx v = ld_stream(src + t + T * e, ZD_TUNE(S.nt & 4));
         re[e] = v.x;
         im[e] = v.y;
     }
-    if (!(S.prune & 32)) zdfft::fft_line<PL, LDS>(re, im, t, line, lds, tw);  // bit 5: tuning ablation
-    if ((S.prune & 64) && re[0] != 123.456) return;                           // bit 6: tuning ablation (no epilogue)
+    if (!ZD_TUNE(S.prune & 32)) zdfft::fft_line<PL, LDS>(re, im, t, line, lds, tw);  // bit 5: tuning ablation
+    if (ZD_TUNE(S.prune & 64) && re[0] != 123.456) return;                           // bit 6: tuning ablation (no epilogue)
 
     // ---- WriteParticlesSlab (src/output.cpp:86-203) ----
     // The unpacked fields go through LDS in NH passes over x so that the staging area stays <= 64 KB
@@ -1597,11 +1607,14 @@ __global__ __launch_bounds__(W *N / E) void k_test_fft_lines(const cplx *__restr
     for (int e = 0; e < E; e++) out[line * N + t + T * e] = cplx{re[e], im[e]};
 }
 
+#ifdef ZD_TUNING
 __global__ void k_copy16(const uint4 *__restrict__ in, uint4 *__restrict__ out, long long n) {
     long long i      = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     const long long s = (long long) gridDim.x * blockDim.x;
     for (; i < n; i += s) out[i] = in[i];
 }
+
+#endif
 
 // ================================================================================================
 // launchers (C++ linkage inside the library; the C ABI lives in zd_capi.cpp)
@@ -1636,7 +1649,11 @@ static int launch_genf_t(const GenConst &g, const GenJumps &J, const StoreLayout
                          hipStream_t st) {
     const int N = g.N;
     constexpr bool za = KIND == GENF_DENS || KIND == GENF_ZA || KIND == GENF_ZAP;
+#ifdef ZD_TUNING
     static const bool mirror_off = getenv("ZD_GEN_NO_MIRROR") != nullptr;
+#else
+    constexpr bool mirror_off = false;
+#endif
     const bool mirror = za && !mirror_off;
     const int gx = ((mirror ? N / 2 + 1 : N) + GEN_BX - 1) / GEN_BX;
     const long long ntiles = (long long) gx * (L / GEN_ZR) * nrows;
@@ -1684,10 +1701,14 @@ static int genf_kind(const JobList &jobs, bool plt) {
 int launch_gen(const GenConst &g, const GenJumps &J, const JobList &jobs, const StoreLayout &S, int ky0, int nky, int L,
                int residue, int residue2, const void *twN, void *Y, unsigned *tile_ctr, int max_wgs, hipStream_t st) {
     if (L % GEN_ZR != 0) return 2;
+#ifdef ZD_TUNING
     static const bool force_general = getenv("ZD_GEN_GENERAL") != nullptr;
+#else
+    constexpr bool force_general = false;
+#endif
     // rows ky >= 1 of a production run go through k_genf; everything else through the general kernel
     const int kind = genf_kind(jobs, g.qPLT != 0);
-    const bool fast = g.genf_tab && tile_ctr && !g.phik && !g.gen_phi && !g.qonemode && !(g.ablate & 15) && !force_general
+    const bool fast = g.genf_tab && tile_ctr && !g.phik && !g.gen_phi && !g.qonemode && !ZD_TUNE(g.ablate & 15) && !force_general
                       && kind >= 0;
     int general_rows = nky;
     if (fast) {
@@ -1912,6 +1933,7 @@ int launch_test_fft(int n, int kind, const void *tw, const void *in, void *out, 
 }
 int test_fft_tile_width(int n) { return zfft_tile_width(n); }
 
+#ifdef ZD_TUNING
 // ---- tuning harness: the y pass in alternative tile shapes (zd_test_yfft_variant) ----
 template <int N, int E, int W, int MINW>
 static int launch_yfft_v(const StoreLayout &S, int nplanes, const void *tw, void *data, hipStream_t st) {
@@ -1933,6 +1955,8 @@ int launch_yfft_variant(int variant, const StoreLayout &S, int nplanes, const vo
 #undef VC
     return 2;
 }
+
+#endif  // ZD_TUNING
 
 int launch_fnl_table(const GenConst &g, int n, void *tab, hipStream_t st) {
     dim3 grid((n + 255) / 256), block(256);
@@ -1987,10 +2011,13 @@ int launch_fnl_stage(int which, const StoreLayout &S, double f_NL, const void *t
     return 2;
 }
 
+#ifdef ZD_TUNING
 int launch_copy16(const void *in, void *out, long long n16, hipStream_t st) {
     hipLaunchKernelGGL(k_copy16, dim3(256 * 8), dim3(256), 0, st, (const uint4 *) in, (uint4 *) out, n16);
     ZD_LAUNCH_CHECK();
     return 0;
 }
+
+#endif
 
 }  // namespace zd

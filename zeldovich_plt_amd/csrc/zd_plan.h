@@ -1,0 +1,60 @@
+// zd_plan.h — the plan object behind the staged C ABI (include/zeldovich_hip.h), shared by zd_capi.cpp (single-rank
+// stages) and zd_multi.cpp (the in-library multi-GPU driver).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "../../include/zeldovich_hip.h"
+#include "zd_device.h"
+
+struct EventPair {
+    hipEvent_t a, b;
+    int kind;
+};
+
+struct zd_plan {
+    zd_params p;
+    int rank = 0, nranks = 1;
+    int N = 0, half = 0, narray = 0, R = 1, L = 0, Hq = 0, Zq = 0;
+    int pack = zd::PACK_NONE;  // what the store holds (zd_device.h PACK_*)
+    int npass = 1, pstep = 1;  // passes per run; planes a store plane delivers (2 with PACK_ZAPAIR)
+    bool var_pending = true;   // packed stores: the next Z stage accumulates sum |D|^2
+    zd::GenConst g;
+    zd::GenJumps J;
+    zd::JobList jobs;
+    zd::StoreLayout S;
+    zd::EpiConst ec;
+    // device tables
+    double *d_pk = nullptr;  // x | y | y2
+    int *d_lut = nullptr;
+    double *d_pktab = nullptr;
+    double *d_fnlM = nullptr;  // f_NL: M(k) by integer |k|^2
+    double *d_eig = nullptr;
+    zdpcg::u128 *d_rowstate = nullptr;
+    zdfft::cplx *d_twN = nullptr, *d_twL = nullptr;
+    double *d_genf = nullptr;  // LDS image of k_genf
+    unsigned *d_tilectr = nullptr;  // one work counter per k_genf launch of a pass
+    int n_tilectr = 0, gen_max_wgs = 0;
+    zd::Reduce *d_red = nullptr;
+    // folded FFT inputs of one slab of half-space rows: Y[job][row][k2][x]; double-buffered so that
+    // k_gen (VALU-bound) of slab s+1 runs beside k_zfft (HBM-bound) of slab s on a second stream
+    // folded FFT inputs: a ring of slabs Y[job][row][k2][x].  Two slabs suffice for the gen || zfft overlap inside a
+    // pass; whatever HBM the store leaves free holds more of them, so that the (VALU-bound) generator of pass p+1
+    // runs ahead on its own stream while the (HBM-bound) y and x passes of pass p are still working
+    std::vector<zdfft::cplx *> d_Y;
+    std::vector<hipEvent_t> ev_gen, ev_fft;
+    int slab_rows = 0;        // rows generated per k_gen launch
+    long long next_g = 0;     // running slab number: slab g lives in ring slot g % K
+    int ahead_pass = -1;      // pass whose first `ahead_n` slabs (numbers ahead_g0...) are already being generated
+    long long ahead_g0 = 0;
+    int ahead_n = 0;
+    hipStream_t s_gen = nullptr, s_fft = nullptr;
+    hipEvent_t ev_fork = nullptr;
+    bool overlap = true;
+    // timing
+    std::vector<EventPair> events;
+    std::vector<hipEvent_t> pool;
+    double kernel_ms[ZD_K_COUNT] = {0, 0, 0, 0};
+    int64_t launches[ZD_K_COUNT] = {0, 0, 0, 0};
+};

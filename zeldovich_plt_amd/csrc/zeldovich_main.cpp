@@ -36,6 +36,7 @@ struct Writer {
 
     // first z stored in file `f`: smallest z with z*cpd/ppd == f   (output.cpp:208)
     int64_t first_z_of_file(int f) const {
+        if (p.cpd <= 0) return 0;  // CPD <= 0: z*cpd/ppd == 0 for every plane, everything lands in ic_0 (as in the reference)
         int64_t z = ((int64_t) f * p.ppd + p.cpd - 1) / p.cpd;
         while (z > 0 && (z - 1) * p.cpd / p.ppd == f) z--;
         while (z * p.cpd / p.ppd < f) z++;
@@ -45,7 +46,8 @@ struct Writer {
         auto it = fds.find(f);
         if (it != fds.end()) return it->second;
         const fs::path fn = dir / ("ic_" + std::to_string(f));
-        int fd = open(fn.c_str(), O_WRONLY | O_CREAT, 0644);
+        // planes are placed with pwrite, so a file is opened once per run: truncate whatever an earlier (longer) run left
+        int fd = open(fn.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
         if (fd < 0) {
             fprintf(stderr, "Could not open output file \"%s\"\n", fn.c_str());
             exit(1);

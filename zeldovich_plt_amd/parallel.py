@@ -1,9 +1,9 @@
 """One-process-per-GPU driver of the grid->displacements path.
 
 The reference is single-process; its y<->z "transpose" is StoreBlock/LoadBlock on one big array
-(src/block_array.cpp:387-414,466-504).  Here rank g owns the half-space rows ky in [g*H,(g+1)*H)
-(+ Hermitian twins) during the Z stage and the planes [g*Zq,(g+1)*Zq) of each residue pass during the
-XY stage; the block exchange between the two is ONE all-to-all per pass (RCCL over xGMI through
+(src/block_array.cpp:387-414,466-504).  Here rank g of G owns the half-space rows ky = g, g + G, g + 2G, ...
+(cyclic: the rows near ky = 0 carry most of the non-zero modes) during the Z stage and the planes
+[g*Zq,(g+1)*Zq) of each residue pass during the XY stage; the block exchange between the two is ONE all-to-all per pass (RCCL over xGMI through
 torch.distributed; gloo in the CPU tests).  No other collective is on the data path.
 
 `engine` is anything with the staged interface of include/zeldovich_hip.h:
