@@ -30,10 +30,15 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 WMAP = os.path.join(ROOT, "tests", "golden", "wmap1new.pow")
 
 
-def synthetic_eigenmodes(ppd_e=128, seed=7, amp=0.15):
-    """Synthetic PLT eigenmode table in the reference's file layout (src/zeldovich.cpp:796-797,815):
-    eigmodes128 is not part of the reference mount, so the benchmark input is generated: a smooth
-    odd perturbation of k_hat (~(k/k_Ny)^2) and lambda = 1 - 0.2 (k/k_Ny)^2."""
+def synthetic_eigenmodes(ppd_e=128, seed=7, amp=0.03, singular=False):
+    """Synthetic PLT eigenmode table in the reference's file layout (src/zeldovich.cpp:796-797,815,
+    155-159): float64 [ppd_e][ppd_e][ppd_e/2+1][4] = (e_x,e_y,e_z,lambda), FFT order, |e|=1.
+    eigmodes128 is absent from the reference mount, so PLT paths are exercised with this table:
+    e = normalised(k_hat + amp min((k/k_Ny)^2, 1.5) M k_hat) with a fixed random 3x3 matrix M (entries in
+    [-1, 1]) — within ~5 degrees of k_hat like real PLT eigenvectors, so k^2/(k.e) stays O(k) and the
+    displacements O(1) — and lambda = 1 - 0.2 (k/k_Ny)^2.
+    singular=True is the round-1 recipe (perturbation up to ~1.3 |k_hat|): e can come out almost
+    perpendicular to k, k^2/(k.e) blows up at a handful of modes; kept as an edge-case input."""
     h = ppd_e // 2 + 1
     idx = np.arange(ppd_e)
     kfull = np.where(idx > ppd_e // 2, idx - ppd_e, idx).astype(np.float64)
@@ -43,8 +48,11 @@ def synthetic_eigenmodes(ppd_e=128, seed=7, amp=0.15):
     kk = np.sqrt(np.where(k2 > 0, k2, 1.0))
     q2 = k2 / (kn * kn)
     c = np.random.RandomState(seed).uniform(-1, 1, size=(3, 3))
-    e = [kx / kk + amp * q2 * (c[i, 0] * kx + c[i, 1] * ky + c[i, 2] * kz) / kn for i in range(3)]
-    e[2] = kz / kk + amp * q2 * (c[2, 0] * kx + c[2, 1] * ky + c[2, 2] * kz) / kn
+    if singular:
+        pert = [0.15 * q2 * (c[i, 0] * kx + c[i, 1] * ky + c[i, 2] * kz) / kn for i in range(3)]
+    else:
+        pert = [amp * np.minimum(q2, 1.5) * (c[i, 0] * kx + c[i, 1] * ky + c[i, 2] * kz) / kk for i in range(3)]
+    e = [kx / kk + pert[0], ky / kk + pert[1], kz / kk + pert[2]]
     mag = np.sqrt(e[0] ** 2 + e[1] ** 2 + e[2] ** 2)
     mag = np.where(mag > 0, mag, 1.0)
     out = np.empty((ppd_e, ppd_e, h, 4), dtype=np.float64)

@@ -193,6 +193,9 @@ void zd_free(void *p);
 int zd_test_draws(int64_t seed, int64_t n, const int32_t *kxyz, uint64_t *out);
 /* Gaussian amplitudes D(k) for the same mode list (cgauss<2>, src/power_spectrum.cpp:338-359) */
 int zd_test_modes(const zd_params *p, const zd_pk *pk, int64_t n, const int32_t *kxyz, double *D);
+/* the same through the arithmetic the production generator k_genf uses (LDS-table ln / exp / sincos / spline segments,
+ * integer zero rule, Newton reciprocal): out[3*i] = {Re D, Im D, fundamental / |k|^2}; ky >= 0 */
+int zd_test_modes_table(const zd_params *p, const zd_pk *pk, int64_t n, const int32_t *kxyz, double *out);
 /* batch of `lines` independent length-n inverse FFTs, host in/out [lines][n] complex double;
  * axis_kind 0: the contiguous-line kernel path (x pass), 1: the strided-line path (y/z passes) */
 int zd_test_fft(int32_t n, int64_t lines, int32_t axis_kind, const double *in, double *out);

@@ -806,6 +806,27 @@ static void load_block(const geom *g, double *arr, int yblock, int zblock, doubl
             }
 }
 
+/* test helper: the same StoreBlock-all / LoadBlock-all sequence as oracle/ref_src/ref_blockarray.cpp drives through
+ * the reference's BlockArray; tests/golden/blockarray_kat.json (made from the reference object code) pins it */
+int zdo_blockarray_roundtrip(int ppd, int numblock, int narray, const double *slabs_in, double *arr_out,
+                             double *slabs_out, double fill) {
+    geom gg;
+    gg.ppd = ppd;
+    gg.ppdhalf = ppd / 2;
+    gg.narray = narray;
+    gg.numblock = numblock;
+    gg.block = ppd / numblock;
+    const geom *g = &gg;
+    const int64_t slab_c = (int64_t) g->block * narray * ppd * ppd;
+    for (int64_t i = 0; i < 2 * (int64_t) ppd * ppd * ppd * narray; i++) arr_out[i] = 0.0;
+    for (int yblock = 0; yblock < numblock; yblock++)
+        for (int zblock = 0; zblock < numblock; zblock++) store_block(g, arr_out, yblock, zblock, slabs_in + 2 * slab_c * yblock);
+    for (int64_t i = 0; i < 2 * slab_c * numblock; i++) slabs_out[i] = fill;
+    for (int zblock = 0; zblock < numblock; zblock++)
+        for (int yblock = 0; yblock < numblock; yblock++) load_block(g, arr_out, yblock, zblock, slabs_out + 2 * slab_c * zblock);
+    return 0;
+}
+
 typedef struct { unsigned short i, j, k, pad; double displ[3]; } zel_rec;               /* ZelParticle */
 typedef struct { unsigned short i, j, k, pad; float displ[3]; float vel[3]; } rv_rec;   /* RVZelParticle */
 typedef struct { unsigned short i, j, k, pad; double displ[3]; double vel[3]; } rvdouble_rec; /* RVdoubleZelParticle */

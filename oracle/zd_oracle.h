@@ -124,6 +124,12 @@ int zdo_run(const zdo_params *p, const zdo_pk *pk, const double *eig, int64_t ei
 int zdo_mode_cube(const zdo_params *p, const zdo_pk *pk, const double *eig, int64_t eig_ppd,
                   double *cube);
 
+/* StoreBlock for every (yblock, zblock) then LoadBlock for every (zblock, yblock) (src/block_array.cpp:387-414,
+ * 466-504): slabs_in [yblock][yres][a][z][x], arr_out = the BlockArray image, slabs_out [zblock][zres][a][y][x]
+ * pre-filled with `fill`.  Test helper pinned by tests/golden/blockarray_kat.json. */
+int zdo_blockarray_roundtrip(int ppd, int numblock, int narray, const double *slabs_in, double *arr_out,
+                             double *slabs_out, double fill);
+
 #ifdef __cplusplus
 }
 #endif

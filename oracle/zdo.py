@@ -95,6 +95,7 @@ def lib():
         L.zdo_infer_Tk.restype = C.c_double
         L.zdo_spline_build.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.zdo_spline_val.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
+        L.zdo_blockarray_roundtrip.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
         _lib = L
     return _lib
 
@@ -117,8 +118,31 @@ def ref():
         R.ref_pcg_draw.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int, C.c_void_p]
         R.ref_pcg_advance.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64]
         R.ref_spline_val.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        R.ref_blockarray_roundtrip.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
         _ref = R
     return _ref
+
+
+def blockarray_input(ppd, numblock, narray):
+    """deterministic z-stage slabs [yblock][yres][a][z][x]: every element carries its own coordinates
+    (re = 1 + linear index over (y, a, z, x), im = -re - 0.25), so any misplaced skewer shows"""
+    n = ppd * narray * ppd * ppd
+    re = 1.0 + np.arange(n, dtype=np.float64)
+    out = np.empty((n, 2), dtype=np.float64)
+    out[:, 0] = re
+    out[:, 1] = -re - 0.25
+    return out
+
+
+def blockarray_roundtrip(fn, ppd, numblock, narray, fill=-7.5):
+    """fn = lib().zdo_blockarray_roundtrip or ref().ref_blockarray_roundtrip; returns (arr, slabs_out) as float64 [n, 2]"""
+    inp = blockarray_input(ppd, numblock, narray)
+    arr = np.zeros_like(inp)
+    out = np.zeros_like(inp)
+    rc = fn(ppd, numblock, narray, inp.ctypes.data, arr.ctypes.data, out.ctypes.data, fill)
+    if rc:
+        raise RuntimeError("blockarray roundtrip failed")
+    return arr, out
 
 
 def make_params(ppd, numblock=2, boxsize=720.0, seed=12346, k_cutoff=1.0, qPLT=0, qPLTrescale=0,
@@ -218,36 +242,34 @@ def mode_cube(params, pk, eig=None, eig_ppd=0):
     return cube
 
 
-def synthetic_eigenmodes(ppd_e, seed=7, amp=0.15):
+def synthetic_eigenmodes(ppd_e=128, seed=7, amp=0.03, singular=False):
     """Synthetic PLT eigenmode table in the reference's file layout (src/zeldovich.cpp:796-797,815,
     155-159): float64 [ppd_e][ppd_e][ppd_e/2+1][4] = (e_x,e_y,e_z,lambda), FFT order, |e|=1.
     eigmodes128 is absent from the reference mount, so PLT paths are exercised with this table:
-    e = normalised(k_hat + smooth perturbation ~ (k/k_Ny)^2), lambda = 1 - 0.2 (k/k_Ny)^2."""
+    e = normalised(k_hat + amp min((k/k_Ny)^2, 1.5) M k_hat) with a fixed random 3x3 matrix M (entries in
+    [-1, 1]) — within ~5 degrees of k_hat like real PLT eigenvectors, so k^2/(k.e) stays O(k) and the
+    displacements O(1) — and lambda = 1 - 0.2 (k/k_Ny)^2.
+    singular=True is the round-1 recipe (perturbation up to ~1.3 |k_hat|): e can come out almost
+    perpendicular to k, k^2/(k.e) blows up at a handful of modes; kept as an edge-case input."""
     h = ppd_e // 2 + 1
     idx = np.arange(ppd_e)
     kfull = np.where(idx > ppd_e // 2, idx - ppd_e, idx).astype(np.float64)
-    kx = kfull[:, None, None]
-    ky = kfull[None, :, None]
-    kz = np.arange(h, dtype=np.float64)[None, None, :]
+    kx, ky, kz = kfull[:, None, None], kfull[None, :, None], np.arange(h, dtype=np.float64)[None, None, :]
     kn = ppd_e / 2.0
     k2 = kx * kx + ky * ky + kz * kz
     kk = np.sqrt(np.where(k2 > 0, k2, 1.0))
     q2 = k2 / (kn * kn)
-    rng = np.random.RandomState(seed)
-    c = rng.uniform(-1, 1, size=(3, 3))
-    # smooth, odd-in-k perturbation so that e(-k) = -e(k) like k_hat itself
-    px = (c[0, 0] * kx + c[0, 1] * ky + c[0, 2] * kz) / kn
-    py = (c[1, 0] * kx + c[1, 1] * ky + c[1, 2] * kz) / kn
-    pz = (c[2, 0] * kx + c[2, 1] * ky + c[2, 2] * kz) / kn
-    ex = kx / kk + amp * q2 * px
-    ey = ky / kk + amp * q2 * py
-    ez = kz / kk + amp * q2 * pz
-    mag = np.sqrt(ex * ex + ey * ey + ez * ez)
+    c = np.random.RandomState(seed).uniform(-1, 1, size=(3, 3))
+    if singular:
+        pert = [0.15 * q2 * (c[i, 0] * kx + c[i, 1] * ky + c[i, 2] * kz) / kn for i in range(3)]
+    else:
+        pert = [amp * np.minimum(q2, 1.5) * (c[i, 0] * kx + c[i, 1] * ky + c[i, 2] * kz) / kk for i in range(3)]
+    e = [kx / kk + pert[0], ky / kk + pert[1], kz / kk + pert[2]]
+    mag = np.sqrt(e[0] ** 2 + e[1] ** 2 + e[2] ** 2)
     mag = np.where(mag > 0, mag, 1.0)
     out = np.empty((ppd_e, ppd_e, h, 4), dtype=np.float64)
-    out[..., 0] = ex / mag
-    out[..., 1] = ey / mag
-    out[..., 2] = ez / mag
+    for i in range(3):
+        out[..., i] = e[i] / mag
     out[..., 3] = 1.0 - 0.2 * q2
     out[0, 0, 0, :3] = 0.0
     return np.ascontiguousarray(out)

@@ -83,6 +83,26 @@ def main():
               open(os.path.join(HERE, "spline_kat.json"), "w"), indent=1)
     print("wrote pcg_kat.json, spline_kat.json")
 
+    # BlockArray: StoreBlock for every block, then LoadBlock for every block, through the reference's own object code
+    # (src/block_array.cpp:387-414,466-504, RAM mode).  Input = oracle.zdo.blockarray_input (coordinates as values).
+    import hashlib
+    cases = []
+    for ppd, nb, na in [(8, 2, 2), (8, 4, 4), (8, 2, 1), (16, 2, 4), (16, 4, 2), (16, 8, 4), (32, 4, 2)]:
+        arr, slabs = zdo.blockarray_roundtrip(R.ref_blockarray_roundtrip, ppd, nb, na)
+        case = {"ppd": ppd, "numblock": nb, "narray": na, "fill": -7.5,
+                "arr_sha256": hashlib.sha256(arr.tobytes()).hexdigest(),
+                "slabs_sha256": hashlib.sha256(slabs.tobytes()).hexdigest()}
+        if ppd == 8:  # small cases in full: real parts (the imaginary part of every input element is -re - 0.25)
+            case["arr_re"] = [int(v) for v in arr[:, 0]]
+            case["slabs_re"] = [float(v) for v in slabs[:, 0]]
+        cases.append(case)
+    json.dump({"source": "reference BlockArray (src/block_array.cpp + src/STimer.cc, RAM mode) via oracle/_ref; input = "
+                         "oracle.zdo.blockarray_input: element (y, a, z, x) of the z-stage slabs holds re = 1 + linear "
+                         "index, im = -re - 0.25; arr = BlockArray image after all StoreBlock calls, slabs = xy-stage "
+                         "slabs [zblock][zres][a][y][x] after all LoadBlock calls (pre-filled with `fill`)",
+               "cases": cases}, open(os.path.join(HERE, "blockarray_kat.json"), "w"), indent=1)
+    print("wrote blockarray_kat.json")
+
 
 if __name__ == "__main__":
     main()

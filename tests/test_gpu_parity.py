@@ -99,6 +99,7 @@ def _compare(zd, oracle, ps, opk, n, fmt="RVdoubleZel", eig=None, tie_ok=False, 
     p = zd.make_params(n, icformat=fmt, **kw)
     okw = dict(kw)
     okw.pop("stream_factor", None)
+    okw.pop("store_mode", None)
     if "corner_modes" in okw:
         okw["CornerModes"] = okw.pop("corner_modes")
     op = oracle.make_params(n, numblock=2, icformat=fmt, **okw)

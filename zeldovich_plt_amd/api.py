@@ -76,7 +76,7 @@ EXPORTED_SYMBOLS = [
     "zd_plan_plane_z", "zd_plan_stage_z", "zd_plan_stage_y", "zd_plan_stage_x", "zd_plan_stats",
     "zd_params_from_file", "zd_pk_create_from_file", "zd_pk_create_powerlaw", "zd_pk_power",
     "zd_pk_sigmaR", "zd_pk_destroy", "zd_load_eigmodes", "zd_free", "zd_test_draws", "zd_test_modes",
-    "zd_test_fft",
+    "zd_test_modes_table", "zd_test_fft",
 ]
 STORE_MODES = {"auto": 0, "reference": 1, "packed": 2, "fields": 3}  # zd_params.store_mode (ZD_STORE_*)
 
@@ -131,6 +131,7 @@ def load_library():
     L.zd_free.restype = None
     L.zd_test_draws.argtypes = [i64, i64, vp, vp]
     L.zd_test_modes.argtypes = [C.POINTER(ZdParams), C.POINTER(ZdPk), i64, vp, vp]
+    L.zd_test_modes_table.argtypes = [C.POINTER(ZdParams), C.POINTER(ZdPk), i64, vp, vp]
     L.zd_test_fft.argtypes = [i32, i64, i32, vp, vp]
     _lib = L
     return L
@@ -350,6 +351,16 @@ def test_modes(params, ps, kxyz):
     if L.zd_test_modes(C.byref(params), C.byref(ps.pk), k.shape[0], k.ctypes.data, out.ctypes.data):
         raise RuntimeError("zd_test_modes failed")
     return out[:, 0] + 1j * out[:, 1]
+
+
+def test_modes_table(params, ps, kxyz):
+    """D(k) and fundamental/k^2 through k_genf's table arithmetic; returns (complex D [n], float64 [n])"""
+    L = load_library()
+    k = np.ascontiguousarray(kxyz, dtype=np.int32).reshape(-1, 3)
+    out = np.zeros((k.shape[0], 3), dtype=np.float64)
+    if L.zd_test_modes_table(C.byref(params), C.byref(ps.pk), k.shape[0], k.ctypes.data, out.ctypes.data):
+        raise RuntimeError("zd_test_modes_table failed")
+    return out[:, 0] + 1j * out[:, 1], out[:, 2]
 
 
 def test_fft(x, axis_kind):

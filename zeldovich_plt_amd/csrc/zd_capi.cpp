@@ -978,6 +978,26 @@ int zd_test_modes(const zd_params *p, const zd_pk *pk, int64_t n, const int32_t 
     return rc;
 }
 
+int zd_test_modes_table(const zd_params *p, const zd_pk *pk, int64_t n, const int32_t *kxyz, double *out) {
+    zd_plan *pl = nullptr;
+    if (make_test_gen(p, pk, &pl)) return 1;
+    int *d_k = nullptr;
+    double *d_o = nullptr;
+    int rc = 1;
+    do {
+        if (hipMalloc((void **) &d_k, sizeof(int) * 3 * n) != hipSuccess) break;
+        if (hipMalloc((void **) &d_o, sizeof(double) * 3 * n) != hipSuccess) break;
+        if (hipMemcpy(d_k, kxyz, sizeof(int) * 3 * n, hipMemcpyHostToDevice) != hipSuccess) break;
+        if (zd::launch_test_modes_table(pl->g, n, d_k, d_o, 0)) break;
+        if (hipMemcpy(out, d_o, sizeof(double) * 3 * n, hipMemcpyDeviceToHost) != hipSuccess) break;
+        rc = 0;
+    } while (0);
+    hipFree(d_k);
+    hipFree(d_o);
+    zd_plan_destroy(pl);
+    return rc;
+}
+
 int zd_test_fft(int32_t n, int64_t lines, int32_t axis_kind, const double *in, double *out) {
     const int W = zd::test_fft_tile_width(n);
     if (W == 0 || lines % W) {

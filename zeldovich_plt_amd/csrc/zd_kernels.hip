@@ -1139,6 +1139,39 @@ __global__ void k_test_modes(GenConst g, long long n, const int *__restrict__ kx
     }
 }
 
+// test hook: the PRODUCTION arithmetic of k_genf (LDS-table ln / exp / sincos / spline, integer zero rule, frcp) on an
+// explicit mode list; out[3*i] = {Re D, Im D, fundamental / k^2}
+template <bool PLAW>
+__global__ void k_test_modes_table(GenConst g, long long n, const int *__restrict__ kxyz, double *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) double T[];
+    for (int i = threadIdx.x; i < g.genf_n / 2; i += blockDim.x)
+        reinterpret_cast<double2 *>(T)[i] = reinterpret_cast<const double2 *>(g.genf_tab)[i];
+    __syncthreads();
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int kx = kxyz[3 * i], ky = kxyz[3 * i + 1], kz = kxyz[3 * i + 2];
+    const uint64_t off = 2ULL * ((uint64_t) (kz & 65535) * 65536ULL + (uint64_t) (kx & 65535)) + 1ULL;
+    const u128 s      = advance_bits(g.row_state[ky], off);
+    const uint64_t r1 = zdpcg::output(s);
+    const uint64_t r2 = zdpcg::output(zdpcg::step(s));
+    const int k2i     = kx * kx + ky * ky + kz * kz;
+    const bool dead   = (kx < 0 ? -kx : kx) == g.kmax || ky == g.kmax || (kz < 0 ? -kz : kz) == g.kmax;
+    const bool live   = !dead && (g.corner_modes || k2i < g.k2i_cut) && k2i > 0;
+    const double k2v  = (double) (k2i > 0 ? k2i : 1) * g.fundamental2;
+    const double P    = genf_power<PLAW>(g, T, k2v);
+    const double ik2  = frcp(k2v);
+    const uint64_t m1 = r1 + 1ULL;
+    double v = P;
+    if (!g.fixed_power) v = -P * flog(u64_to_double(m1), 64, T);
+    v = (m1 == 0 && !g.fixed_power) || !live ? 0.0 : v;
+    const double amp = sqrt_pos(v);
+    double sn, cs;
+    sincos_u01(u64_to_double(r2 + 1ULL), T, sn, cs);
+    out[3 * i]     = amp * cs;
+    out[3 * i + 1] = amp * sn;
+    out[3 * i + 2] = g.fundamental * ik2;
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_zfft: length-L FFT of one job's folded inputs for a W-wide column tile of row ky, then the
 // Hermitian stores: "self" columns at (row ky, column x), "twin" columns conjugated at
@@ -1757,6 +1790,18 @@ int launch_pk_table(const GenConst &g, int n, void *tab, hipStream_t st) {
 int launch_test_modes(const GenConst &g, long long n, const int *kxyz, uint64_t *draws, double *D, hipStream_t st) {
     dim3 grid((unsigned) ((n + 255) / 256)), block(256);
     hipLaunchKernelGGL(k_test_modes, grid, block, 0, st, g, n, kxyz, draws, D);
+    ZD_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_test_modes_table(const GenConst &g, long long n, const int *kxyz, double *out, hipStream_t st) {
+    if (!g.genf_tab) return 2;
+    dim3 grid((unsigned) ((n + 255) / 256)), block(256);
+    const size_t shmem = sizeof(double) * (size_t) (g.genf_n + 2);
+    if (g.is_powerlaw)
+        hipLaunchKernelGGL(k_test_modes_table<true>, grid, block, shmem, st, g, n, kxyz, out);
+    else
+        hipLaunchKernelGGL(k_test_modes_table<false>, grid, block, shmem, st, g, n, kxyz, out);
     ZD_LAUNCH_CHECK();
     return 0;
 }
