@@ -161,12 +161,19 @@ def test_plt_streaming(zd, oracle, ps, opk):
     (128, dict(stream_factor=2, fmt="Zeldovich")),
     (64, dict(stream_factor=2, fmt="ZelSimple", k_cutoff=4.0)),
 ])
-def test_packed_za_pairs_sweep(zd, oracle, ps, opk, n, kw):
-    """ZA without ZD_qdensity and R >= 2: two z-residues per pass in 3 arrays, density_variance from sum |D|^2"""
-    kw = dict(kw)
+@pytest.mark.parametrize("store", ["fields", "packed"])
+def test_packed_za_pairs_sweep(zd, oracle, ps, opk, n, kw, store):
+    """ZA without ZD_qdensity and R >= 2: two z-residues per pass, density_variance from sum |D|^2.
+    store = fields: the potentials E, Z of the half-space rows, zero columns not stored (PACK_ZAFIELD, the default);
+    store = packed: the three arrays (qy + i qz)_r0 | (qy + i qz)_r1 | qx_r0 + i qx_r1 with Hermitian twins (PACK_ZAPAIR)"""
+    kw = dict(kw, store_mode=store)
     fmt = kw.pop("fmt", "RVdoubleZel")
     plan = zd.Plan(zd.make_params(n, icformat=fmt, **kw), ps)
     assert plan.narray == 3 and plan.plane_step == 2
+    ref_store = zd.Plan(zd.make_params(n, icformat=fmt, **dict(kw, store_mode="packed")), ps)
+    if store == "fields":  # 4 half-space fields (= 2 arrays' worth) minus the zero columns, vs 3 arrays
+        assert plan.exchange_bytes <= ref_store.exchange_bytes * 2 // 3
+    ref_store.close()
     plan.close()
     got, _ = _compare(zd, oracle, ps, opk, n, fmt=fmt, **kw)
     assert sorted(got["planes_seen"]) == list(range(n))
@@ -217,8 +224,10 @@ def test_oneslab(zd, oracle, ps, opk):
     assert abs(got["density_variance"] - ref["density_variance"]) <= TOL * ref["density_variance"]
 
 
-@pytest.mark.parametrize("world,R,plt", [(2, 1, False), (4, 2, False), (2, 4, False), (2, 2, True)])
-def test_multirank_layout_on_one_gpu(zd, oracle, ps, opk, world, R, plt):
+@pytest.mark.parametrize("world,R,plt,store", [(2, 1, False, "auto"), (4, 2, False, "auto"), (2, 4, False, "auto"),
+                                               (2, 2, True, "auto"), (4, 2, False, "packed"), (2, 4, False, "packed"),
+                                               (4, 4, False, "auto")])
+def test_multirank_layout_on_one_gpu(zd, oracle, ps, opk, world, R, plt, store):
     """the N>1 data path with the REAL kernels: `world` rank plans share this GPU, the all-to-all is
     emulated by chunk copies (chunk d of rank s's send buffer -> chunk s of rank d's receive buffer,
     i.e. all_to_all_single semantics); results must equal the single-process oracle."""
@@ -227,8 +236,9 @@ def test_multirank_layout_on_one_gpu(zd, oracle, ps, opk, world, R, plt):
     eig = oracle.synthetic_eigenmodes(32) if plt else None
     kw = dict(qPLT=1, qPLTrescale=1, PLT_target_z=5.0, f_cluster=0.97) if plt else {}
     fmt = "RVdoubleZel"
-    plans = [zd.Plan(zd.make_params(n, icformat=fmt, stream_factor=R, **kw), ps, eig=eig, rank=r, nranks=world)
-             for r in range(world)]
+    n = 256 if (world, R) == (4, 4) else n  # big enough for pruned tiles and compacted rows in every chunk
+    plans = [zd.Plan(zd.make_params(n, icformat=fmt, stream_factor=R, store_mode=store, **kw), ps, eig=eig, rank=r,
+                     nranks=world) for r in range(world)]
     nb = plans[0].exchange_bytes
     cb = nb // world
     Zq = plans[0].local_planes
@@ -285,6 +295,9 @@ def test_packed_store_matches_reference_arrays(zd, oracle, ps, plt):
     assert plan.narray == (4 if plt else 2) and plan.plane_step == 1 and plan.passes == 4
     plan.close()
     b = zd.generate(p, ps, eig=eig)
+    if not plt:  # the round-1 packing (three arrays with Hermitian twins) as well
+        c = zd.generate(zd.make_params(n, icformat="RVdoubleZel", stream_factor=4, store_mode="packed"), ps)
+        assert _rel(c["records"]["d"], b["records"]["d"]) < 1e-13
     assert sorted(a["planes_seen"]) == list(range(n)) == sorted(b["planes_seen"])
     assert np.array_equal(a["records"]["ijk"], b["records"]["ijk"])
     for f in ("d", "v"):

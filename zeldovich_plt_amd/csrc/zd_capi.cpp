@@ -183,24 +183,94 @@ static int pack_mode(const zd_params *p, int R) {
         if (!nyquist_dead) return zd::PACK_NONE;
     }
     if (p->qPLT) return zd::PACK_PLT3;
-    return R >= 2 ? zd::PACK_ZAPAIR : zd::PACK_NONE;
+    if (R < 2) return zd::PACK_NONE;  // the ZA packings carry two z-residues per pass
+    return p->store_mode == ZD_STORE_PACKED ? zd::PACK_ZAPAIR : zd::PACK_ZAFIELD;
 }
 static int store_arrays(const zd_params *p, int R) {
     if (pack_mode(p, R) != zd::PACK_NONE) return 3;
     return p->qdensity == 2 ? 1 : (p->qPLT ? 4 : 2);
 }
 
+// the zero rule of zeldovich.cpp:350-353 as the kernels prune by it (zd_device.h column_is_zero)
+static void prune_rule(const zd_params *p, zd::StoreLayout &S) {
+    const int half = (int) (p->ppd / 2);
+    S.N         = (int) p->ppd;
+    S.half      = half;
+    S.prune     = 7;
+    S.kmax      = (int) ((double) half * (1.0 / p->k_cutoff) + .5);
+    S.fund2     = p->fundamental * p->fundamental;
+    S.k2_cutoff = p->corner_modes ? 0.0 : p->nyquist * p->nyquist / (p->k_cutoff * p->k_cutoff);  // CornerModes: only |k_i| == kmax prunes
+}
+
+// Row table of the field store (zd_device.h FieldLayout) for `nranks` ranks: slot i stands for the rows ky = c + nranks*i
+// of every rank c and is sized by the longest of them (ky = nranks*i).  Returns the elements per (plane, field) image.
+static int64_t field_rows(const zd_params *p, int nranks, std::vector<zd::FieldRow> *rows) {
+    zd::StoreLayout S;
+    memset(&S, 0, sizeof(S));
+    prune_rule(p, S);
+    const int N = S.N, half = S.half, Hq = half / nranks, CW = zd::FIELD_CW, NT = std::max(1, N / CW);
+    int64_t total = 0;
+    if (rows) rows->resize(Hq);
+    for (int i = 0; i < Hq; i++) {
+        const int ky = i * nranks;
+        // live columns are kx in (-c, c): tiles [0, tl) on the low side, [th, NT) on the high side
+        int tl = 0, th = NT;
+        if (N >= 2 * CW) {
+            while (tl < NT) {  // tile tl holds a live column?
+                bool live = false;
+                for (int x = tl * CW; x < (tl + 1) * CW && !live; x++) live = !zd::column_is_zero(S, x > half ? x - N : x, ky);
+                if (!live) break;
+                tl++;
+            }
+            while (th > tl) {
+                bool live = false;
+                for (int x = (th - 1) * CW; x < th * CW && !live; x++) live = !zd::column_is_zero(S, x > half ? x - N : x, ky);
+                if (!live) break;
+                th--;
+            }
+            // a live tile strictly between dead ones cannot happen for the symmetric interval rule, but the table must be
+            // safe for any rule: if one exists, keep the whole row
+            for (int tt = tl; tt < th; tt++)
+                for (int x = tt * CW; x < (tt + 1) * CW; x++)
+                    if (!zd::column_is_zero(S, x > half ? x - N : x, ky)) { tl = NT; th = NT; }
+        } else {
+            tl = NT;
+        }
+        zd::FieldRow r;
+        r.base  = (int) total;
+        r.split = tl >= th ? N : tl * CW;
+        r.gap   = tl >= th ? 0 : (th - tl) * CW;
+        r.pad   = 0;
+        if (rows) (*rows)[i] = r;
+        total += N - r.gap;
+    }
+    return total;
+}
+
+// bytes of the block store one rank holds per pass (send side; nranks > 1 doubles it with the receive buffer)
+static int64_t store_bytes(const zd_params *p, int R, int nranks) {
+    const int64_t N = p->ppd;
+    if (pack_mode(p, R) == zd::PACK_ZAFIELD) return (N / R) * 4 * field_rows(p, nranks, nullptr) * 16;
+    return N * (N + store_row_pad(N)) * (N / R) / nranks * 16 * store_arrays(p, R);
+}
+// ring between the y and x stages of the field store: planes of the three PACK_ZAPAIR arrays
+static int field_ring_planes(int64_t N, int64_t Zq) {
+    const int64_t plane_b = 3 * N * (N + store_row_pad(N)) * 16;
+    return (int) std::max<int64_t>(1, std::min<int64_t>(Zq, ((int64_t) 6 << 30) / plane_b));
+}
+
 int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes) {
     const int64_t N = p->ppd;
-    // ZA without density: two residues share a pass (3 arrays of N/R planes < 2 arrays of 2N/R planes), so R = 2 is
-    // preferred over R = 1 whenever the z FFT is long enough
+    // ZA without density: two residues share a pass, so R = 2 is preferred over R = 1 whenever the z FFT is long enough
     int R0 = 1;
-    if (!p->qPLT && pack_mode(p, 2) == zd::PACK_ZAPAIR && N / 2 >= 32 && (N / 2) % nranks == 0) R0 = 2;
+    if (!p->qPLT && pack_mode(p, 2) != zd::PACK_NONE && N / 2 >= 32 && (N / 2) % nranks == 0) R0 = 2;
     for (int R = R0; N / R >= 32; R *= 2) {
         if ((N / R) % nranks) break;
         if (N / R > 4096) continue;  // z-FFT kernels exist up to length 4096
-        int64_t store = N * (N + store_row_pad(N)) * (N / R) / nranks * 16 * store_arrays(p, R);
+        int64_t store = store_bytes(p, R, nranks);
         if (nranks > 1) store *= 2;  // separate send and receive buffers
+        if (pack_mode(p, R) == zd::PACK_ZAFIELD)
+            store += (int64_t) field_ring_planes(N, N / R / nranks) * 3 * N * (N + store_row_pad(N)) * 16;
         if (store <= budget_bytes) return R;
     }
     return -1;
@@ -249,7 +319,7 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
     pl->narray  = (phi_mode == 1 || p->qdensity == 2) ? 1 : (p->qPLT ? 4 : 2);  // zeldovich.cpp:871-876
     if (phi_mode == 0 && phik == nullptr && pl->narray >= 2) pl->pack = pack_mode(p, R);
     if (pl->pack != zd::PACK_NONE) pl->narray = 3;
-    pl->pstep   = pl->pack == zd::PACK_ZAPAIR ? 2 : 1;
+    pl->pstep   = (pl->pack == zd::PACK_ZAPAIR || pl->pack == zd::PACK_ZAFIELD) ? 2 : 1;
     pl->npass   = R / pl->pstep;
     pl->R       = R;
     pl->L       = (int) (N / R);
@@ -435,7 +505,12 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
             jl.res[jl.n]  = res;
             jl.n++;
         };
-        if (pl->pack == zd::PACK_ZAPAIR) {  // (qy + i qz)_r0 | (qy + i qz)_r1 | qx_r0 + i qx_r1
+        if (pl->pack == zd::PACK_ZAFIELD) {  // the potentials E, Z of the two residues (k_zfft_f: job index = field index)
+            add(zd::JOB_E, 0, 0, 0);
+            add(zd::JOB_Z, 1, 0, 0);
+            add(zd::JOB_E, 2, 0, 1);
+            add(zd::JOB_Z, 3, 0, 1);
+        } else if (pl->pack == zd::PACK_ZAPAIR) {  // (qy + i qz)_r0 | (qy + i qz)_r1 | qx_r0 + i qx_r1
             add(zd::JOB_B_SELF, 0, 0, 0);
             add(zd::JOB_B_TWIN, 0, 1, 0);
             add(zd::JOB_B_SELF, 1, 0, 1);
@@ -515,8 +590,43 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
     pl->ec.qPLT     = p->qPLT;
     pl->ec.qdensity = p->qdensity;
     pl->ec.vnorm    = p->qPLT ? 1.0 : (sqrt(1. + 24 * p->f_cluster) - 1) * .25;  // output.cpp:78-82
-    pl->ec.pack     = pl->pack;
+    pl->ec.pack     = pl->pack == zd::PACK_ZAFIELD ? zd::PACK_ZAPAIR : pl->pack;  // the y stage rebuilds the ZAPAIR arrays
     pl->ec.z_pair   = R / 2;
+    pl->store_bytes_ = (int64_t) S.chunk_rows * S.pitch * nranks * 16;
+    if (pl->pack == zd::PACK_ZAFIELD) {
+        std::vector<zd::FieldRow> rows;
+        const int64_t fe = field_rows(p, nranks, &rows);
+        PLCHECK(hipMalloc((void **) &pl->d_fieldrows, sizeof(zd::FieldRow) * rows.size()));
+        PLCHECK(hipMemcpy(pl->d_fieldrows, rows.data(), sizeof(zd::FieldRow) * rows.size(), hipMemcpyHostToDevice));
+        pl->F.lG          = S.lG;
+        pl->F.lZq         = 0;
+        while ((1 << pl->F.lZq) < pl->Zq) pl->F.lZq++;
+        pl->F.field_elems = fe;
+        pl->F.chunk_elems = (int64_t) pl->Zq * 4 * fe;
+        pl->F.rows        = pl->d_fieldrows;
+        pl->store_bytes_  = pl->F.chunk_elems * nranks * 16;
+        // ring: `ring_planes` store planes of the three arrays, laid out as a single-rank block store (one_block)
+        pl->ring_planes = field_ring_planes(pl->N, pl->Zq);
+        zd::StoreLayout &Q = pl->SR;
+        Q            = S;
+        Q.Hq         = pl->half;
+        Q.lHq        = 0;
+        while ((1 << Q.lHq) < pl->half) Q.lHq++;
+        Q.lG         = 0;
+        Q.ky_stride  = 1;
+        Q.narray     = 3;
+        Q.lBk        = Q.lHq + 1;
+        Q.lBz        = 0;
+        Q.rows_outer = 0;
+        Q.one_block  = 1;
+        Q.prune      = 0;
+        Q.pitch      = pl->N + store_row_pad(pl->N);
+        Q.a_rows     = pl->N;
+        Q.zb_rows    = 3 * pl->N;
+        Q.kb_rows    = Q.zb_rows * pl->ring_planes;
+        Q.chunk_rows = Q.kb_rows;
+        PLCHECK(hipMalloc((void **) &pl->d_ring, (size_t) Q.chunk_rows * Q.pitch * 16));
+    }
     g.var_slots     = pl->d_red->sumsq;
 
     // ---- folded-input slabs (two, for the gen||zfft overlap): enough rows per launch to fill the chip ----
@@ -592,6 +702,8 @@ void zd_plan_destroy(zd_plan *pl) {
     hipFree(pl->d_genf);
     hipFree(pl->d_tilectr);
     hipFree(pl->d_red);
+    hipFree(pl->d_fieldrows);
+    hipFree(pl->d_ring);
     for (cplx *y : pl->d_Y) hipFree(y);
     if (pl->s_gen) hipStreamDestroy(pl->s_gen);
     if (pl->s_fft) hipStreamDestroy(pl->s_fft);
@@ -606,9 +718,7 @@ void zd_plan_destroy(zd_plan *pl) {
 int32_t zd_plan_narray(const zd_plan *pl) { return pl->narray; }
 int32_t zd_plan_stream_factor(const zd_plan *pl) { return pl->R; }
 int32_t zd_plan_record_size(const zd_plan *pl) { return pl->ec.recsize; }
-int64_t zd_plan_exchange_bytes(const zd_plan *pl) {
-    return (int64_t) pl->S.chunk_rows * pl->S.pitch * pl->nranks * 16;
-}
+int64_t zd_plan_exchange_bytes(const zd_plan *pl) { return pl->store_bytes_; }
 int32_t zd_plan_passes(const zd_plan *pl) { return pl->npass; }
 int32_t zd_plan_plane_step(const zd_plan *pl) { return pl->pstep; }
 int64_t zd_plan_local_planes(const zd_plan *pl) { return (int64_t) pl->Zq * pl->pstep; }
@@ -618,10 +728,17 @@ int64_t zd_plan_plane_z(const zd_plan *pl, int pass, int64_t local_plane) {
     return (pass + which * (pl->R / 2)) + (int64_t) pl->R * ((int64_t) pl->rank * pl->Zq + zl);
 }
 
+// z FFT of one slab of generated rows into the block store (reference / packed arrays with Hermitian twins, or the
+// potentials of the field store)
+static int launch_zstage_fft(zd_plan *pl, int ky0, int kyloc0, int nky, const void *Y, void *d_send, hipStream_t st) {
+    if (pl->pack == zd::PACK_ZAFIELD) return zd::launch_zfft_fields(pl->L, pl->F, pl->S, ky0, kyloc0, nky, Y, pl->d_twL, d_send, st);
+    return zd::launch_zfft(pl->L, pl->jobs, pl->S, ky0, kyloc0, nky, pl->Zq, Y, pl->d_twL, d_send, st);
+}
+
 int zd_plan_stage_z(zd_plan *pl, int residue, void *d_send, void *hip_stream) {
     hipStream_t st = (hipStream_t) hip_stream;
     if (residue < 0 || residue >= pl->npass) return 1;
-    const int residue2 = pl->pack == zd::PACK_ZAPAIR ? residue + pl->R / 2 : residue;
+    const int residue2 = pl->pstep == 2 ? residue + pl->R / 2 : residue;
     pl->g.accum_var = (pl->pack != zd::PACK_NONE && pl->var_pending) ? 1 : 0;  // once per run: every pass sees every mode
     pl->var_pending = false;
     const int ky_first = pl->rank, G = pl->nranks;  // this rank's half-space rows: rank, rank + G, ... (cyclic)
@@ -636,8 +753,7 @@ int zd_plan_stage_z(zd_plan *pl, int residue, void *d_send, void *hip_stream) {
                 return 1;
             tick(pl, ZD_K_GEN, st, false);
             tick(pl, ZD_K_ZFFT, st, true);
-            if (zd::launch_zfft(pl->L, pl->jobs, pl->S, ky_first + G * r0, r0, nky, pl->Zq, pl->d_Y[0], pl->d_twL, d_send, st))
-                return 1;
+            if (launch_zstage_fft(pl, ky_first + G * r0, r0, nky, pl->d_Y[0], d_send, st)) return 1;
             tick(pl, ZD_K_ZFFT, st, false);
         }
         return 0;
@@ -656,7 +772,7 @@ int zd_plan_stage_z(zd_plan *pl, int residue, void *d_send, void *hip_stream) {
         pl->g.accum_var = accum;
         tick(pl, ZD_K_GEN, pl->s_gen, true);
         if (zd::launch_gen(pl->g, pl->J, pl->jobs, pl->S, ky_first + G * r0, pl->slab_rows, pl->L, pass,
-                           pl->pack == zd::PACK_ZAPAIR ? pass + pl->R / 2 : pass, pl->d_twN, pl->d_Y[slot], ctr + slab,
+                           pl->pstep == 2 ? pass + pl->R / 2 : pass, pl->d_twN, pl->d_Y[slot], ctr + slab,
                            pl->gen_max_wgs, pl->s_gen))
             return 1;
         tick(pl, ZD_K_GEN, pl->s_gen, false);
@@ -676,9 +792,7 @@ int zd_plan_stage_z(zd_plan *pl, int residue, void *d_send, void *hip_stream) {
         const int slot = (int) (gno % K), r0 = slab * pl->slab_rows;
         HIPCHECK(hipStreamWaitEvent(pl->s_fft, pl->ev_gen[slot], 0));
         tick(pl, ZD_K_ZFFT, pl->s_fft, true);
-        if (zd::launch_zfft(pl->L, pl->jobs, pl->S, ky_first + G * r0, r0, pl->slab_rows, pl->Zq, pl->d_Y[slot], pl->d_twL, d_send,
-                            pl->s_fft))
-            return 1;
+        if (launch_zstage_fft(pl, ky_first + G * r0, r0, pl->slab_rows, pl->d_Y[slot], d_send, pl->s_fft)) return 1;
         tick(pl, ZD_K_ZFFT, pl->s_fft, false);
         HIPCHECK(hipEventRecord(pl->ev_fft[slot], pl->s_fft));
     }
@@ -702,6 +816,7 @@ int zd_plan_stage_z(zd_plan *pl, int residue, void *d_send, void *hip_stream) {
 
 int zd_plan_stage_y(zd_plan *pl, void *d_recv, void *hip_stream) {
     hipStream_t st = (hipStream_t) hip_stream;
+    if (pl->pack == zd::PACK_ZAFIELD) return 0;  // field store: the y transform runs plane group by plane group in stage_x
     tick(pl, ZD_K_YFFT, st, true);
     if (zd::launch_yfft(pl->S, pl->Zq, pl->d_twN, d_recv, st)) return 1;
     tick(pl, ZD_K_YFFT, st, false);
@@ -718,6 +833,24 @@ int zd_plan_stage_x(zd_plan *pl, int residue, const void *d_recv, int64_t plane0
         return 1;
     }
     if (d_density && pl->pack != zd::PACK_NONE) return 1;  // packed stores carry no density field
+    if (pl->pack == zd::PACK_ZAFIELD) {
+        // y stage (potentials -> the three displacement arrays of a group of store planes, into the ring) + x stage
+        const int p0 = (int) (plane0 / ps), np = (int) (nplanes / ps);
+        for (int g0 = 0; g0 < np; g0 += pl->ring_planes) {
+            const int ng = std::min(pl->ring_planes, np - g0);
+            tick(pl, ZD_K_YFFT, st, true);
+            if (zd::launch_yfft_fields(pl->F, pl->S, pl->d_twN, d_recv, p0 + g0, ng, pl->SR.pitch, pl->d_ring, st)) return 1;
+            tick(pl, ZD_K_YFFT, st, false);
+            const int z_first = (int) zd_plan_plane_z(pl, residue, (int64_t) (p0 + g0) * ps);
+            tick(pl, ZD_K_XFFT, st, true);
+            if (zd::launch_xfft(pl->SR, pl->ec, pl->d_twN, pl->d_ring, 0, ng, z_first, pl->R,
+                                d_records ? (char *) d_records + (size_t) g0 * ps * pl->N * pl->N * pl->ec.recsize : nullptr,
+                                nullptr, pl->d_red, st))
+                return 1;
+            tick(pl, ZD_K_XFFT, st, false);
+        }
+        return 0;
+    }
     const int z_first = (int) zd_plan_plane_z(pl, residue, plane0);
     tick(pl, ZD_K_XFFT, st, true);
     if (zd::launch_xfft(pl->S, pl->ec, pl->d_twN, d_recv, (int) (plane0 / ps), (int) (nplanes / ps), z_first, pl->R, d_records,
@@ -919,7 +1052,7 @@ int zd_generate(const zd_params *p_in, const zd_pk *pk, const double *eig, int64
 static int make_test_gen(const zd_params *p, const zd_pk *pk, zd_plan **pl) {
     zd_params q = *p;
     q.qPLT      = 0;
-    q.stream_factor = 1;
+    q.stream_factor = q.ppd > 4096 ? (int) (q.ppd / 4096) : 1;  // z-FFT kernels exist up to length 4096
     return zd_plan_create(&q, pk, nullptr, 0, 0, 1, pl);
 }
 

@@ -155,7 +155,10 @@ enum JobKind {
     // packed stores (no density field, see PACK_*):
     JOB_XV_SELF = 8,  // (i - f) sx D = F_x + i f F_x            (qx + i vx)
     JOB_XV_TWIN = 9,  // conj FFT[(i + f) sx D]
-    JOB_FX      = 10  // i sx D of one residue; the two residues of a pass are combined into qx_r0 + i qx_r1
+    JOB_FX      = 10, // i sx D of one residue; the two residues of a pass are combined into qx_r0 + i qx_r1
+    // field store (PACK_ZAFIELD): the two potentials of the ZA displacement, per z-residue of the pass
+    JOB_E       = 11, // (fundamental / k^2) D          q_x = d/dx, q_y = d/dy of its transform
+    JOB_Z       = 12  // kz (fundamental / k^2) D       q_z = i x its transform
 };
 // What the store holds.  The reference always transforms the density (Re of its array 0) although only
 // ZD_qdensity writes it out and only its sum of squares is reported; without ZD_qdensity the density is not
@@ -164,7 +167,33 @@ enum JobKind {
 //   PACK_PLT3    arrays  qx + i vx | qy + i qz | vy + i vz
 //   PACK_ZAPAIR  one pass carries TWO z-residues r0, r1 (the y/x transforms act per plane, so fields of
 //                different planes pack into one complex array):  (qy + i qz)_r0 | (qy + i qz)_r1 | qx_r0 + i qx_r1
-enum { PACK_NONE = 0, PACK_ZAPAIR = 1, PACK_PLT3 = 2 };
+//   PACK_ZAFIELD the ZA displacement is the gradient of ONE scalar: after the z transform, q_x = i kx E, q_y = i ky E and
+//                q_z = i Z with E = sum_kz (fund/k^2) D e^{..}, Z = sum_kz kz (fund/k^2) D e^{..}.  E is Hermitian and Z
+//                anti-Hermitian in (kx, ky), so the store keeps E and Z of the two residues of a pass for the half-space
+//                rows ky < N/2 ONLY (no Hermitian twins: 4 half fields = 2 arrays' worth instead of 3), and skips the
+//                (kx, ky) columns the zero rule kills (FieldLayout below: 21.5 % at k_cutoff = 1).  That is what lets
+//                PPD = 4096 run in 4 passes instead of 8 on one 288 GB GPU and halves the all-to-all volume between
+//                GPUs.  The y pass rebuilds the three PACK_ZAPAIR arrays plane by plane into a small ring that the x
+//                pass consumes.
+enum { PACK_NONE = 0, PACK_ZAPAIR = 1, PACK_PLT3 = 2, PACK_ZAFIELD = 3 };
+
+// Field store addressing.  chunk c = the rank that generated the rows (ky = c + G*slot), inside a chunk
+// [plane zl][field f < 4][slot][compact x].  Row `slot` keeps the columns x < split and x >= split + gap
+// (kx in (-w, w) rounded out to FIELD_CW columns; the same table for every chunk, taken from the longest row ky = G*slot
+// of the group), at position x (x < split) or x - gap.
+constexpr int FIELD_CW = 32;  // compaction granularity in columns (512 B): a multiple of every z / y tile width
+struct FieldRow {
+    int base;   // element offset of the row inside a (plane, field) image
+    int split;  // first column not stored on the low side (N if the whole row is stored)
+    int gap;    // columns skipped between the low and the high part
+    int pad;
+};
+struct FieldLayout {
+    int lG, lZq;                 // log2(ranks), log2(planes per chunk)
+    long long chunk_elems;       // elements per chunk = Zq * 4 * field_elems
+    long long field_elems;       // elements per (plane, field) image = sum of the row lengths
+    const FieldRow *rows;        // [Hq] device table
+};
 struct JobList {
     int n;
     int pack;

@@ -384,11 +384,12 @@ __global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, JobList 
                 sz = -sz;
             }
             vsum += dr * dr + di * di;
-            double d2r = dr, d2i = di;  // PACK_ZAPAIR: the same mode folded for the second residue of the pass
+            const double se = g.fundamental * ik2;  // even in k: the conjugated copy keeps its sign (JOB_E)
+            double d2r = dr, d2i = di;  // PACK_ZAPAIR / PACK_ZAFIELD: the same mode folded for the second residue of the pass
             if (R > 1) {  // W_R^{k1 r}
                 const cplx w = twN[(int) (((long long) k1 * residue * L) & (N - 1))];
                 const double a = dr * w.x - di * w.y, b = dr * w.y + di * w.x;
-                if (jobs.pack == PACK_ZAPAIR) {
+                if (jobs.pack == PACK_ZAPAIR || jobs.pack == PACK_ZAFIELD) {
                     const cplx w2 = twN[(int) (((long long) k1 * residue2 * L) & (N - 1))];
                     const double a2 = dr * w2.x - di * w2.y, b2 = dr * w2.y + di * w2.x;
                     d2r = a2;
@@ -411,6 +412,8 @@ __global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, JobList 
                     case JOB_XV_SELF: cr = -f * sx; ci = sx; break;
                     case JOB_XV_TWIN: cr = f * sx; ci = sx; break;
                     case JOB_FX: cr = 0.0; ci = sx; break;
+                    case JOB_E: cr = se; ci = 0.0; break;
+                    case JOB_Z: cr = sz; ci = 0.0; break;
                     default: cr = 1.0; ci = 0.0; break;
                 }
                 const double ur = jobs.res[j] ? d2r : dr, ui = jobs.res[j] ? d2i : di;
@@ -634,7 +637,8 @@ __device__ __forceinline__ double genf_power(const GenConst &g, const double *T,
 //     where S0 = sum D w, SE = sum (fund/k^2) D w, SZ = sum kz (fund/k^2) D w   (3 accumulators for the
 //     4 ZA jobs; PLT keeps 7 because its eigenvectors differ mode by mode).
 // grid: (ceil(N/GEN_BX), L/ZR, nrows)  block: GEN_BX          row kyl = kyl0 + blockIdx.z of the slab
-enum { GENF_DENS = 0, GENF_ZA = 1, GENF_PLT = 2, GENF_ZAP = 3 /* PACK_ZAPAIR */, GENF_PLTN = 4 /* PACK_PLT3 */ };
+enum { GENF_DENS = 0, GENF_ZA = 1, GENF_PLT = 2, GENF_ZAP = 3 /* PACK_ZAPAIR */, GENF_PLTN = 4 /* PACK_PLT3 */,
+       GENF_ZAF = 5 /* PACK_ZAFIELD: the sums of GENF_ZAP written out as they are (E, Z of both residues) */ };
 
 __device__ __forceinline__ void cmac(double &ar, double &ai, double c, double dr, double di) {
     ar = fma(c, dr, ar);
@@ -710,7 +714,8 @@ __device__ __forceinline__ double genf_tile(const GenConst &g, const GenJumps &J
                                             const cplx *__restrict__ twN, cplx *__restrict__ Y) {
     // field sums per k2:  DENS {S0}  ZA {S0, SE, SZ}  PLT {S0, X, Y, Z, fX, fY, fZ}  ZAP {SE, SZ}(r0), {SE, SZ}(r1)
     //                     PLTN {X, Y, Z, fX, fY, fZ}
-    constexpr int NACC = KIND == GENF_DENS ? 1 : KIND == GENF_ZA ? 3 : KIND == GENF_PLT ? 7 : KIND == GENF_ZAP ? 4 : 6;
+    constexpr bool ZA2 = KIND == GENF_ZAP || KIND == GENF_ZAF;  // two residues per pass
+    constexpr int NACC = KIND == GENF_DENS ? 1 : KIND == GENF_ZA ? 3 : KIND == GENF_PLT ? 7 : ZA2 ? 4 : 6;
     constexpr bool IS_PLT = KIND == GENF_PLT || KIND == GENF_PLTN;
     double vsum = 0.0;  // sum |D|^2 of this thread's modes (packed stores: density_variance by Parseval)
     const int N = g.N, half = g.half, R = N / L;
@@ -788,7 +793,7 @@ __device__ __forceinline__ double genf_tile(const GenConst &g, const GenJumps &J
             if (R > 1) {  // W_R^{k1 r}
                 const cplx w = twN[(int) (((long long) k1 * residue * L) & (N - 1))];
                 const double a = dr * w.x - di * w.y, b = dr * w.y + di * w.x;
-                if constexpr (KIND == GENF_ZAP) {
+                if constexpr (ZA2) {
                     const cplx w2 = twN[(int) (((long long) k1 * residue2 * L) & (N - 1))];
                     d2r = dr * w2.x - di * w2.y;
                     d2i = dr * w2.y + di * w2.x;
@@ -806,7 +811,7 @@ __device__ __forceinline__ double genf_tile(const GenConst &g, const GenJumps &J
                 accr[1] += er;
                 acci[1] += ei;
                 cmac(accr[2], acci[2], (double) kz, er, ei);
-            } else if constexpr (KIND == GENF_ZAP) {
+            } else if constexpr (ZA2) {
                 const double q  = g.fundamental * ik2, dkz = (double) kz;
                 const double er = q * dr, ei = q * di, e2r = q * d2r, e2i = q * d2i;
                 accr[0] += er;
@@ -839,7 +844,7 @@ __device__ __forceinline__ double genf_tile(const GenConst &g, const GenJumps &J
             const cplx w = twN[(int) (((long long) k2 * residue) & (N - 1))];
             pr = w.x;
             pi = w.y;
-            if constexpr (KIND == GENF_ZAP) {
+            if constexpr (ZA2) {
                 const cplx w2 = twN[(int) (((long long) k2 * residue2) & (N - 1))];
                 qr = w2.x;
                 qi = w2.y;
@@ -852,6 +857,12 @@ __device__ __forceinline__ double genf_tile(const GenConst &g, const GenJumps &J
         auto putp = [&](int j, double vr, double vi) { put(j, vr * pr - vi * pi, vr * pi + vi * pr); };
         if constexpr (KIND == GENF_DENS) {
             putp(0, accr[0], acci[0]);
+        } else if constexpr (KIND == GENF_ZAF) {
+            auto putq = [&](int j, double vr, double vi) { put(j, vr * qr - vi * qi, vr * qi + vi * qr); };
+            putp(0, accr[0], acci[0]);  // E(r0)
+            putp(1, accr[1], acci[1]);  // Z(r0)
+            putq(2, accr[2], acci[2]);  // E(r1)
+            putq(3, accr[3], acci[3]);  // Z(r1)
         } else if constexpr (KIND == GENF_ZAP) {
             const double dkx = (double) kx, dky = (double) ky;
             // residue r0: B jobs and F_x = i kx SE, all times W_N^{k2 r0}
@@ -906,7 +917,8 @@ template <int ZR, int KIND, bool PLAW>
 __device__ __forceinline__ double genf_tile_mirror(const GenConst &g, const GenJumps &J, const StoreLayout &S, const double *T,
                                                    int zW, int ky0, int kyl, int nky, int L, int residue, int residue2, int bx,
                                                    int by, const cplx *__restrict__ twN, cplx *__restrict__ Y) {
-    static_assert(KIND == GENF_DENS || KIND == GENF_ZA || KIND == GENF_ZAP, "ZA kinds only");
+    static_assert(KIND == GENF_DENS || KIND == GENF_ZA || KIND == GENF_ZAP || KIND == GENF_ZAF, "ZA kinds only");
+    constexpr bool ZA2 = KIND == GENF_ZAP || KIND == GENF_ZAF;  // two residues per pass
     constexpr int NACC = KIND == GENF_DENS ? 1 : KIND == GENF_ZA ? 3 : 4;
     double vsum = 0.0;
     const int N = g.N, half = g.half, R = N / L;
@@ -983,7 +995,7 @@ __device__ __forceinline__ double genf_tile_mirror(const GenConst &g, const GenJ
                 const cplx w = twN[(int) (((long long) k1 * residue * L) & (N - 1))];
                 wr = w.x;
                 wi = w.y;
-                if constexpr (KIND == GENF_ZAP) {
+                if constexpr (ZA2) {
                     const cplx w2 = twN[(int) (((long long) k1 * residue2 * L) & (N - 1))];
                     w2r = w2.x;
                     w2i = w2.y;
@@ -1033,7 +1045,7 @@ __device__ __forceinline__ double genf_tile_mirror(const GenConst &g, const GenJ
             const cplx w = twN[(int) (((long long) k2 * residue) & (N - 1))];
             pr = w.x;
             pi = w.y;
-            if constexpr (KIND == GENF_ZAP) {
+            if constexpr (ZA2) {
                 const cplx w2 = twN[(int) (((long long) k2 * residue2) & (N - 1))];
                 qr = w2.x;
                 qi = w2.y;
@@ -1054,6 +1066,12 @@ __device__ __forceinline__ double genf_tile_mirror(const GenConst &g, const GenJ
                 putp(1, ar[0] + xr, ai[0] + xi);       // JOB_A_TWIN
                 putp(2, -ar[2] - yi, -ai[2] + yr);     // JOB_B_SELF
                 putp(3, ar[2] - yi, ai[2] + yr);       // JOB_B_TWIN
+            } else if constexpr (KIND == GENF_ZAF) {
+                auto putq = [&](int j, double vr, double vi) { put(j, vr * qr - vi * qi, vr * qi + vi * qr); };
+                putp(0, ar[0], ai[0]);                 // E(r0)
+                putp(1, ar[1], ai[1]);                 // Z(r0)
+                putq(2, ar[2], ai[2]);                 // E(r1)
+                putq(3, ar[3], ai[3]);                 // Z(r1)
             } else {
                 auto putq = [&](int j, double vr, double vi) { put(j, vr * qr - vi * qi, vr * qi + vi * qr); };
                 const double y0r = dky * ar[0], y0i = dky * ai[0], y1r = dky * ar[2], y1i = dky * ai[2];
@@ -1297,6 +1315,124 @@ __global__ __launch_bounds__(W *N / E, MINW) void k_yfft(StoreLayout S, const cp
         asm volatile("" : "+v"(t2));  // see above: do not carry the load offsets across the FFT
 #pragma unroll
         for (int e = 0; e < E; e++) base[row_offset(S, zl, a, t2 + T * e)] = cplx{re[e], im[e]};
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Field store (PACK_ZAFIELD, zd_device.h): z stage and y stage.
+//
+// k_zfft_f: length-L FFT of one potential (E or Z of one residue) for a W-wide column tile of a half-space row, stored
+// at (row slot, compact column).  No Hermitian twins are written: the y stage rebuilds them from the symmetry
+//      E(-ky, -kx) = conj E(ky, kx),   Z(-ky, -kx) = -conj Z(ky, kx)      (E, i Z: z-transforms of real fields)
+//   grid: (N/W, nky, 4)   block: W*L/E
+template <int L, int E, int W>
+__global__ __launch_bounds__(W *L / E) void k_zfft_f(FieldLayout F, StoreLayout S, int ky0, int kyloc0, int nky,
+                                                    const cplx *__restrict__ Y, const cplx *__restrict__ twL,
+                                                    cplx *__restrict__ out) {
+    static_assert(W <= FIELD_CW && FIELD_CW % W == 0, "a z tile must not straddle a compaction boundary");
+    using PL  = zdfft::Plan<L, E>;
+    using LDS = zdfft::ColsInner<L, W>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int T = PL::T;
+    const int N = S.N;
+    const int w = threadIdx.x % W, t = threadIdx.x / W;
+    const int kyl = blockIdx.y;
+    const int ky  = ky0 + kyl * S.ky_stride;
+    const int x   = blockIdx.x * W + w;
+    if (S.prune & 2) {  // tile of identically-zero columns: the generator produced nothing, the y stage will not read it
+        if (__syncthreads_and(column_is_zero(S, x > S.half ? x - N : x, ky))) return;
+    }
+    const char *src = reinterpret_cast<const char *>(Y + (((long long) blockIdx.z * nky + kyl) * L) * N);
+    const unsigned xb = (unsigned) x * 16u, rb = (unsigned) N * 16u;
+    double re[E], im[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const cplx v = *reinterpret_cast<const cplx *>(src + ((unsigned) (t + T * e) * rb + xb));
+        re[e] = v.x;
+        im[e] = v.y;
+    }
+    zdfft::fft_line<PL, LDS>(re, im, t, w, lds, twL);
+    const FieldRow row = F.rows[kyloc0 + kyl];  // workgroup-uniform
+    const unsigned pos = (unsigned) (x < row.split ? x : x - row.gap);
+    const int Zq = 1 << F.lZq;
+    int t2 = t;
+    asm volatile("" : "+v"(t2));  // keep the store-address arithmetic after the FFT (register pressure)
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int z2  = t2 + T * e;
+        const int dst = z2 >> F.lZq, zl = z2 & (Zq - 1);
+        out[(long long) dst * F.chunk_elems + (long long) (zl * 4 + (int) blockIdx.z) * F.field_elems + (unsigned) row.base + pos]
+            = cplx{re[e], im[e]};
+    }
+}
+
+// k_yfft_f: y FFT of one PACK_ZAPAIR array (a = 0: (qy + i qz)_r0, 1: (qy + i qz)_r1, 2: qx_r0 + i qx_r1) of one
+// store plane, built on the fly from the potentials (replaces LoadBlock's y shift + the Nyquist-row zeroing + half of
+// Inverse2dFFT, block_array.cpp:466-504, zeldovich.cpp:644-658):
+//   rows y < N/2 (ky = y):      B_r = -Z_r + i ky E_r              X = i kx E_0 - kx E_1
+//   rows y > N/2 (ky = y - N):  read row N - y at column N - x, conjugated (Z anti-Hermitian):
+//                               B_r = conj Z_r - i (N-y) conj E_r   X = i kx conj E_0 - kx conj E_1
+//   row  y = N/2 and columns the zero rule kills: 0, not read.
+// Output: ring[plane][a][row slot][x] in the single-rank block-store layout k_xfft reads.
+//   grid: (N/W, 3, planes)   block: W*N/E
+template <int N, int E, int W>
+__global__ __launch_bounds__(W *N / E) void k_yfft_f(FieldLayout F, StoreLayout S, const cplx *__restrict__ tw,
+                                                    const cplx *__restrict__ store, int plane0, int ring_pitch,
+                                                    cplx *__restrict__ ring) {
+    using PL  = zdfft::Plan<N, E>;
+    using LDS = zdfft::ColsInner<N, W>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int T = PL::T;
+    const int w = threadIdx.x % W, t = threadIdx.x / W;
+    constexpr int G = W >= 8 ? 1 : 8 / W;  // tiles sharing a 128-byte line go to ONE XCD (see k_yfft)
+    int tile = blockIdx.x;
+    if constexpr (G > 1 && (N / W) % (8 * G) == 0) tile = ((tile / (8 * G)) * 8 + (tile % 8)) * G + ((tile / 8) % G);
+    const int x = tile * W + w, xm = (N - x) & (N - 1);
+    const int a = blockIdx.y, zl = plane0 + blockIdx.z;
+    const int kx = x > N / 2 ? x - N : x;
+    // fields combined by this array: (E, Z) of residue a, or (E_0, E_1) for the x displacements
+    const int f0 = a == 2 ? 0 : 2 * a, f1 = a == 2 ? 2 : 2 * a + 1;
+    const cplx *p0 = store + (long long) (zl * 4 + f0) * F.field_elems;
+    const long long d01 = (long long) (f1 - f0) * F.field_elems;
+    const int gmask = (1 << F.lG) - 1;
+    double re[E], im[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int y = t + T * e;
+        const bool mir = y > N / 2;
+        const int kyp = mir ? N - y : y;  // the half-space row that holds the data
+        const int xs  = mir ? xm : x;
+        const bool skip = (y == N / 2) || ((S.prune & 4) && column_is_zero(S, kx, kyp));
+        double vr = 0.0, vi = 0.0;
+        if (!skip) {
+            const FieldRow row = F.rows[kyp >> F.lG];
+            const unsigned pos = (unsigned) (xs < row.split ? xs : xs - row.gap);
+            const cplx *q = p0 + ((long long) (kyp & gmask) * F.chunk_elems + (unsigned) row.base + pos);
+            const cplx u = q[0], v = q[d01];
+            const double s = mir ? -1.0 : 1.0;
+            if (a == 2) {  // u = E_0, v = E_1
+                const double dk = (double) kx;
+                vr = -dk * (s * u.y + v.x);
+                vi = dk * (u.x - s * v.y);
+            } else {  // u = E_r, v = Z_r
+                const double dk = (double) kyp;
+                vr = -s * v.x - dk * u.y;
+                vi = -v.y + s * dk * u.x;
+            }
+        }
+        re[e] = vr;
+        im[e] = vi;
+    }
+    zdfft::fft_line<PL, LDS>(re, im, t, w, lds, tw);
+    char *base = reinterpret_cast<char *>(ring + ((long long) ((int) blockIdx.z * 3 + a) * N) * ring_pitch);
+    const unsigned xb = (unsigned) x * 16u, pb = (unsigned) ring_pitch * 16u;
+    int t2 = t;
+    asm volatile("" : "+v"(t2));
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int y = t2 + T * e;
+        const unsigned slot = y < N / 2 ? y : (y == N / 2 ? N / 2 : N / 2 + (N - y));
+        *reinterpret_cast<cplx *>(base + (slot * pb + xb)) = cplx{re[e], im[e]};
     }
 }
 
@@ -1681,7 +1817,7 @@ static int launch_genf_t(const GenConst &g, const GenJumps &J, const StoreLayout
                          int L, int residue, int residue2, const void *twN, void *Y, unsigned *tile_ctr, int max_wgs,
                          hipStream_t st) {
     const int N = g.N;
-    constexpr bool za = KIND == GENF_DENS || KIND == GENF_ZA || KIND == GENF_ZAP;
+    constexpr bool za = KIND == GENF_DENS || KIND == GENF_ZA || KIND == GENF_ZAP || KIND == GENF_ZAF;
 #ifdef ZD_TUNING
     static const bool mirror_off = getenv("ZD_GEN_NO_MIRROR") != nullptr;
 #else
@@ -1718,6 +1854,7 @@ static int genf_kind(const JobList &jobs, bool plt) {
     static const int std7[7] = {JOB_A_SELF, JOB_A_TWIN, JOB_B_SELF, JOB_B_TWIN, JOB_C_BOTH, JOB_D_SELF, JOB_D_TWIN};
     static const int zap[6]  = {JOB_B_SELF, JOB_B_TWIN, JOB_B_SELF, JOB_B_TWIN, JOB_FX, JOB_FX};
     static const int pln[6]  = {JOB_XV_SELF, JOB_XV_TWIN, JOB_B_SELF, JOB_B_TWIN, JOB_D_SELF, JOB_D_TWIN};
+    static const int zaf[4]  = {JOB_E, JOB_Z, JOB_E, JOB_Z};
     auto same = [&](const int *ref, int n) {
         if (jobs.n != n) return false;
         for (int j = 0; j < n; j++)
@@ -1726,6 +1863,7 @@ static int genf_kind(const JobList &jobs, bool plt) {
     };
     if (jobs.n == 1 && jobs.kind[0] == JOB_DENS) return GENF_DENS;
     if (jobs.pack == PACK_ZAPAIR) return (!plt && same(zap, 6)) ? GENF_ZAP : -1;
+    if (jobs.pack == PACK_ZAFIELD) return (!plt && same(zaf, 4)) ? GENF_ZAF : -1;
     if (jobs.pack == PACK_PLT3) return (plt && same(pln, 6)) ? GENF_PLTN : -1;
     if (!plt && same(std7, 4)) return GENF_ZA;
     if (plt && same(std7, 7)) return GENF_PLT;
@@ -1756,6 +1894,7 @@ int launch_gen(const GenConst &g, const GenJumps &J, const JobList &jobs, const 
             FCASE(GENF_PLT)
             FCASE(GENF_ZAP)
             FCASE(GENF_PLTN)
+            FCASE(GENF_ZAF)
 #undef FCASE
             if (rc) return rc;
         }
@@ -1870,6 +2009,76 @@ static int launch_yfft_t(const StoreLayout &S, int nplanes, const void *tw, void
     ZD_LAUNCH_CHECK();
     return 0;
 }
+template <int L, int E, int W>
+static int launch_zfft_f_t(const FieldLayout &F, const StoreLayout &S, int ky0, int kyloc0, int nky, const void *Y,
+                           const void *twL, void *out, hipStream_t st) {
+    constexpr int threads = W * L / E;
+    const size_t shmem = sizeof(double) * zdfft::ColsInner<L, W>::SIZE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void *) k_zfft_f<L, E, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+        attr_set = true;
+    }
+    dim3 grid(S.N / W, nky, 4), block(threads);
+    hipLaunchKernelGGL((k_zfft_f<L, E, W>), grid, block, shmem, st, F, S, ky0, kyloc0, nky, (const cplx *) Y,
+                       (const cplx *) twL, (cplx *) out);
+    ZD_LAUNCH_CHECK();
+    return 0;
+}
+int launch_zfft_fields(int L, const FieldLayout &F, const StoreLayout &S, int ky0, int kyloc0, int nky, const void *Y,
+                       const void *twL, void *out, hipStream_t st) {
+#define ZCASE(l, e, w) \
+    case l: return launch_zfft_f_t<l, e, w>(F, S, ky0, kyloc0, nky, Y, twL, out, st);
+    switch (L) {  // the tile widths of launch_zfft / zfft_tile_width (the generator prunes by them)
+        ZCASE(32, 16, 32)
+        ZCASE(64, 16, 32)
+        ZCASE(128, 16, 32)
+        ZCASE(256, 16, 16)
+        ZCASE(512, 16, 16)
+        ZCASE(1024, 16, 8)
+        ZCASE(2048, 16, 8)
+        ZCASE(4096, 16, 4)
+    }
+#undef ZCASE
+    fprintf(stderr, "zeldovich_hip: unsupported z-FFT length %d (power of two in [32,4096] required)\n", L);
+    return 2;
+}
+
+template <int N, int E, int W>
+static int launch_yfft_f_t(const FieldLayout &F, const StoreLayout &S, const void *tw, const void *store, int plane0,
+                           int nplanes, int ring_pitch, void *ring, hipStream_t st) {
+    constexpr int threads = W * N / E;
+    const size_t shmem = sizeof(double) * zdfft::ColsInner<N, W>::SIZE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void *) k_yfft_f<N, E, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+        attr_set = true;
+    }
+    dim3 grid(N / W, 3, nplanes), block(threads);
+    hipLaunchKernelGGL((k_yfft_f<N, E, W>), grid, block, shmem, st, F, S, (const cplx *) tw, (const cplx *) store, plane0,
+                       ring_pitch, (cplx *) ring);
+    ZD_LAUNCH_CHECK();
+    return 0;
+}
+// y stage of the field store: store planes [plane0, plane0 + nplanes) -> ring planes [0, nplanes)
+int launch_yfft_fields(const FieldLayout &F, const StoreLayout &S, const void *tw, const void *store, int plane0,
+                       int nplanes, int ring_pitch, void *ring, hipStream_t st) {
+#define YCASE(n, e, w) \
+    case n: return launch_yfft_f_t<n, e, w>(F, S, tw, store, plane0, nplanes, ring_pitch, ring, st);
+    switch (S.N) {
+        YCASE(64, 16, 32)
+        YCASE(128, 16, 32)
+        YCASE(256, 16, 16)
+        YCASE(512, 16, 16)
+        YCASE(1024, 16, 8)
+        YCASE(2048, 16, 8)
+        YCASE(4096, 16, 4)
+    }
+#undef YCASE
+    fprintf(stderr, "zeldovich_hip: field store unsupported for PPD %d\n", S.N);
+    return 2;
+}
+
 int launch_yfft(const StoreLayout &S, int nplanes, const void *tw, void *data, hipStream_t st) {
 #define YCASE(n, e, w) \
     case n: return launch_yfft_t<n, e, w>(S, nplanes, tw, data, st);

@@ -18,6 +18,10 @@ int launch_test_modes_table(const GenConst &g, long long n, const int *kxyz, dou
 int launch_zfft(int L, const JobList &jobs, const StoreLayout &S, int ky0, int kyloc0, int nky, int Zq, const void *Y,
                 const void *twL, void *out, hipStream_t st);
 int zfft_tile_width(int L);
+int launch_zfft_fields(int L, const FieldLayout &F, const StoreLayout &S, int ky0, int kyloc0, int nky, const void *Y,
+                       const void *twL, void *out, hipStream_t st);
+int launch_yfft_fields(const FieldLayout &F, const StoreLayout &S, const void *tw, const void *store, int plane0,
+                       int nplanes, int ring_pitch, void *ring, hipStream_t st);
 int launch_yfft(const StoreLayout &S, int nplanes, const void *tw, void *data, hipStream_t st);
 int launch_xfft(const StoreLayout &S, const EpiConst &ec, const void *tw, const void *data, int plane0, int nplanes,
                 int z_first, int z_step, void *records, float *density, Reduce *red, hipStream_t st);

@@ -25,6 +25,13 @@ struct zd_plan {
     zd::JobList jobs;
     zd::StoreLayout S;
     zd::EpiConst ec;
+    // field store (PACK_ZAFIELD): layout of the store, and the ring the y stage fills for the x stage
+    zd::FieldLayout F;
+    zd::FieldRow *d_fieldrows = nullptr;
+    zd::StoreLayout SR;             // the ring as a single-rank block store of 3 arrays
+    zdfft::cplx *d_ring = nullptr;
+    int ring_planes = 0;
+    int64_t store_bytes_ = 0;       // bytes of the send (= receive) buffer per pass
     // device tables
     double *d_pk = nullptr;  // x | y | y2
     int *d_lut = nullptr;
