@@ -238,11 +238,12 @@ static int64_t field_rows(const zd_params *p, int nranks, std::vector<zd::FieldR
         }
         zd::FieldRow r;
         r.base  = (int) total;
-        r.split = tl >= th ? N : tl * CW;
-        r.gap   = tl >= th ? 0 : (th - tl) * CW;
-        r.pad   = 0;
+        r.split = (unsigned short) (tl >= th ? N : tl * CW);
+        r.gap   = (unsigned short) (tl >= th ? 0 : (th - tl) * CW);
         if (rows) (*rows)[i] = r;
-        total += N - r.gap;
+        // 384 B of padding per row as in the other stores: the first ~N/11 rows are complete (64 KiB apart at PPD = 4096)
+        // and the y stage reads 16 consecutive rows per wave — without the pad they all sit on one HBM channel
+        total += N - r.gap + store_row_pad(N);
     }
     return total;
 }
@@ -590,7 +591,7 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
     pl->ec.qPLT     = p->qPLT;
     pl->ec.qdensity = p->qdensity;
     pl->ec.vnorm    = p->qPLT ? 1.0 : (sqrt(1. + 24 * p->f_cluster) - 1) * .25;  // output.cpp:78-82
-    pl->ec.pack     = pl->pack == zd::PACK_ZAFIELD ? zd::PACK_ZAPAIR : pl->pack;  // the y stage rebuilds the ZAPAIR arrays
+    pl->ec.pack     = pl->pack;
     pl->ec.z_pair   = R / 2;
     pl->store_bytes_ = (int64_t) S.chunk_rows * S.pitch * nranks * 16;
     if (pl->pack == zd::PACK_ZAFIELD) {

@@ -173,8 +173,8 @@ enum JobKind {
 //                rows ky < N/2 ONLY (no Hermitian twins: 4 half fields = 2 arrays' worth instead of 3), and skips the
 //                (kx, ky) columns the zero rule kills (FieldLayout below: 21.5 % at k_cutoff = 1).  That is what lets
 //                PPD = 4096 run in 4 passes instead of 8 on one 288 GB GPU and halves the all-to-all volume between
-//                GPUs.  The y pass rebuilds the three PACK_ZAPAIR arrays plane by plane into a small ring that the x
-//                pass consumes.
+//                GPUs.  The y pass builds, plane by plane, the three arrays (qx + i qy)_r0 | (qx + i qy)_r1 | qz_r0 + i qz_r1
+//                (each potential feeds exactly one of them) into a small ring that the x pass consumes.
 enum { PACK_NONE = 0, PACK_ZAPAIR = 1, PACK_PLT3 = 2, PACK_ZAFIELD = 3 };
 
 // Field store addressing.  chunk c = the rank that generated the rows (ky = c + G*slot), inside a chunk
@@ -182,11 +182,10 @@ enum { PACK_NONE = 0, PACK_ZAPAIR = 1, PACK_PLT3 = 2, PACK_ZAFIELD = 3 };
 // (kx in (-w, w) rounded out to FIELD_CW columns; the same table for every chunk, taken from the longest row ky = G*slot
 // of the group), at position x (x < split) or x - gap.
 constexpr int FIELD_CW = 32;  // compaction granularity in columns (512 B): a multiple of every z / y tile width
-struct FieldRow {
-    int base;   // element offset of the row inside a (plane, field) image
-    int split;  // first column not stored on the low side (N if the whole row is stored)
-    int gap;    // columns skipped between the low and the high part
-    int pad;
+struct FieldRow {  // 8 bytes: one load per row in the y stage
+    int base;              // element offset of the row inside a (plane, field) image
+    unsigned short split;  // first column not stored on the low side (N if the whole row is stored)
+    unsigned short gap;    // columns skipped between the low and the high part
 };
 struct FieldLayout {
     int lG, lZq;                 // log2(ranks), log2(planes per chunk)

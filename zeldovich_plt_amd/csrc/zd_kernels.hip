@@ -1366,15 +1366,17 @@ __global__ __launch_bounds__(W *L / E) void k_zfft_f(FieldLayout F, StoreLayout 
     }
 }
 
-// k_yfft_f: y FFT of one PACK_ZAPAIR array (a = 0: (qy + i qz)_r0, 1: (qy + i qz)_r1, 2: qx_r0 + i qx_r1) of one
-// store plane, built on the fly from the potentials (replaces LoadBlock's y shift + the Nyquist-row zeroing + half of
-// Inverse2dFFT, block_array.cpp:466-504, zeldovich.cpp:644-658):
-//   rows y < N/2 (ky = y):      B_r = -Z_r + i ky E_r              X = i kx E_0 - kx E_1
-//   rows y > N/2 (ky = y - N):  read row N - y at column N - x, conjugated (Z anti-Hermitian):
-//                               B_r = conj Z_r - i (N-y) conj E_r   X = i kx conj E_0 - kx conj E_1
-//   row  y = N/2 and columns the zero rule kills: 0, not read.
+// k_yfft_f: y FFT of one of the three arrays the x stage consumes, built on the fly from the potentials (replaces
+// LoadBlock's y shift + the Nyquist-row zeroing + half of Inverse2dFFT, block_array.cpp:466-504, zeldovich.cpp:644-658).
+// The real fields are paired so that every potential is read by exactly ONE array (pairing qy with qz as the reference
+// does would make E feed two arrays and be fetched twice):
+//   a = 0, 1:  A_r = qx_r + i qy_r = (i kx - ky) E_r          (residue r = a of the pass)
+//   a = 2:     C   = qz_0 + i qz_1 = i Z_0 - Z_1
+//   rows y < N/2 (ky = y): as written.  Rows y > N/2 (ky = y - N): read row N - y at column N - x and use
+//   E(-ky, -kx) = conj E(ky, kx), Z(-ky, -kx) = -conj Z(ky, kx):   A_r = (i kx + (N-y)) conj E_r,  C = -i conj Z_0 + conj Z_1
+//   row y = N/2 and columns the zero rule kills: 0, not read.
 // Output: ring[plane][a][row slot][x] in the single-rank block-store layout k_xfft reads.
-//   grid: (N/W, 3, planes)   block: W*N/E
+//   grid: (3*N/W, 1, planes)   block: W*N/E
 template <int N, int E, int W>
 __global__ __launch_bounds__(W *N / E) void k_yfft_f(FieldLayout F, StoreLayout S, const cplx *__restrict__ tw,
                                                     const cplx *__restrict__ store, int plane0, int ring_pitch,
@@ -1384,46 +1386,84 @@ __global__ __launch_bounds__(W *N / E) void k_yfft_f(FieldLayout F, StoreLayout 
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int T = PL::T;
     const int w = threadIdx.x % W, t = threadIdx.x / W;
-    constexpr int G = W >= 8 ? 1 : 8 / W;  // tiles sharing a 128-byte line go to ONE XCD (see k_yfft)
-    int tile = blockIdx.x;
-    if constexpr (G > 1 && (N / W) % (8 * G) == 0) tile = ((tile / (8 * G)) * 8 + (tile % 8)) * G + ((tile / 8) % G);
+    // Workgroup -> (column tile, array).  Workgroups go to the 8 XCDs round-robin by their linear index and every XCD has
+    // its own L2, so the 12 workgroups that read the same lines are made consecutive ON ONE XCD: the tiles 2j, 2j+1 (they
+    // share 128-byte lines when W < 8), their mirror images NT-1-2j, NT-2-2j (rows y > N/2 are read at column N - x: a
+    // tile's mirrored reads are its mirror tile's direct reads, off by one column), for each of the three arrays.
+    constexpr int NT = N / W;
+    int tile, a;
+    if constexpr (NT % 32 == 0) {
+        const int id = blockIdx.x, xcd = id & 7, s = id >> 3;  // s: position in this XCD's stream
+        // (groups interleaved over the XCDs; giving each XCD a contiguous range of groups measured 12 % slower)
+        const int g = (s / 12) * 8 + xcd, m = s % 12;          // group of 4 tiles, member
+        const int q = m & 3;
+        a    = m >> 2;
+        tile = (q & 2) ? NT - 1 - 2 * g - (q & 1) : 2 * g + (q & 1);
+    } else {
+        tile = blockIdx.x % NT;
+        a    = blockIdx.x / NT;
+    }
     const int x = tile * W + w, xm = (N - x) & (N - 1);
-    const int a = blockIdx.y, zl = plane0 + blockIdx.z;
+    const int zl = plane0 + blockIdx.z;
     const int kx = x > N / 2 ? x - N : x;
-    // fields combined by this array: (E, Z) of residue a, or (E_0, E_1) for the x displacements
-    const int f0 = a == 2 ? 0 : 2 * a, f1 = a == 2 ? 2 : 2 * a + 1;
+    // potentials this array is made of: E_a alone, or (Z_0, Z_1)
+    const int f0 = a == 2 ? 1 : 2 * a;
     const cplx *p0 = store + (long long) (zl * 4 + f0) * F.field_elems;
-    const long long d01 = (long long) (f1 - f0) * F.field_elems;
+    const long long d01 = a == 2 ? 2 * F.field_elems : 0;  // Z_1 sits two fields after Z_0
     const int gmask = (1 << F.lG) - 1;
     double re[E], im[E];
+    // Branch-free in three steps so that the loads of many rows are in flight together (as `if (!skip) { table load,
+    // two data loads, combine }` the compiler emitted one branch and one full wait per row: 1.65x the time of k_yfft):
+    // (1) the row records of all E rows, (2) in batches of BATCH rows the two potentials, from a clamped (always valid)
+    // address, (3) combine, zero for skipped rows.
+    FieldRow rows[E];
 #pragma unroll
     for (int e = 0; e < E; e++) {
         const int y = t + T * e;
-        const bool mir = y > N / 2;
-        const int kyp = mir ? N - y : y;  // the half-space row that holds the data
-        const int xs  = mir ? xm : x;
-        const bool skip = (y == N / 2) || ((S.prune & 4) && column_is_zero(S, kx, kyp));
-        double vr = 0.0, vi = 0.0;
-        if (!skip) {
-            const FieldRow row = F.rows[kyp >> F.lG];
-            const unsigned pos = (unsigned) (xs < row.split ? xs : xs - row.gap);
-            const cplx *q = p0 + ((long long) (kyp & gmask) * F.chunk_elems + (unsigned) row.base + pos);
-            const cplx u = q[0], v = q[d01];
-            const double s = mir ? -1.0 : 1.0;
-            if (a == 2) {  // u = E_0, v = E_1
-                const double dk = (double) kx;
-                vr = -dk * (s * u.y + v.x);
-                vi = dk * (u.x - s * v.y);
-            } else {  // u = E_r, v = Z_r
-                const double dk = (double) kyp;
-                vr = -s * v.x - dk * u.y;
-                vi = -v.y + s * dk * u.x;
-            }
-        }
-        re[e] = vr;
-        im[e] = vi;
+        int kyp = y > N / 2 ? N - y : y;
+        kyp = kyp < N / 2 ? kyp : N / 2 - 1;  // the Nyquist row is never used: any valid record
+        rows[e] = F.rows[kyp >> F.lG];
     }
-    zdfft::fft_line<PL, LDS>(re, im, t, w, lds, tw);
+    constexpr int BATCH = 4;
+#pragma unroll
+    for (int b = 0; b < E; b += BATCH) {
+        cplx u[BATCH], v[BATCH];
+        bool skip[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; j++) {
+            const int e = b + j, y = t + T * e;
+            const bool mir = y > N / 2;
+            const int kyp = mir ? N - y : y;  // the half-space row that holds the data
+            const int xs  = (mir && !ZD_TUNE(S.prune & 1024)) ? xm : x;  // bit 10: tuning ablation (aligned mirror reads)
+            skip[j] = (y == N / 2) || ((S.prune & 4) && column_is_zero(S, kx, kyp));
+            const int split = rows[e].split, gap = rows[e].gap;
+            // skipped rows read element 0 of the chunk image (their own record may describe an empty row at the very end)
+            const unsigned off = skip[j] ? 0u : (unsigned) rows[e].base + (unsigned) (xs < split ? xs : xs - gap);
+            const cplx *q = p0 + ((long long) (kyp & gmask) * F.chunk_elems + off);
+            u[j] = q[0];
+            if (a == 2) v[j] = q[d01];  // workgroup-uniform: the A arrays issue one load per row
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; j++) {
+            const int e = b + j, y = t + T * e;
+            const bool mir = y > N / 2;
+            const double s = mir ? -1.0 : 1.0;
+            double vr, vi;
+            if (a == 2) {  // u = Z_0, v = Z_1:  i u - v,  mirrored -i conj u + conj v
+                vr = -u[j].y - s * v[j].x;
+                vi = s * u[j].x - v[j].y;
+            } else {  // u = E_r:  (i kx - ky) u,  mirrored (i kx + (N - y)) conj u
+                const double dky = (double) (mir ? N - y : y), dkx = (double) kx;
+                vr = -s * (dky * u[j].x + dkx * u[j].y);
+                vi = dkx * u[j].x - dky * u[j].y;
+            }
+            re[e] = skip[j] ? 0.0 : vr;
+            im[e] = skip[j] ? 0.0 : vi;
+        }
+    }
+    if (ZD_TUNE(S.prune & 4096) && a == 2) return;                           // bit 12: tuning ablation (no x array)
+    if (!ZD_TUNE(S.prune & 128)) zdfft::fft_line<PL, LDS>(re, im, t, w, lds, tw);  // bit 7: tuning ablation
+    if (ZD_TUNE(S.prune & 256) && re[0] != 123.456) return;                  // bit 8: tuning ablation (no stores)
     char *base = reinterpret_cast<char *>(ring + ((long long) ((int) blockIdx.z * 3 + a) * N) * ring_pitch);
     const unsigned xb = (unsigned) x * 16u, pb = (unsigned) ring_pitch * 16u;
     int t2 = t;
@@ -1558,10 +1598,14 @@ __global__ __launch_bounds__(ROWS *NA *N / E, (ROWS * NA * N / E == 512 ? 4 : 1)
                     const double pos[3] = {f[0], f[2 * NXH], f[3 * NXH]};
                     const double vel[3] = {f[1 * NXH] * ec.vnorm, f[4 * NXH] * ec.vnorm, f[5 * NXH] * ec.vnorm};
                     finish(plane_rec0 + (long long) yy * N + xx, z, pos, vel);
-                } else {  // PACK_ZAPAIR: (qy + i qz)_r0 | (qy + i qz)_r1 | qx_r0 + i qx_r1 -> two planes, z and z + z_pair
+                } else {  // two planes, z and z + z_pair, from the three arrays
+                    // PACK_ZAPAIR: (qy + i qz)_r0 | (qy + i qz)_r1 | qx_r0 + i qx_r1      PACK_ZAFIELD (ring of k_yfft_f):
+                    // (qx + i qy)_r0 | (qx + i qy)_r1 | qz_r0 + i qz_r1
+                    const bool fld3 = ec.pack == PACK_ZAFIELD;
 #pragma unroll
                     for (int w2 = 0; w2 < 2; w2++) {
-                        const double pos[3] = {f[(4 + w2) * NXH], f[(2 * w2) * NXH], f[(2 * w2 + 1) * NXH]};
+                        const double pos[3] = {f[(fld3 ? 2 * w2 : 4 + w2) * NXH], f[(fld3 ? 2 * w2 + 1 : 2 * w2) * NXH],
+                                               f[(fld3 ? 4 + w2 : 2 * w2 + 1) * NXH]};
                         const double vel[3] = {pos[0] * ec.vnorm, pos[1] * ec.vnorm, pos[2] * ec.vnorm};
                         finish(2 * plane_rec0 + (long long) w2 * N * N + (long long) yy * N + xx, z + w2 * ec.z_pair, pos, vel);
                     }
@@ -2054,7 +2098,7 @@ static int launch_yfft_f_t(const FieldLayout &F, const StoreLayout &S, const voi
         hipFuncSetAttribute((const void *) k_yfft_f<N, E, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
         attr_set = true;
     }
-    dim3 grid(N / W, 3, nplanes), block(threads);
+    dim3 grid(3 * (N / W), 1, nplanes), block(threads);
     hipLaunchKernelGGL((k_yfft_f<N, E, W>), grid, block, shmem, st, F, S, (const cplx *) tw, (const cplx *) store, plane0,
                        ring_pitch, (cplx *) ring);
     ZD_LAUNCH_CHECK();
