@@ -186,35 +186,58 @@ def main():
     if rank == 0:
         particles = float(N) ** 3
         value = particles * args.steps / dt
-        # per-kernel algorithmic bytes per particle (64*a + S_out split over the passes)
-        alg = {"k_zfft": 16.0 * narray, "k_yfft": 32.0 * narray, "k_xfft": 16.0 * narray + recsize}
+        # SURVEY §8d algorithmic bytes per particle, split over the three units of the path (64*a + S_out in all; a = the
+        # REFERENCE's array count).  The Z stage is ONE unit: generator and z FFT overlap on two streams, their own
+        # hipEvent spans include each other; `z_stage` is first generator launch .. last z FFT of a pass.
+        alg = {"z_stage": 16.0 * narray, "k_yfft": 32.0 * narray, "k_xfft": 16.0 * narray + recsize}
         kms, kl = st["kernel_ms"], st["kernel_launches"]
-        dom = max(alg, key=lambda k: kms[k])
-        launches = max(1, kl[dom])
-        per_launch_particles = particles * args.steps / world / launches
-        avg_ms = kms[dom] / launches
-        achieved = alg[dom] * per_launch_particles / (avg_ms * 1e-3) / 1e9
-        per_kernel = {k: {"alg_GBps": alg[k] * particles * args.steps / world / (kms[k] * 1e-3) / 1e9 if kms[k] > 0 else None,
-                          "ms_per_step": kms[k] / args.steps, "launches_per_step": kl[k] / args.steps,
-                          "alg_bytes_per_particle": alg[k]} for k in alg}
-        per_kernel["k_gen"] = {"alg_GBps": None, "ms_per_step": kms["k_gen"] / args.steps,
-                               "launches_per_step": kl["k_gen"] / args.steps, "alg_bytes_per_particle": 0.0,
-                               "bound": "fp64/int VALU: 2 pcg64 steps + Box-Muller + P(k) per mode, regenerated for each of the R residue passes"}
-        isolated = None
-        if iso is not None:
-            ims = iso["kernel_ms"]
-            isolated = {k: {"ms_per_step": ims[k],
-                            "alg_GBps": (alg[k] * particles / (ims[k] * 1e-3) / 1e9) if k in alg and ims[k] > 0 else None}
-                        for k in ims}
-        traffic = None
+        # bytes this implementation moves BY CONSTRUCTION per step (every buffer touched once; what rocprof's PMC
+        # counters should approach): store = block store of all passes, inter = what the y stage hands to the x stage
+        store_b = float(plan.exchange_bytes) * plan.passes
+        fields = plan.store_mode == "fields"
+        inter_b = 1.5 * particles * 16 if fields else store_b
+        design = {"z_stage": 3.0 * store_b,                       # folded inputs written + read, store written
+                  "k_yfft": (store_b + inter_b) if fields else 2.0 * store_b,
+                  "k_xfft": inter_b + recsize * particles}
+        traffic_file = None
         tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                if tj.get("workload") == "PPD=%d plt=%d" % (N, int(plt)):
-                    traffic = tj.get("bytes_per_launch", {}).get(dom)
+                if tj.get("workload") == "PPD=%d plt=%d" % (N, int(plt)) and tj.get("store_arrays") == plan.narray \
+                        and tj.get("passes") == plan.passes:
+                    traffic_file = tj
             except Exception:
-                traffic = None
+                traffic_file = None
+
+        def unit(k, ms, launches):
+            if ms <= 0 or launches <= 0:
+                return None
+            per_launch = alg[k] * particles * args.steps / world / launches
+            d = {"ms_per_step": ms / args.steps, "launches_per_step": launches / args.steps, "avg_launch_ms": ms / launches,
+                 "alg_bytes_per_particle": alg[k], "alg_bytes_per_launch": per_launch,
+                 "alg_GBps": per_launch / (ms / launches * 1e-3) / 1e9,
+                 "design_bytes_per_step": design[k] / world,
+                 "design_GBps": design[k] / world * args.steps / (ms * 1e-3) / 1e9}
+            if traffic_file:
+                d["pmc_bytes_per_launch"] = traffic_file.get("bytes_per_launch", {}).get(k)
+            return d
+
+        per_kernel = {k: unit(k, kms[k], kl[k]) for k in alg}
+        for k in ("k_gen", "k_zfft"):  # members of the Z stage, spans overlap each other in the timed region
+            per_kernel[k] = {"ms_per_step": kms[k] / args.steps, "launches_per_step": kl[k] / args.steps,
+                             "note": "overlapped span inside z_stage"}
+        per_kernel["k_gen"]["bound"] = ("fp64/int VALU: 2 pcg64 steps + Box-Muller + P(k) per mode, regenerated for each "
+                                        "of the %d passes" % plan.passes)
+        dom = max(alg, key=lambda k: kms[k])
+        du = per_kernel[dom]
+        isolated = None
+        if iso is not None:
+            ims = iso["kernel_ms"]
+            isolated = {k: {"ms_per_step": ims[k]} for k in ims}
+            for k in ("k_yfft", "k_xfft"):
+                if ims[k] > 0:
+                    isolated[k]["alg_GBps"] = alg[k] * particles / (ims[k] * 1e-3) / 1e9
         out = {
             "metric": "particles/sec (grid->displacements)", "value": value, "unit": "particles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -223,30 +246,23 @@ def main():
                 ", synthetic ppd_e=128 PLT eigenmodes" if plt else ""),
             "config": {"workload": "PPD=%d %s ICFormat=%s seed=12346 BoxSize=720" % (
                 N, "ZD_qPLT=1 ZD_qPLT_rescale=1" if plt else "ZA (ZD_qPLT=0)", fmt),
-                "stream_factor": R, "modes_cached": st["modes_cached"], "narray": narray,  # the reference's array count (SURVEY §8d prices the roofline with it)
-                "store_arrays": plan.narray, "passes": plan.passes,
+                "stream_factor": R, "narray_reference": narray,
+                "store": ("fields E,Z of the half-space rows, zero columns not stored" if fields else
+                          "%d arrays" % plan.narray), "passes": plan.passes,
                 "block_store_GB": plan.exchange_bytes / 1e9, "parallelism": "ky/z slabs x%d" % world},
             "hbm_GBps_path": (64.0 * narray + recsize) * value / 1e9,
             "roofline_path_frac": (64.0 * narray + recsize) * value / 1e9 / (HBM_PEAK_GBS * world),
-            "kernel_ms_per_step": {k: v / args.steps for k, v in kms.items()},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_launch_ms": avg_ms, "launches": launches,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": du["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": du["alg_GBps"] / HBM_PEAK_GBS, "traffic": du.get("pmc_bytes_per_launch"),
+                         "avg_launch_ms": du["avg_launch_ms"], "launches": kl[dom],
+                         "alg_bytes_per_launch": du["alg_bytes_per_launch"],
                          "alg_bytes_per_particle": alg[dom],
-                         "note": "k_gen (VALU-bound) and k_zfft (HBM-bound) run concurrently on two streams: their "
-                                 "hipEvent spans in the timed region include each other; `kernels_isolated` has "
-                                 "every kernel alone on the chip (one extra untimed pass)"},
+                         "note": "achieved = SURVEY 8d algorithmic bytes of this unit per launch / hipEvent launch time "
+                                 "(launch stream, timed region): a figure of merit against the reference's traffic, not "
+                                 "bytes moved — this implementation moves fewer (design_bytes_per_step; PMC in traffic)"},
             "kernels": per_kernel,
             "kernels_isolated": isolated,
         }
-        if isolated and all(isolated.get(k, {}).get("ms_per_step", 0) > 0 for k in alg):
-            # the FFT + displacement part of the pass (the three HBM-bound kernels alone), priced like the whole path
-            ms_fft = sum(isolated[k]["ms_per_step"] for k in alg)
-            rate = (64.0 * narray + recsize) * particles / (ms_fft * 1e-3) / 1e9
-            out["fft_passes_isolated"] = {"ms_per_step": ms_fft, "alg_GBps": rate, "frac": rate / HBM_PEAK_GBS}
-        if isolated and isolated.get(dom, {}).get("alg_GBps"):
-            out["roofline"]["isolated_achieved"] = isolated[dom]["alg_GBps"]
-            out["roofline"]["isolated_frac"] = isolated[dom]["alg_GBps"] / HBM_PEAK_GBS
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(N, plt, fmt, eig)

@@ -80,7 +80,10 @@ typedef struct zd_pk {
 } zd_pk;
 
 /* Names of the kernels in timing arrays */
-enum { ZD_K_GEN = 0, ZD_K_ZFFT = 1, ZD_K_YFFT = 2, ZD_K_XFFT = 3, ZD_K_COUNT = 4 };
+enum { ZD_K_GEN = 0, ZD_K_ZFFT = 1, ZD_K_YFFT = 2, ZD_K_XFFT = 3,
+       ZD_K_ZSTAGE = 4, /* the Z stage as one unit: first generator launch .. last z FFT of a pass (the two kernels overlap
+                         * on two streams, so their own spans include each other) */
+       ZD_K_COUNT = 5 };
 
 typedef struct zd_stats {
     double max_disp[3];      /* output.cpp:28: signed value of the largest |displacement| per axis (x,y,z) */
@@ -134,6 +137,7 @@ int32_t zd_plan_narray(const zd_plan *plan);       /* arrays of the store: 1, 2 
                                                      * ZA packs TWO z-residues per pass (qy+i qz of each, qx_r0 + i qx_r1),
                                                      * PLT packs qx+i vx | qy+i qz | vy+i vz; density_variance then comes
                                                      * from sum |D(k)|^2 (Parseval) */
+int32_t zd_plan_store_mode(const zd_plan *plan);   /* ZD_STORE_REFERENCE / _PACKED / _FIELDS: what the store of this plan holds */
 int32_t zd_plan_stream_factor(const zd_plan *plan);/* R: z-residue classes */
 int32_t zd_plan_passes(const zd_plan *plan);       /* passes per run: R, or R/2 when a pass carries two residues */
 int32_t zd_plan_plane_step(const zd_plan *plan);   /* 1, or 2 when a pass carries two residues: stage_x plane ranges

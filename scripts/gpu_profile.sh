@@ -5,7 +5,7 @@
 # Summaries are copied to profiles/ by hand afterwards (profiles/README.md).
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-TAG=${TAG:-r01b}
+TAG=${TAG:-r02a}
 ARGS=${ARGS:-}
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-isolated $ARGS > $R/gpurun_out/prof_${TAG}_bench.log 2>&1 || { tail -5 $R/gpurun_out/prof_${TAG}_bench.log; exit 1; }
@@ -32,18 +32,26 @@ for c in ("FETCH_SIZE","WRITE_SIZE"):
             res[k][c]={"launches":n,"total_KB":v}; o.write('"%s",%d,%.1f\n'%(k,n,v))
 line=json.loads([l for l in open(f"{R}/gpurun_out/pmc_{TAG}_FETCH_SIZE.log").read().splitlines() if l.startswith('{"metric"')][-1])
 wl=line["config"]["workload"]
-out={"workload": "PPD=%s plt=%d" % (wl.split()[0].split("=")[1], 1 if "qPLT=1" in wl else 0), "bytes_per_launch": {},
+out={"workload": "PPD=%s plt=%d" % (wl.split()[0].split("=")[1], 1 if "qPLT=1" in wl else 0),
+     "store_arrays": 3 if ("fields" in line["config"]["store"] or line["config"]["store"].startswith("3")) else int(line["config"]["store"].split()[0]),
+     "passes": line["config"]["passes"], "bytes_per_launch": {}, "bytes_per_step": {},
      "note": "(2*FETCH_SIZE + WRITE_SIZE)*1024/launches: gfx950 FETCH_SIZE counts half of wide coalesced reads (MI355X_MICROARCH.md, HBM)"}
 for k,v in res.items():
     if not k.startswith("k_") or "FETCH_SIZE" not in v or "WRITE_SIZE" not in v: continue
     n=v["FETCH_SIZE"]["launches"]
     fetch=2*v["FETCH_SIZE"]["total_KB"]*1024; write=v["WRITE_SIZE"]["total_KB"]*1024
-    name={"k_genf":"k_gen"}.get(k,k)
+    name={"k_genf":"k_gen","k_zfft_f":"k_zfft","k_yfft_f":"k_yfft"}.get(k,k)
     out["bytes_per_launch"][name]=out["bytes_per_launch"].get(name,0)+(fetch+write)/n
+    out["bytes_per_step"][name]=out["bytes_per_step"].get(name,0)+(fetch+write)
     print(k,"launches",n,"fetch GB (x2)",round(fetch/1e9,1),"write GB",round(write/1e9,1),"per launch MB",round((fetch+write)/n/1e6,1))
+# the Z stage as one unit (bench.py's z_stage): generator + z FFT bytes per pass
+zs=sum(out["bytes_per_step"].get(k,0) for k in ("k_gen","k_zfft"))
+if zs: out["bytes_per_launch"]["z_stage"]=zs/line["config"]["passes"]; out["bytes_per_step"]["z_stage"]=zs
 json.dump(out,open(f"{R}/gpurun_out/traffic_{TAG}.json","w"),indent=1)
 PY
 cat $(find $R/gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1) | head -8 | cut -c1-200
 cp gpurun_out/traffic_$TAG.json profiles/traffic_latest.json
 timeout 900 python bench.py $ARGS 2>&1 | tail -1 > gpurun_out/bench_$TAG.json; python3 -c "
 import json;d=json.load(open('gpurun_out/bench_$TAG.json'));print(d['value'],d['ms_per_step'],d['roofline_path_frac']);print(d['cpu_baseline']);print(d['roofline']);print(d['kernels_isolated'])"
+cp gpurun_out/bench_$TAG.json gpurun_out/prof_${TAG}_bench.log gpurun_out/pmc_${TAG}_*_summary.csv gpurun_out/traffic_$TAG.json gpurun_out/ 2>/dev/null
+find gpurun_out/prof_$TAG -name "*kernel_stats.csv" -exec cp {} gpurun_out/${TAG}_kernel_stats.csv \;

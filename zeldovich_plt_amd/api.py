@@ -21,7 +21,7 @@ RECORD_DTYPES = {
     "RVdoubleZel": np.dtype([("ijk", "<u2", 3), ("pad", "<u2"), ("d", "<f8", 3), ("v", "<f8", 3)]),
     "ZelSimple": np.dtype([("d", "<f4", 3)]),
 }
-KERNEL_NAMES = ("k_gen", "k_zfft", "k_yfft", "k_xfft")
+KERNEL_NAMES = ("k_gen", "k_zfft", "k_yfft", "k_xfft", "z_stage")
 
 
 class ZdParams(C.Structure):
@@ -50,7 +50,7 @@ class ZdPk(C.Structure):
 class ZdStats(C.Structure):
     _fields_ = [
         ("max_disp", C.c_double * 3), ("density_variance", C.c_double), ("seconds_total", C.c_double),
-        ("kernel_ms", C.c_double * 4), ("kernel_launches", C.c_int64 * 4),
+        ("kernel_ms", C.c_double * 5), ("kernel_launches", C.c_int64 * 5),
         ("bytes_intermediate", C.c_int64), ("stream_factor", C.c_int32), ("modes_cached", C.c_int32),
     ]
 
@@ -71,7 +71,7 @@ SLAB_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c
 
 # every symbol include/zeldovich_hip.h declares (checked by tests/test_capi_symbols.py)
 EXPORTED_SYMBOLS = [
-    "zd_generate", "zd_choose_stream_factor", "zd_plan_create", "zd_plan_destroy", "zd_plan_narray",
+    "zd_generate", "zd_choose_stream_factor", "zd_plan_create", "zd_plan_destroy", "zd_plan_narray", "zd_plan_store_mode",
     "zd_plan_stream_factor", "zd_plan_passes", "zd_plan_plane_step", "zd_plan_record_size", "zd_plan_exchange_bytes", "zd_plan_local_planes",
     "zd_plan_plane_z", "zd_plan_stage_z", "zd_plan_stage_y", "zd_plan_stage_x", "zd_plan_stats",
     "zd_params_from_file", "zd_pk_create_from_file", "zd_pk_create_powerlaw", "zd_pk_power",
@@ -105,7 +105,7 @@ def load_library():
     L.zd_plan_create.argtypes = [C.POINTER(ZdParams), C.POINTER(ZdPk), vp, i64, C.c_int, C.c_int, C.POINTER(vp)]
     L.zd_plan_destroy.argtypes = [vp]
     L.zd_plan_destroy.restype = None
-    for name in ("zd_plan_narray", "zd_plan_stream_factor", "zd_plan_record_size", "zd_plan_passes", "zd_plan_plane_step"):
+    for name in ("zd_plan_narray", "zd_plan_store_mode", "zd_plan_stream_factor", "zd_plan_record_size", "zd_plan_passes", "zd_plan_plane_step"):
         getattr(L, name).argtypes = [vp]
         getattr(L, name).restype = i32
     for name in ("zd_plan_exchange_bytes", "zd_plan_local_planes"):
@@ -294,6 +294,7 @@ class Plan:
         self.h = h
         self.rank, self.nranks = rank, nranks
         self.narray = self.L.zd_plan_narray(h)
+        self.store_mode = [k for k, v in STORE_MODES.items() if v == self.L.zd_plan_store_mode(h)][0]
         self.R = self.L.zd_plan_stream_factor(h)
         self.passes = self.L.zd_plan_passes(h)          # R, or R/2 when a pass carries two z-residues
         self.plane_step = self.L.zd_plan_plane_step(h)  # stage_x plane ranges are multiples of it

@@ -131,6 +131,21 @@ void tick(zd_plan *pl, int kind, hipStream_t st, bool begin) {
     }
 }
 
+// span events (begin and end recorded at different places, other ticks in between)
+int span_begin(zd_plan *pl, int kind, hipStream_t st) {
+    if (!pl->p.profile) return -1;
+    EventPair ep;
+    hipEventCreate(&ep.a);
+    hipEventCreate(&ep.b);
+    ep.kind = kind;
+    hipEventRecord(ep.a, st);
+    pl->events.push_back(ep);
+    return (int) pl->events.size() - 1;
+}
+void span_end(zd_plan *pl, int idx, hipStream_t st) {
+    if (idx >= 0) hipEventRecord(pl->events[idx].b, st);
+}
+
 void collect_events(zd_plan *pl) {
     for (auto &ep : pl->events) {
         float ms = 0;
@@ -717,6 +732,9 @@ void zd_plan_destroy(zd_plan *pl) {
 }
 
 int32_t zd_plan_narray(const zd_plan *pl) { return pl->narray; }
+int32_t zd_plan_store_mode(const zd_plan *pl) {
+    return pl->pack == zd::PACK_NONE ? ZD_STORE_REFERENCE : pl->pack == zd::PACK_ZAFIELD ? ZD_STORE_FIELDS : ZD_STORE_PACKED;
+}
 int32_t zd_plan_stream_factor(const zd_plan *pl) { return pl->R; }
 int32_t zd_plan_record_size(const zd_plan *pl) { return pl->ec.recsize; }
 int64_t zd_plan_exchange_bytes(const zd_plan *pl) { return pl->store_bytes_; }
@@ -743,6 +761,7 @@ int zd_plan_stage_z(zd_plan *pl, int residue, void *d_send, void *hip_stream) {
     pl->g.accum_var = (pl->pack != zd::PACK_NONE && pl->var_pending) ? 1 : 0;  // once per run: every pass sees every mode
     pl->var_pending = false;
     const int ky_first = pl->rank, G = pl->nranks;  // this rank's half-space rows: rank, rank + G, ... (cyclic)
+    const int zspan = span_begin(pl, ZD_K_ZSTAGE, st);
     if (!pl->overlap) {
         HIPCHECK(hipMemsetAsync(pl->d_tilectr, 0, sizeof(unsigned) * pl->n_tilectr, st));
         int slab = 0;
@@ -757,6 +776,7 @@ int zd_plan_stage_z(zd_plan *pl, int residue, void *d_send, void *hip_stream) {
             if (launch_zstage_fft(pl, ky_first + G * r0, r0, nky, pl->d_Y[0], d_send, st)) return 1;
             tick(pl, ZD_K_ZFFT, st, false);
         }
+        span_end(pl, zspan, st);
         return 0;
     }
     // Two worker streams.  s_fft (k_zfft, writes the store) starts after everything already queued on the caller's
@@ -812,6 +832,7 @@ int zd_plan_stage_z(zd_plan *pl, int residue, void *d_send, void *hip_stream) {
     // join: the caller's stream continues after the last k_zfft of this pass
     HIPCHECK(hipEventRecord(pl->ev_fork, pl->s_fft));
     HIPCHECK(hipStreamWaitEvent(st, pl->ev_fork, 0));
+    span_end(pl, zspan, st);
     return 0;
 }
 

@@ -62,6 +62,6 @@ struct zd_plan {
     // timing
     std::vector<EventPair> events;
     std::vector<hipEvent_t> pool;
-    double kernel_ms[ZD_K_COUNT] = {0, 0, 0, 0};
-    int64_t launches[ZD_K_COUNT] = {0, 0, 0, 0};
+    double kernel_ms[ZD_K_COUNT] = {0, 0, 0, 0, 0};
+    int64_t launches[ZD_K_COUNT] = {0, 0, 0, 0, 0};
 };
