@@ -51,6 +51,7 @@ typedef struct zd_params {
     int32_t store_mode;    /* ZD_STORE_*: what the block store between the z and y passes holds (0 = best available) */
     int32_t serial_z;      /* 1: generator and z FFT on ONE stream (per-kernel timing runs); 0: two overlapped streams */
     int32_t ngpu;          /* ZD_NumGPU: GPUs of this node that zd_generate / the CLI drive (0 or 1 = one) */
+    int32_t exchange_planes; /* store planes per exchange group between ranks (0 = ~4 GB ring slots) */
     /* --- local primordial non-Gaussianity (include/parameters.h:56-58); f_NL = 0 disables the path --- */
     double f_NL, n_s, Omega_M;
 } zd_params;
@@ -156,6 +157,27 @@ int zd_plan_stage_z(zd_plan *plan, int residue, void *d_send, void *hip_stream);
 int zd_plan_stage_y(zd_plan *plan, void *d_recv, void *hip_stream);
 int zd_plan_stage_x(zd_plan *plan, int residue, const void *d_recv, int64_t plane0, int64_t nplanes,
                     void *d_records, float *d_density, void *hip_stream);
+
+/* ---- N > 1 ranks: exchange + pipelined XY stages inside the library --------------------------------
+ * Replaces the per-block StoreBlock / LoadBlock traffic of src/zeldovich.cpp:583-587,634-637 between ZeldovichZ and
+ * ZeldovichXY.  The send store is [destination rank][plane]...: plane groups of every chunk are contiguous, group j+1
+ * travels (RCCL grouped ncclSend/ncclRecv over xGMI) while the y and x stages of group j run.  zd_generate with
+ * zd_params.ngpu > 1 (`ZD_NumGPU` in the parameter file) drives all of this with one host thread per GPU; the entry
+ * points below serve one-process-per-GPU drivers (bench.py under torch.distributed.run). */
+typedef struct zd_comm zd_comm;
+int zd_comm_unique_id(void *id128);  /* rank 0: 128-byte RCCL id, to be made known to all ranks by the launcher */
+int zd_comm_create(int rank, int nranks, const void *id128, zd_comm **out); /* ncclCommInitRank on the current device */
+void zd_comm_destroy(zd_comm *comm);
+/* bytes of the two-slot receive ring zd_plan_run_pass allocates (0 for one rank) and the planes per exchange group */
+int64_t zd_plan_ring_bytes(const zd_plan *plan, int32_t *group_planes);
+/* consumer of finished planes: `nplanes` delivered planes starting at local plane `first_local_plane` of the pass lie
+ * in d_records, produced by work still queued on hip_stream (order yourself after it, or synchronise) */
+typedef int (*zd_group_cb)(void *user, int64_t first_local_plane, int64_t nplanes, const void *d_records, void *hip_stream);
+/* One residue pass of this rank: Z stage into d_store (zd_plan_exchange_bytes), exchange and XY stages plane group by
+ * plane group through d_records (room for rec_planes planes, a multiple of zd_plan_plane_step).  comm == NULL for one
+ * rank.  cb may be NULL (benchmark sink). */
+int zd_plan_run_pass(zd_plan *plan, zd_comm *comm, int pass, void *d_store, void *d_records, int64_t rec_planes,
+                     zd_group_cb cb, void *user, void *hip_stream);
 
 /* Fetch + reset the device-side reductions (max_disp, density_variance) and kernel timers. Syncs. */
 int zd_plan_stats(zd_plan *plan, zd_stats *out);

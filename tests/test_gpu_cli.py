@@ -38,15 +38,19 @@ def test_usage_and_bad_file():
     assert r.returncode == 1
 
 
-@pytest.mark.parametrize("fmt,R,qd", [("RVdoubleZel", 1, 0), ("RVZel", 2, 1), ("ZelSimple", 2, 0)])
-def test_cli_writes_reference_files(tmp_path, oracle, fmt, R, qd):
-    n, cpd = 64, 5
+@pytest.mark.parametrize("fmt,R,qd,ngpu", [("RVdoubleZel", 1, 0, 1), ("RVZel", 2, 1, 1), ("ZelSimple", 2, 0, 1),
+                                          ("Zeldovich", 2, 0, 1), ("RVZel", 2, 0, 2), ("RVdoubleZel", 4, 0, 4)])
+def test_cli_writes_reference_files(tmp_path, oracle, fmt, R, qd, ngpu):
+    """ngpu > 1: `ZD_NumGPU` in the parameter file — one host thread per rank inside the library; on this one-GPU box the
+    ranks share the device (see test_native_multi_gpu_driver)"""
+    n, cpd = (64, 5) if ngpu == 1 else (128, 7)
     out = tmp_path / "ic"
     out.mkdir()
     (out / "ic_99").write_bytes(b"stale")       # SetupOutputDir removes ic_* and zeldovich.* (output.cpp:236-251)
     (out / "keep.txt").write_text("keep")
     par = tmp_path / "t.par"
-    par.write_text(PAR % dict(cpd=cpd, fmt=fmt, out=out, np=n ** 3, pk=WMAP, qd=qd, R=R))
+    par.write_text(PAR % dict(cpd=cpd, fmt=fmt, out=out, np=n ** 3, pk=WMAP, qd=qd, R=R)
+                   + ("ZD_NumGPU = %d\nZD_ExchangePlanes = 3\n" % ngpu if ngpu > 1 else ""))
     r = subprocess.run([EXE, str(par)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert "Mpart/sec" in r.stderr and "maximum component-wise displacements" in r.stderr

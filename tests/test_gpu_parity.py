@@ -100,6 +100,8 @@ def _compare(zd, oracle, ps, opk, n, fmt="RVdoubleZel", eig=None, tie_ok=False, 
     okw = dict(kw)
     okw.pop("stream_factor", None)
     okw.pop("store_mode", None)
+    okw.pop("ngpu", None)
+    okw.pop("exchange_planes", None)
     if "corner_modes" in okw:
         okw["CornerModes"] = okw.pop("corner_modes")
     op = oracle.make_params(n, numblock=2, icformat=fmt, **okw)
@@ -430,3 +432,45 @@ def test_fnl_with_plt(zd, oracle, ps, wmap_path):
     ref = oracle.run(oracle.make_params(64, numblock=2, icformat="RVdoubleZel", **kw), opk, eig=eig, eig_ppd=32)
     for f in ("d", "v"):
         assert _rel(got["records"][f], ref["records"][f]) < TOL
+
+
+@pytest.mark.parametrize("ngpu,n,kw", [
+    (2, 128, dict(stream_factor=2)),                                   # field store, two ranks, one exchange group
+    (2, 128, dict(stream_factor=2, exchange_planes=5)),                # 32 planes per rank in groups of 5 (last: 2)
+    (4, 256, dict(stream_factor=4, k_cutoff=2.0, fmt="RVZel", exchange_planes=3)),  # compacted rows, pruned tiles
+    (2, 128, dict(store_mode="reference", exchange_planes=7)),
+    (2, 64, dict(store_mode="reference")),                             # the reference's arrays with Hermitian twins
+    (4, 128, dict(stream_factor=2, store_mode="packed")),
+    (2, 128, dict(stream_factor=2, plt=True)),
+])
+def test_native_multi_gpu_driver(zd, oracle, ps, opk, ngpu, n, kw):
+    """ZD_NumGPU > 1 through zd_generate: one host thread per rank, exchange in plane groups + pipelined XY stages inside
+    the library (csrc/zd_multi.cpp).  This box has one GPU, so the ranks share it and pull their slices with device
+    copies (the `local` transport; RCCL needs distinct GPUs) — kernels, layouts, ring and plane-group pipeline are the real
+    ones.  Result == single-process oracle."""
+    kw = dict(kw)
+    fmt = kw.pop("fmt", "RVdoubleZel")
+    eig = None
+    if kw.pop("plt", False):
+        eig = oracle.synthetic_eigenmodes(32)
+        kw.update(qPLT=1, qPLTrescale=1, PLT_target_z=5.0, f_cluster=0.97)
+    got, _ = _compare(zd, oracle, ps, opk, n, fmt=fmt, eig=eig, ngpu=ngpu, **kw)
+    assert sorted(got["planes_seen"]) == list(range(n))
+
+
+def test_rccl_communicator_single_rank(zd, ps):
+    """the library's RCCL binding (lazy dlopen, ncclGetUniqueId, ncclCommInitRank) on the one GPU of this box; a pass
+    through zd_plan_run_pass with that communicator"""
+    import torch
+    comm = zd.Comm(0, 1, lambda raw: raw)
+    n = 64
+    plan = zd.Plan(zd.make_params(n, icformat="RVZel", stream_factor=2), ps)
+    store = torch.empty(plan.exchange_bytes, dtype=torch.uint8, device="cuda")
+    rec = torch.empty(plan.local_planes * n * n * 32, dtype=torch.uint8, device="cuda")
+    seen = []
+    plan.run_pass(0, store.data_ptr(), rec.data_ptr(), plan.local_planes, comm=comm,
+                  consume=lambda first, cnt, ptr, st: seen.append((first, cnt)))
+    torch.cuda.synchronize()
+    assert seen == [(0, plan.local_planes)]
+    plan.close()
+    comm.close()

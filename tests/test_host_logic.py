@@ -127,19 +127,22 @@ def test_eigenmode_loader(zd, oracle, tmp_path):
 def test_stream_factor_chooser(zd):
     L = zd.load_library()
     GB = 1 << 30
-    # ZA without ZD_qdensity: packed store, two z-residues per pass (3 arrays of N/R planes, 384-B row pad):
-    # 2048*2072*(2048/R)*48 B = 194 GiB at R = 2, which is preferred over R = 1
+    # ZA without ZD_qdensity: field store, two z-residues per pass (4 half-space potentials, zero columns not stored,
+    # 384-B row pad + the y->x ring): ~111 GB at R = 2, which is preferred over R = 1
     p = zd.make_params(2048)
     assert L.zd_choose_stream_factor(C.byref(p), 1, 300 * GB) == 2
     assert L.zd_choose_stream_factor(C.byref(p), 1, 200 * GB) == 2
     assert L.zd_choose_stream_factor(C.byref(p), 1, 100 * GB) == 4
-    assert L.zd_choose_stream_factor(C.byref(p), 8, 100 * GB) == 2   # 24 GiB/rank x2 buffers
+    assert L.zd_choose_stream_factor(C.byref(p), 8, 100 * GB) == 2   # one store per rank + the exchange ring
     pd = zd.make_params(2048, qdensity=1)  # density wanted: the reference's 2 arrays, 259 GiB at R = 1
     assert L.zd_choose_stream_factor(C.byref(pd), 1, 300 * GB) == 1
     assert L.zd_choose_stream_factor(C.byref(pd), 1, 200 * GB) == 2
     p4 = zd.make_params(4096)
     assert L.zd_choose_stream_factor(C.byref(p4), 1, 200 * GB) == 16
-    assert L.zd_choose_stream_factor(C.byref(p4), 8, 200 * GB) == 4
+    assert L.zd_choose_stream_factor(C.byref(p4), 1, 260 * GB) == 8    # 4 passes on one 288 GB GPU
+    assert L.zd_choose_stream_factor(C.byref(p4), 8, 200 * GB) == 2    # 8 GPUs: ONE pass (round 1: R = 4, send + receive stores)
+    pr = zd.make_params(4096, store_mode="packed")  # round-1 packing: 3 arrays with Hermitian twins, 8 passes
+    assert L.zd_choose_stream_factor(C.byref(pr), 1, 260 * GB) == 16
     assert L.zd_choose_stream_factor(C.byref(p4), 1, 1 * GB) == -1
 
 

@@ -1,6 +1,6 @@
-"""CPU, world_size 2 (gloo): the one-process-per-rank driver — rank ownership of ky rows / z planes,
-the block-store chunk layout and the all-to-all between the Z and XY stages — reproduces the
-single-process oracle result, for R = 1 and with z-residue streaming."""
+"""CPU, world_size 2 and 4 (gloo): the one-process-per-rank driver — CYCLIC rank ownership of the half-space rows, z-plane
+ownership, the block-store chunk layout and the exchange between the Z and XY stages, in one piece and pipelined in plane
+groups through the two-slot ring — reproduces the single-process oracle result, for R = 1 and with z-residue streaming."""
 import os
 import socket
 import sys
@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, R, outdir, max_msg=None):
+def _worker(rank, world, port, n, R, outdir, group_bytes=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -34,9 +34,10 @@ def _worker(rank, world, port, n, R, outdir, max_msg=None):
     pk = zdo.pk_from_file(WMAP, 720.0)
     cube = zdo.mode_cube(zdo.make_params(n, numblock=2), pk)
     eng = NumpyEngine(cube, n, R, rank, world)
-    pipe = SlabPipeline(eng, n, world=world, dist=dist, device="cpu", chunk_bytes=3 * n * n * eng.record_size)
-    if max_msg:
-        pipe.MAX_MSG_ELEMS = max_msg  # force the multi-round form of the exchange
+    kw = dict(group_bytes=group_bytes) if group_bytes else {}
+    pipe = SlabPipeline(eng, n, world=world, dist=dist, device="cpu", chunk_bytes=3 * n * n * eng.record_size, **kw)
+    if group_bytes:
+        assert pipe.group_planes < eng.Zq  # several plane groups per pass: the pipelined form of the exchange
     got = {}
 
     def consume(zs, ring):
@@ -51,11 +52,11 @@ def _worker(rank, world, port, n, R, outdir, max_msg=None):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("R,max_msg", [(1, None), (2, None), (2, 700)])
-def test_two_rank_pipeline_matches_oracle(tmp_path, oracle, R, max_msg):
-    n, world = 16, 2
+@pytest.mark.parametrize("R,world,group_bytes", [(1, 2, None), (2, 2, None), (1, 2, 3 * 16 * 16 * 32 * 2), (1, 4, 2 * 8192)])
+def test_multi_rank_pipeline_matches_oracle(tmp_path, oracle, R, world, group_bytes):
+    n = 16
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, n, R, str(tmp_path), max_msg), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, n, R, str(tmp_path), group_bytes), nprocs=world, join=True)
     pk = oracle.pk_from_file(WMAP, 720.0)
     ref = oracle.run(oracle.make_params(n, numblock=2), pk, want_planes=True)["planes"]  # [z][a][y][x]
     seen = {}

@@ -33,7 +33,7 @@ class ZdParams(C.Structure):
         ("qoneslab", C.c_int32), ("qonemode", C.c_int32), ("one_mode", C.c_int32 * 3),
         ("qPLT", C.c_int32), ("qPLTrescale", C.c_int32), ("icformat", C.c_int32),
         ("stream_factor", C.c_int32), ("profile", C.c_int32),
-        ("store_mode", C.c_int32), ("serial_z", C.c_int32), ("ngpu", C.c_int32),
+        ("store_mode", C.c_int32), ("serial_z", C.c_int32), ("ngpu", C.c_int32), ("exchange_planes", C.c_int32),
         ("f_NL", C.c_double), ("n_s", C.c_double), ("Omega_M", C.c_double),
     ]
 
@@ -68,12 +68,13 @@ class ZdParamStrings(C.Structure):
 
 
 SLAB_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p)
+GROUP_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p)
 
 # every symbol include/zeldovich_hip.h declares (checked by tests/test_capi_symbols.py)
 EXPORTED_SYMBOLS = [
     "zd_generate", "zd_choose_stream_factor", "zd_plan_create", "zd_plan_destroy", "zd_plan_narray", "zd_plan_store_mode",
     "zd_plan_stream_factor", "zd_plan_passes", "zd_plan_plane_step", "zd_plan_record_size", "zd_plan_exchange_bytes", "zd_plan_local_planes",
-    "zd_plan_plane_z", "zd_plan_stage_z", "zd_plan_stage_y", "zd_plan_stage_x", "zd_plan_stats",
+    "zd_plan_plane_z", "zd_plan_stage_z", "zd_plan_stage_y", "zd_plan_stage_x", "zd_plan_stats", "zd_comm_unique_id", "zd_comm_create", "zd_comm_destroy", "zd_plan_ring_bytes", "zd_plan_run_pass",
     "zd_params_from_file", "zd_pk_create_from_file", "zd_pk_create_powerlaw", "zd_pk_power",
     "zd_pk_sigmaR", "zd_pk_destroy", "zd_load_eigmodes", "zd_free", "zd_test_draws", "zd_test_modes",
     "zd_test_modes_table", "zd_test_fft",
@@ -117,6 +118,13 @@ def load_library():
     L.zd_plan_stage_y.argtypes = [vp, vp, vp]
     L.zd_plan_stage_x.argtypes = [vp, C.c_int, vp, i64, i64, vp, vp, vp]
     L.zd_plan_stats.argtypes = [vp, C.POINTER(ZdStats)]
+    L.zd_comm_unique_id.argtypes = [vp]
+    L.zd_comm_create.argtypes = [C.c_int, C.c_int, vp, C.POINTER(vp)]
+    L.zd_comm_destroy.argtypes = [vp]
+    L.zd_comm_destroy.restype = None
+    L.zd_plan_ring_bytes.argtypes = [vp, C.POINTER(i32)]
+    L.zd_plan_ring_bytes.restype = i64
+    L.zd_plan_run_pass.argtypes = [vp, vp, C.c_int, vp, vp, i64, GROUP_CB, vp, vp]
     L.zd_params_from_file.argtypes = [C.c_char_p, C.POINTER(ZdParams), C.POINTER(ZdParamStrings)]
     L.zd_pk_create_from_file.argtypes = [C.c_char_p, dbl, dbl, dbl, dbl, dbl, C.c_int, dbl, C.POINTER(vp), C.POINTER(ZdPk)]
     L.zd_pk_create_powerlaw.argtypes = [dbl, dbl, dbl, dbl, dbl, C.c_int, dbl, C.POINTER(vp), C.POINTER(ZdPk)]
@@ -140,7 +148,7 @@ def load_library():
 def make_params(ppd, numblock=2, boxsize=720.0, seed=12346, k_cutoff=1.0, qPLT=0, qPLTrescale=0,
                 PLT_target_z=0.0, z_initial=49.0, f_cluster=1.0, icformat="RVdoubleZel", qdensity=0,
                 qoneslab=-1, qonemode=0, one_mode=(0, 0, 0), corner_modes=0, cpd=None, stream_factor=0,
-                profile=0, f_NL=0.0, n_s=1.0, Omega_M=1.0, store_mode="auto", serial_z=0, ngpu=0):
+                profile=0, f_NL=0.0, n_s=1.0, Omega_M=1.0, store_mode="auto", serial_z=0, ngpu=0, exchange_planes=0):
     """Parameters with the derived quantities of Parameters::setup (src/parameters.cpp:172-174)."""
     p = ZdParams()
     p.ppd = ppd
@@ -167,6 +175,7 @@ def make_params(ppd, numblock=2, boxsize=720.0, seed=12346, k_cutoff=1.0, qPLT=0
     p.store_mode = STORE_MODES[store_mode] if isinstance(store_mode, str) else int(store_mode)
     p.serial_z = serial_z
     p.ngpu = ngpu
+    p.exchange_planes = exchange_planes
     p.f_NL, p.n_s, p.Omega_M = f_NL, n_s, Omega_M
     return p
 
@@ -317,6 +326,15 @@ class Plan:
         if self.L.zd_plan_stage_x(self.h, residue, d_recv, plane0, nplanes, d_records, d_density, stream):
             raise RuntimeError("zd_plan_stage_x failed")
 
+    def run_pass(self, residue, d_store, d_records, rec_planes, comm=None, consume=None, stream=0):
+        """Z stage -> exchange (plane groups, overlapped) -> y/x stages inside the library (zd_plan_run_pass);
+        consume(first_local_plane, nplanes, d_records_ptr, stream) is called per finished group of planes"""
+        cb = GROUP_CB()
+        if consume is not None:
+            cb = GROUP_CB(lambda user, first, n, recp, st: int(consume(int(first), int(n), recp, st) or 0))
+        if self.L.zd_plan_run_pass(self.h, comm.h if comm is not None else None, residue, d_store, d_records, rec_planes, cb, None, stream):
+            raise RuntimeError("zd_plan_run_pass failed")
+
     def stats(self):
         st = ZdStats()
         if self.L.zd_plan_stats(self.h, C.byref(st)):
@@ -333,6 +351,28 @@ class Plan:
             self.close()
         except Exception:
             pass
+
+
+class Comm:
+    """RCCL communicator of the library (one process per GPU): `exchange_id` makes rank 0's 128-byte id known to every
+    rank, e.g. lambda b: torch.distributed broadcast of a uint8 tensor"""
+
+    def __init__(self, rank, nranks, exchange_id):
+        self.L = load_library()
+        buf = (C.c_ubyte * 128)()
+        if rank == 0 and self.L.zd_comm_unique_id(buf):
+            raise RuntimeError("zd_comm_unique_id failed")
+        raw = exchange_id(bytes(buf))
+        idb = (C.c_ubyte * 128).from_buffer_copy(raw)
+        h = C.c_void_p()
+        if self.L.zd_comm_create(rank, nranks, idb, C.byref(h)):
+            raise RuntimeError("zd_comm_create failed")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.L.zd_comm_destroy(self.h)
+            self.h = None
 
 
 # ---- device test hooks ---------------------------------------------------------------------------

@@ -284,7 +284,7 @@ int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes
         if ((N / R) % nranks) break;
         if (N / R > 4096) continue;  // z-FFT kernels exist up to length 4096
         int64_t store = store_bytes(p, R, nranks);
-        if (nranks > 1) store *= 2;  // separate send and receive buffers
+        if (nranks > 1) store += std::min<int64_t>(store, (int64_t) 9 << 30);  // + the two-slot exchange ring (zd_multi.cpp), not a second store
         if (pack_mode(p, R) == zd::PACK_ZAFIELD)
             store += (int64_t) field_ring_planes(N, N / R / nranks) * 3 * N * (N + store_row_pad(N)) * 16;
         if (store <= budget_bytes) return R;
@@ -584,7 +584,8 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
                 lBk = a; lBz = b; S.rows_outer = o;
             }
         }
-        const int max_lBk = S.lHq + (nranks == 1 ? 1 : 0);  // one rank: self + twin slots in ONE block
+        const int max_lBk = S.lHq + 1;  // self + twin slots of a chunk in ONE block: chunks are plane-major (zd_multi.cpp
+                                        // exchanges them in plane groups)
         while (lBk > max_lBk) lBk--;
         while ((1 << lBz) > pl->Zq) lBz--;
         S.lBk = lBk;
@@ -836,34 +837,57 @@ int zd_plan_stage_z(zd_plan *pl, int residue, void *d_send, void *hip_stream) {
     return 0;
 }
 
-int zd_plan_stage_y(zd_plan *pl, void *d_recv, void *hip_stream) {
+// The XY stages address the store through its layout; after an exchange in plane groups (zd_multi.cpp) the data sits in
+// a ring slot whose chunks are `chunk_planes` planes long instead of Zq.  Chunks are plane-major, so only the chunk stride
+// changes.
+static zd::StoreLayout layout_for_chunks(const zd_plan *pl, int chunk_planes) {
+    zd::StoreLayout S = pl->S;
+    if (chunk_planes != pl->Zq) {
+        S.kb_rows    = S.zb_rows * (chunk_planes >> S.lBz);
+        S.chunk_rows = S.kb_rows * ((2 * pl->Hq) >> S.lBk);
+    }
+    return S;
+}
+static zd::FieldLayout fields_for_chunks(const zd_plan *pl, int chunk_planes) {
+    zd::FieldLayout F = pl->F;
+    F.chunk_elems     = (long long) chunk_planes * 4 * F.field_elems;
+    return F;
+}
+
+// y stage on a store (or ring slot) whose chunks hold `chunk_planes` planes, for its planes [0, nplanes)
+int zd_plan_stage_y_group(zd_plan *pl, void *d_recv, int chunk_planes, int nplanes, void *hip_stream) {
     hipStream_t st = (hipStream_t) hip_stream;
     if (pl->pack == zd::PACK_ZAFIELD) return 0;  // field store: the y transform runs plane group by plane group in stage_x
     tick(pl, ZD_K_YFFT, st, true);
-    if (zd::launch_yfft(pl->S, pl->Zq, pl->d_twN, d_recv, st)) return 1;
+    if (zd::launch_yfft(layout_for_chunks(pl, chunk_planes), nplanes, pl->d_twN, d_recv, st)) return 1;
     tick(pl, ZD_K_YFFT, st, false);
     return 0;
 }
+int zd_plan_stage_y(zd_plan *pl, void *d_recv, void *hip_stream) { return zd_plan_stage_y_group(pl, d_recv, pl->Zq, pl->Zq, hip_stream); }
 
-int zd_plan_stage_x(zd_plan *pl, int residue, const void *d_recv, int64_t plane0, int64_t nplanes, void *d_records,
-                    float *d_density, void *hip_stream) {
+// x stage (+ the y stage of the field store) for delivered planes [plane0, plane0 + nplanes) of a store / ring slot with
+// `chunk_planes` planes per chunk; `gplane0` = the local plane index of the first one inside the pass (it fixes z)
+int zd_plan_stage_x_group(zd_plan *pl, int residue, const void *d_recv, int chunk_planes, int64_t plane0, int64_t gplane0,
+                          int64_t nplanes, void *d_records, float *d_density, void *hip_stream) {
     hipStream_t st = (hipStream_t) hip_stream;
     const int ps = pl->pstep;
-    if (plane0 < 0 || nplanes < 1 || plane0 + nplanes > (int64_t) pl->Zq * ps || plane0 % ps || nplanes % ps) {
+    if (plane0 < 0 || nplanes < 1 || plane0 + nplanes > (int64_t) chunk_planes * ps || plane0 % ps || nplanes % ps || gplane0 % ps
+        || gplane0 + nplanes > (int64_t) pl->Zq * ps) {
         fprintf(stderr, "zeldovich_hip: stage_x plane range [%lld, +%lld) invalid (multiples of %d inside [0, %lld))\n",
-                (long long) plane0, (long long) nplanes, ps, (long long) pl->Zq * ps);
+                (long long) plane0, (long long) nplanes, ps, (long long) chunk_planes * ps);
         return 1;
     }
     if (d_density && pl->pack != zd::PACK_NONE) return 1;  // packed stores carry no density field
     if (pl->pack == zd::PACK_ZAFIELD) {
         // y stage (potentials -> the three displacement arrays of a group of store planes, into the ring) + x stage
+        const zd::FieldLayout F = fields_for_chunks(pl, chunk_planes);
         const int p0 = (int) (plane0 / ps), np = (int) (nplanes / ps);
         for (int g0 = 0; g0 < np; g0 += pl->ring_planes) {
             const int ng = std::min(pl->ring_planes, np - g0);
             tick(pl, ZD_K_YFFT, st, true);
-            if (zd::launch_yfft_fields(pl->F, pl->S, pl->d_twN, d_recv, p0 + g0, ng, pl->SR.pitch, pl->d_ring, st)) return 1;
+            if (zd::launch_yfft_fields(F, pl->S, pl->d_twN, d_recv, p0 + g0, ng, pl->SR.pitch, pl->d_ring, st)) return 1;
             tick(pl, ZD_K_YFFT, st, false);
-            const int z_first = (int) zd_plan_plane_z(pl, residue, (int64_t) (p0 + g0) * ps);
+            const int z_first = (int) zd_plan_plane_z(pl, residue, gplane0 + (int64_t) g0 * ps);
             tick(pl, ZD_K_XFFT, st, true);
             if (zd::launch_xfft(pl->SR, pl->ec, pl->d_twN, pl->d_ring, 0, ng, z_first, pl->R,
                                 d_records ? (char *) d_records + (size_t) g0 * ps * pl->N * pl->N * pl->ec.recsize : nullptr,
@@ -873,13 +897,17 @@ int zd_plan_stage_x(zd_plan *pl, int residue, const void *d_recv, int64_t plane0
         }
         return 0;
     }
-    const int z_first = (int) zd_plan_plane_z(pl, residue, plane0);
+    const int z_first = (int) zd_plan_plane_z(pl, residue, gplane0);
     tick(pl, ZD_K_XFFT, st, true);
-    if (zd::launch_xfft(pl->S, pl->ec, pl->d_twN, d_recv, (int) (plane0 / ps), (int) (nplanes / ps), z_first, pl->R, d_records,
-                        d_density, pl->d_red, st))
+    if (zd::launch_xfft(layout_for_chunks(pl, chunk_planes), pl->ec, pl->d_twN, d_recv, (int) (plane0 / ps), (int) (nplanes / ps), z_first,
+                        pl->R, d_records, d_density, pl->d_red, st))
         return 1;
     tick(pl, ZD_K_XFFT, st, false);
     return 0;
+}
+int zd_plan_stage_x(zd_plan *pl, int residue, const void *d_recv, int64_t plane0, int64_t nplanes, void *d_records,
+                    float *d_density, void *hip_stream) {
+    return zd_plan_stage_x_group(pl, residue, d_recv, pl->Zq, plane0, plane0, nplanes, d_records, d_density, hip_stream);
 }
 
 int zd_plan_stats(zd_plan *pl, zd_stats *out) {
@@ -921,6 +949,13 @@ int zd_plan_stats(zd_plan *pl, zd_stats *out) {
 // ------------------------------------------------------------------------------------------------
 int zd_generate(const zd_params *p_in, const zd_pk *pk, const double *eig, int64_t eig_ppd, zd_slab_cb cb,
                 void *user, zd_stats *out) {
+    if (p_in->ngpu > 1) {  // ZD_NumGPU: one host thread per GPU, exchange inside the library (zd_multi.cpp)
+        int ndev = 0;
+        HIPCHECK(hipGetDeviceCount(&ndev));
+        // RCCL between distinct GPUs; when the ranks have to share devices (fewer GPUs than ranks: test boxes) they
+        // pull their slices with device copies instead
+        return zd_generate_multi(p_in, pk, eig, eig_ppd, cb, user, out, ndev >= p_in->ngpu ? 0 : 1);
+    }
     zd_params p = *p_in;
     const int64_t N = p.ppd;
     size_t free_b = 0, total_b = 0;

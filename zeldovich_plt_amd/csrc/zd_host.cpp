@@ -466,6 +466,7 @@ int zd_params_from_file(const char *path, zd_params *p, zd_param_strings *s) {
     // optional MI355X knobs (not in the reference; reference .par files run unchanged)
     I("ZD_StreamFactor", p->stream_factor);
     I("ZD_NumGPU", p->ngpu);  // GPUs of this node to drive (default: 1)
+    I("ZD_ExchangePlanes", p->exchange_planes);
     (void) have_cpd;
     p->cpd = cpd;
 

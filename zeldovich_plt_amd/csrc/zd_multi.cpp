@@ -1,2 +1,499 @@
-// zd_multi.cpp — multi-GPU driver inside the library (filled in below).
+// zd_multi.cpp — the N > 1 data path inside the library: one rank per GPU, the block exchange between the Z stage and
+// the XY stage (the reference's StoreBlock / LoadBlock "transpose", src/block_array.cpp:387-414,466-504, called per
+// block from src/zeldovich.cpp:583-587,634-637) pipelined against the XY compute, and a thread-per-GPU driver behind
+// zd_generate / `zeldovich <param_file>` (ZD_NumGPU).
+//
+// Design.  Rank g generates and z-transforms its half-space rows into a SEND store laid out [destination rank d]
+// [plane][array|field][row slot][x] (zd_device.h).  Inside a chunk the planes are the outer index, so the planes
+// [j0, j1) of chunk d are ONE contiguous range: the exchange is cut into plane groups.  Group j of every peer's chunk
+// <me> is received into one of two ring slots ([source rank s][planes of the group]...) on a communication stream while
+// the y and x stages of group j-1 run on the compute stream.  No second full-size store exists (round 1 doubled it),
+// so on 8 GPUs the stream factor is set by ONE store per rank.  Transports:
+//   * RCCL: grouped ncclSend / ncclRecv per plane group (all 7 xGMI links of a GPU busy at once); the communicator
+//     comes from ncclCommInitRank (one process per GPU: bench.py under torch.distributed.run) or ncclCommInitAll
+//     (one thread per GPU: zd_generate).  librccl is opened lazily so that the library loads on hosts without it.
+//   * local: all ranks are threads of this process and PULL their slices with hipMemcpyAsync (peer copies over xGMI when
+//     the ranks sit on different GPUs).  It is also what lets the multi-rank pipeline run — with the real kernels — on
+//     a one-GPU test box (several ranks share the device).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "zd_launch.h"
 #include "zd_plan.h"
+
+using zdfft::cplx;
+
+#define MHIP(call)                                                                                  \
+    do {                                                                                            \
+        hipError_t e__ = (call);                                                                    \
+        if (e__ != hipSuccess) {                                                                    \
+            fprintf(stderr, "zeldovich_hip: %s failed at %s:%d: %s\n", #call, __FILE__, __LINE__,   \
+                    hipGetErrorString(e__));                                                        \
+            return 1;                                                                               \
+        }                                                                                           \
+    } while (0)
+
+namespace {
+
+// ---- lazily bound RCCL entry points --------------------------------------------------------------
+struct RcclApi {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *)                                            = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int)                     = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *)                            = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t)                                                = nullptr;
+    ncclResult_t (*GroupStart)()                                                           = nullptr;
+    ncclResult_t (*GroupEnd)()                                                             = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t)     = nullptr;
+    const char *(*GetErrorString)(ncclResult_t)                                            = nullptr;
+};
+RcclApi *rccl() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // a process that already carries an RCCL (PyTorch ships one) must keep using that copy
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            api.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (api.h) break;
+        }
+        if (!api.h) return;
+#define BIND(f) api.f = reinterpret_cast<decltype(api.f)>(dlsym(api.h, "nccl" #f))
+        BIND(GetUniqueId);
+        BIND(CommInitRank);
+        BIND(CommInitAll);
+        BIND(CommDestroy);
+        BIND(GroupStart);
+        BIND(GroupEnd);
+        BIND(Send);
+        BIND(Recv);
+        BIND(GetErrorString);
+#undef BIND
+        if (!api.GetUniqueId || !api.CommInitRank || !api.CommInitAll || !api.GroupStart || !api.GroupEnd || !api.Send || !api.Recv)
+            api.h = nullptr;
+    });
+    return api.h ? &api : nullptr;
+}
+#define MNCCL(call)                                                                                          \
+    do {                                                                                                     \
+        ncclResult_t r__ = (call);                                                                           \
+        if (r__ != ncclSuccess) {                                                                            \
+            fprintf(stderr, "zeldovich_hip: %s failed at %s:%d: %s\n", #call, __FILE__, __LINE__,            \
+                    rccl()->GetErrorString ? rccl()->GetErrorString(r__) : "?");                             \
+            return 1;                                                                                        \
+        }                                                                                                    \
+    } while (0)
+
+// in-process rendezvous of the local transport
+struct LocalGroup {
+    int n = 0;
+    std::vector<const char *> send_base;  // each rank's send store of the current pass
+    std::atomic<int> failed{0};
+    // barrier that a failed rank can break (a plain pthread barrier would hang the survivors)
+    std::mutex mu;
+    std::condition_variable cv;
+    int waiting = 0;
+    long long generation = 0;
+    int wait() {  // 0: everybody arrived; 1: some rank failed
+        std::unique_lock<std::mutex> lk(mu);
+        const long long gen = generation;
+        if (++waiting == n) {
+            waiting = 0;
+            generation++;
+            cv.notify_all();
+            return failed.load() ? 1 : 0;
+        }
+        while (generation == gen && !failed.load()) cv.wait_for(lk, std::chrono::milliseconds(50));
+        return failed.load() ? 1 : 0;
+    }
+    void fail() {
+        failed.store(1);
+        std::lock_guard<std::mutex> lk(mu);
+        cv.notify_all();
+    }
+};
+
+}  // namespace
+
+struct zd_comm {
+    int rank = 0, nranks = 1;
+    int kind = 0;  // 0 RCCL, 1 local
+    ncclComm_t nccl = nullptr;
+    LocalGroup *grp = nullptr;
+    hipStream_t s_comm = nullptr;
+    hipEvent_t ev_z = nullptr, ev_x[2] = {nullptr, nullptr}, ev_r[2] = {nullptr, nullptr};
+    char *ring = nullptr;  // two slots of [source rank][planes of a group]...
+    int64_t slot_bytes = 0;
+    int group_planes = 0;
+};
+
+namespace {
+
+int comm_prepare(zd_comm *c) {
+    MHIP(hipStreamCreateWithFlags(&c->s_comm, hipStreamNonBlocking));
+    MHIP(hipEventCreateWithFlags(&c->ev_z, hipEventDisableTiming));
+    for (int i = 0; i < 2; i++) {
+        MHIP(hipEventCreateWithFlags(&c->ev_x[i], hipEventDisableTiming));
+        MHIP(hipEventCreateWithFlags(&c->ev_r[i], hipEventDisableTiming));
+    }
+    return 0;
+}
+
+// bytes of ONE store plane inside one chunk (chunks are plane-major)
+int64_t chunk_plane_bytes(const zd_plan *pl) { return zd_plan_exchange_bytes(pl) / pl->nranks / pl->Zq; }
+
+}  // namespace
+
+extern "C" {
+
+int zd_comm_unique_id(void *id128) {
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    RcclApi *R = rccl();
+    if (!R) {
+        fprintf(stderr, "zeldovich_hip: librccl.so not found: multi-process runs need RCCL\n");
+        return 1;
+    }
+    ncclUniqueId id;
+    MNCCL(R->GetUniqueId(&id));
+    memcpy(id128, &id, sizeof(id));
+    return 0;
+}
+
+// one process per GPU: the caller has made `id128` (from rank 0's zd_comm_unique_id) known to every rank and has
+// selected this rank's device (hipSetDevice / torch.cuda.set_device)
+int zd_comm_create(int rank, int nranks, const void *id128, zd_comm **out) {
+    RcclApi *R = rccl();
+    if (!R) {
+        fprintf(stderr, "zeldovich_hip: librccl.so not found: multi-process runs need RCCL\n");
+        return 1;
+    }
+    zd_comm *c = new zd_comm;
+    c->rank    = rank;
+    c->nranks  = nranks;
+    c->kind    = 0;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclResult_t r = R->CommInitRank(&c->nccl, nranks, id, rank);
+    if (r != ncclSuccess || comm_prepare(c)) {
+        fprintf(stderr, "zeldovich_hip: ncclCommInitRank failed (rank %d of %d)\n", rank, nranks);
+        delete c;
+        return 1;
+    }
+    *out = c;
+    return 0;
+}
+
+void zd_comm_destroy(zd_comm *c) {
+    if (!c) return;
+    if (c->nccl && rccl() && rccl()->CommDestroy) rccl()->CommDestroy(c->nccl);
+    if (c->s_comm) hipStreamDestroy(c->s_comm);
+    if (c->ev_z) hipEventDestroy(c->ev_z);
+    for (int i = 0; i < 2; i++) {
+        if (c->ev_x[i]) hipEventDestroy(c->ev_x[i]);
+        if (c->ev_r[i]) hipEventDestroy(c->ev_r[i]);
+    }
+    hipFree(c->ring);
+    delete c;
+}
+
+// planes per exchange group and bytes of the two-slot ring that zd_plan_run_pass allocates on first use
+int64_t zd_plan_ring_bytes(const zd_plan *pl, int32_t *group_planes) {
+    if (pl->nranks <= 1) {
+        if (group_planes) *group_planes = pl->Zq;
+        return 0;
+    }
+    const int64_t per_plane = chunk_plane_bytes(pl) * pl->nranks;  // one store plane from every source rank
+    int gp = (int) std::max<int64_t>(1, std::min<int64_t>(pl->Zq, ((int64_t) 4 << 30) / per_plane));  // ~4 GB per slot
+    // field store: whole y->x ring loads per group
+    if (pl->pack == zd::PACK_ZAFIELD && gp > pl->ring_planes) gp = gp / pl->ring_planes * pl->ring_planes;
+    if (pl->p.exchange_planes > 0) gp = std::min<int>(pl->Zq, pl->p.exchange_planes);
+    if (group_planes) *group_planes = gp;
+    return 2 * per_plane * gp;
+}
+
+// One residue pass of one rank: Z stage into d_store, exchange + XY stages plane group by plane group.
+//   comm       NULL (or nranks == 1): no exchange, the XY stages read d_store directly
+//   d_records  room for `rec_planes` delivered planes (a multiple of zd_plan_plane_step); every time it has been filled
+//              (or the pass ends) `cb(user, first_local_plane, nplanes, d_records, stream)` is called with the work
+//              still queued on `stream` — the consumer orders itself after it (or syncs); cb may be NULL (benchmark sink)
+typedef int (*zd_group_cb)(void *user, int64_t first_local_plane, int64_t nplanes, const void *d_records, void *hip_stream);
+
+int zd_plan_run_pass(zd_plan *pl, zd_comm *c, int pass, void *d_store, void *d_records, int64_t rec_planes, zd_group_cb cb,
+                     void *user, void *hip_stream) {
+    hipStream_t st = (hipStream_t) hip_stream;
+    const int ps = pl->pstep;
+    const int64_t Pp = zd_plan_local_planes(pl);
+    if (rec_planes < ps || rec_planes % ps) {
+        fprintf(stderr, "zeldovich_hip: record buffer of %lld planes (multiples of %d needed)\n", (long long) rec_planes, ps);
+        return 1;
+    }
+    if (zd_plan_stage_z(pl, pass, d_store, st)) return 1;
+    if (!c || pl->nranks <= 1) {
+        if (zd_plan_stage_y(pl, d_store, st)) return 1;
+        for (int64_t q0 = 0; q0 < Pp; q0 += rec_planes) {
+            const int64_t n = std::min<int64_t>(rec_planes, Pp - q0);
+            if (zd_plan_stage_x_group(pl, pass, d_store, pl->Zq, q0, q0, n, d_records, nullptr, st)) return 1;
+            if (cb && cb(user, q0, n, d_records, st)) return 1;
+        }
+        return 0;
+    }
+    if (c->nranks != pl->nranks || c->rank != pl->rank) {
+        fprintf(stderr, "zeldovich_hip: communicator (rank %d of %d) does not match the plan (rank %d of %d)\n", c->rank,
+                c->nranks, pl->rank, pl->nranks);
+        return 1;
+    }
+    // ---- ring ----
+    int gp = 0;
+    const int64_t ring_b = zd_plan_ring_bytes(pl, &gp);
+    if (!c->ring) {
+        MHIP(hipMalloc((void **) &c->ring, (size_t) ring_b));
+        c->slot_bytes   = ring_b / 2;
+        c->group_planes = gp;
+    }
+    const int G = pl->nranks, me = pl->rank;
+    const int64_t cpb = chunk_plane_bytes(pl), chunk_b = cpb * pl->Zq;
+    const int ngroups = (pl->Zq + gp - 1) / gp;
+    // the Z stage must be complete before anything leaves the send store
+    MHIP(hipEventRecord(c->ev_z, st));
+    MHIP(hipStreamWaitEvent(c->s_comm, c->ev_z, 0));
+    if (c->kind == 1) {  // local: every rank's send store must be complete before anybody pulls from it
+        MHIP(hipStreamSynchronize(st));
+        c->grp->send_base[me] = (const char *) d_store;
+        if (c->grp->wait()) return 1;
+    }
+    auto exchange = [&](int j) -> int {
+        const int slot = j & 1;
+        const int64_t p0 = (int64_t) j * gp, np = std::min<int64_t>(gp, pl->Zq - p0);
+        const size_t nb = (size_t) (cpb * np);
+        char *dst = c->ring + (size_t) slot * c->slot_bytes;
+        if (j >= 2) MHIP(hipStreamWaitEvent(c->s_comm, c->ev_x[slot], 0));  // the XY stages of group j-2 have left the slot
+        if (c->kind == 1) {
+            for (int s = 0; s < G; s++)  // pull: chunk <me> of rank s's send store, planes of the group
+                MHIP(hipMemcpyAsync(dst + (size_t) s * cpb * gp, c->grp->send_base[s] + (size_t) me * chunk_b + (size_t) p0 * cpb, nb,
+                                    hipMemcpyDeviceToDevice, c->s_comm));
+        } else {
+            RcclApi *R = rccl();
+            MNCCL(R->GroupStart());
+            for (int p = 0; p < G; p++) {
+                const char *sb = (const char *) d_store + (size_t) p * chunk_b + (size_t) p0 * cpb;
+                char *rb       = dst + (size_t) p * cpb * gp;
+                if (p == me) continue;
+                MNCCL(R->Send(sb, nb, ncclChar, p, c->nccl, c->s_comm));
+                MNCCL(R->Recv(rb, nb, ncclChar, p, c->nccl, c->s_comm));
+            }
+            MNCCL(R->GroupEnd());
+            MHIP(hipMemcpyAsync(dst + (size_t) me * cpb * gp, (const char *) d_store + (size_t) me * chunk_b + (size_t) p0 * cpb, nb,
+                                hipMemcpyDeviceToDevice, c->s_comm));
+        }
+        MHIP(hipEventRecord(c->ev_r[slot], c->s_comm));
+        return 0;
+    };
+    if (exchange(0)) return 1;
+    for (int j = 0; j < ngroups; j++) {
+        if (j + 1 < ngroups && exchange(j + 1)) return 1;  // next group travels while this one is transformed
+        const int slot = j & 1;
+        const int64_t p0 = (int64_t) j * gp, np = std::min<int64_t>(gp, pl->Zq - p0);
+        MHIP(hipStreamWaitEvent(st, c->ev_r[slot], 0));
+        const void *src = c->ring + (size_t) slot * c->slot_bytes;
+        if (zd_plan_stage_y_group(pl, const_cast<void *>(src), gp, (int) np, st)) return 1;
+        // XY on the slot: chunks are gp planes long there
+        for (int64_t q0 = 0; q0 < np * ps; q0 += rec_planes) {
+            const int64_t n = std::min<int64_t>(rec_planes, np * ps - q0);
+            if (zd_plan_stage_x_group(pl, pass, src, gp, q0, p0 * ps + q0, n, d_records, nullptr, st)) return 1;
+            if (cb && cb(user, p0 * ps + q0, n, d_records, st)) return 1;
+        }
+        MHIP(hipEventRecord(c->ev_x[slot], st));
+    }
+    if (c->kind == 1) {  // nobody may start the next Z stage (overwriting its send store) while a peer still pulls
+        MHIP(hipStreamSynchronize(c->s_comm));
+        MHIP(hipStreamSynchronize(st));
+        if (c->grp->wait()) return 1;
+    } else {
+        // the sends of this pass must have left d_store before the caller's next Z stage overwrites it
+        MHIP(hipEventRecord(c->ev_z, c->s_comm));
+        MHIP(hipStreamWaitEvent(st, c->ev_z, 0));
+    }
+    return 0;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// thread-per-GPU driver behind zd_generate (ngpu > 1)
+
+namespace {
+
+struct RankCtx {
+    int rank = 0, device = 0;
+    zd_comm *comm = nullptr;
+    int rc = 0;
+    zd_stats stats;
+};
+
+struct Delivery {  // serialises the per-plane callback over the rank threads (WriteParticlesSlab is not re-entrant,
+                   // src/output.cpp:28-39)
+    std::mutex mu;
+    zd_slab_cb cb = nullptr;
+    void *user    = nullptr;
+};
+
+struct GroupSink {
+    zd_plan *pl;
+    int pass;
+    Delivery *dl;
+    char *h_rec;
+    size_t plane_rec_b;
+    int fail = 0;
+};
+
+int sink_cb(void *user, int64_t first_local_plane, int64_t nplanes, const void *d_records, void *hip_stream) {
+    GroupSink *s = (GroupSink *) user;
+    if (!s->dl->cb) return 0;
+    hipStream_t st = (hipStream_t) hip_stream;
+    if (hipMemcpyAsync(s->h_rec, d_records, s->plane_rec_b * (size_t) nplanes, hipMemcpyDeviceToHost, st) != hipSuccess) return 1;
+    if (hipStreamSynchronize(st) != hipSuccess) return 1;
+    std::lock_guard<std::mutex> lock(s->dl->mu);
+    for (int64_t i = 0; i < nplanes; i++) {
+        const int64_t z = zd_plan_plane_z(s->pl, s->pass, first_local_plane + i);
+        if (s->dl->cb(s->dl->user, z, (int64_t) s->pl->N * s->pl->N, s->h_rec + (size_t) i * s->plane_rec_b, nullptr)) return 1;
+    }
+    return 0;
+}
+
+}  // namespace
+
+// ZeldovichZ + ZeldovichXY on `ngpu` GPUs of this node, one host thread per GPU (called by zd_generate).
+// transport: 0 = RCCL (ncclCommInitAll), 1 = local pulls; ranks are placed on devices rank % device_count, so with the
+// local transport a one-GPU box can run several ranks (tests).
+int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig, int64_t eig_ppd, zd_slab_cb cb, void *user,
+                      zd_stats *out, int transport) {
+    const int G = p_in->ngpu;
+    int ndev = 0;
+    MHIP(hipGetDeviceCount(&ndev));
+    if (ndev < 1) {
+        fprintf(stderr, "zeldovich_hip: no GPU\n");
+        return 1;
+    }
+    if (p_in->qdensity != 0 || p_in->f_NL != 0. || p_in->qoneslab >= 0) {
+        fprintf(stderr, "zeldovich_hip: ZD_NumGPU > 1 supports the displacement path (no ZD_qdensity / ZD_f_NL / ZD_qoneslab)\n");
+        return 1;
+    }
+    if (transport == 0 && ndev < G) {
+        fprintf(stderr, "zeldovich_hip: ZD_NumGPU = %d but only %d GPU(s) are visible\n", G, ndev);
+        return 1;
+    }
+    zd_params p = *p_in;
+    if (p.stream_factor <= 0) {
+        size_t free_b = 0, total_b = 0;
+        MHIP(hipMemGetInfo(&free_b, &total_b));
+        const int ranks_per_dev = (G + ndev - 1) / ndev;
+        const int R = zd_choose_stream_factor(&p, G, ((int64_t) free_b - ((int64_t) 16 << 30)) / ranks_per_dev);
+        if (R < 0) {
+            fprintf(stderr, "zeldovich_hip: PPD %lld does not fit %d GPU(s)\n", (long long) p.ppd, G);
+            return 1;
+        }
+        p.stream_factor = R;
+    }
+    std::vector<RankCtx> ctx(G);
+    LocalGroup grp;
+    std::vector<ncclComm_t> nccls(G, nullptr);
+    if (transport == 1) {
+        grp.n = G;
+        grp.send_base.assign(G, nullptr);
+    } else {
+        RcclApi *R = rccl();
+        if (!R) {
+            fprintf(stderr, "zeldovich_hip: librccl.so not found\n");
+            return 1;
+        }
+        std::vector<int> devs(G);
+        for (int g = 0; g < G; g++) devs[g] = g;
+        MNCCL(R->CommInitAll(nccls.data(), G, devs.data()));
+    }
+    Delivery dl;
+    dl.cb   = cb;
+    dl.user = user;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> threads;
+    for (int g = 0; g < G; g++) {
+        ctx[g].rank   = g;
+        ctx[g].device = g % ndev;
+        threads.emplace_back([&, g]() {
+            RankCtx &me = ctx[g];
+            me.rc       = 1;
+            zd_plan *pl = nullptr;
+            void *d_store = nullptr, *d_rec = nullptr;
+            char *h_rec = nullptr;
+            zd_comm *c  = new zd_comm;
+            hipStream_t st = nullptr;
+            do {
+                if (hipSetDevice(me.device) != hipSuccess) break;
+                if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
+                if (zd_plan_create(&p, pk, eig, eig_ppd, g, G, &pl)) break;
+                c->rank   = g;
+                c->nranks = G;
+                c->kind   = transport;
+                c->nccl   = nccls[g];
+                c->grp    = &grp;
+                if (comm_prepare(c)) break;
+                const int ps = pl->pstep;
+                const size_t plane_rec_b = (size_t) pl->N * pl->N * pl->ec.recsize;
+                const int64_t ring_b = cb ? ((int64_t) 1 << 30) : ((int64_t) 4 << 30);
+                int64_t rec_planes = std::max<int64_t>(ps, std::min<int64_t>(zd_plan_local_planes(pl), ring_b / (int64_t) plane_rec_b) / ps * ps);
+                if (hipMalloc(&d_store, (size_t) zd_plan_exchange_bytes(pl)) != hipSuccess) {
+                    fprintf(stderr, "zeldovich_hip: rank %d cannot allocate the %.2f GB block store\n", g, zd_plan_exchange_bytes(pl) / 1e9);
+                    break;
+                }
+                if (hipMalloc(&d_rec, plane_rec_b * (size_t) rec_planes) != hipSuccess) break;
+                if (cb && hipHostMalloc((void **) &h_rec, plane_rec_b * (size_t) rec_planes) != hipSuccess) break;
+                bool fail = false;
+                for (int pass = 0; pass < pl->npass && !fail; pass++) {
+                    GroupSink sink{pl, pass, &dl, h_rec, plane_rec_b};
+                    if (zd_plan_run_pass(pl, c, pass, d_store, d_rec, rec_planes, sink_cb, &sink, st)) fail = true;
+                }
+                if (fail) break;
+                if (zd_plan_stats(pl, &me.stats)) break;
+                me.rc = 0;
+            } while (0);
+            if (me.rc) grp.fail();
+            if (st) hipStreamDestroy(st);
+            hipFree(d_store);
+            hipFree(d_rec);
+            if (h_rec) hipHostFree(h_rec);
+            c->nccl = nullptr;  // destroyed below, after every thread has left RCCL
+            zd_comm_destroy(c);
+            if (pl) zd_plan_destroy(pl);
+        });
+    }
+    for (auto &t : threads) t.join();
+    if (transport != 1)
+        for (int g = 0; g < G; g++)
+            if (nccls[g] && rccl()->CommDestroy) rccl()->CommDestroy(nccls[g]);
+    int rc = 0;
+    for (int g = 0; g < G; g++) rc |= ctx[g].rc;
+    if (rc) return 1;
+    // reductions over the ranks (output.cpp:28-30,190-197): signed value of the largest |displacement|, sum of dens^2
+    memset(out, 0, sizeof(*out));
+    *out = ctx[0].stats;
+    for (int g = 1; g < G; g++) {
+        out->density_variance += ctx[g].stats.density_variance;
+        for (int j = 0; j < 3; j++)
+            if (std::abs(ctx[g].stats.max_disp[j]) > std::abs(out->max_disp[j])) out->max_disp[j] = ctx[g].stats.max_disp[j];
+        for (int k = 0; k < ZD_K_COUNT; k++) {
+            out->kernel_ms[k] = std::max(out->kernel_ms[k], ctx[g].stats.kernel_ms[k]);
+            out->kernel_launches[k] += ctx[g].stats.kernel_launches[k];
+        }
+    }
+    out->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+}

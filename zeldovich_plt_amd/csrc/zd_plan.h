@@ -65,3 +65,12 @@ struct zd_plan {
     double kernel_ms[ZD_K_COUNT] = {0, 0, 0, 0, 0};
     int64_t launches[ZD_K_COUNT] = {0, 0, 0, 0, 0};
 };
+
+// internal entry points shared by zd_capi.cpp and zd_multi.cpp
+extern "C" {
+int zd_plan_stage_y_group(zd_plan *pl, void *d_recv, int chunk_planes, int nplanes, void *hip_stream);
+int zd_plan_stage_x_group(zd_plan *pl, int residue, const void *d_recv, int chunk_planes, int64_t plane0, int64_t gplane0,
+                          int64_t nplanes, void *d_records, float *d_density, void *hip_stream);
+}
+int zd_generate_multi(const zd_params *p, const zd_pk *pk, const double *eig, int64_t eig_ppd, zd_slab_cb cb, void *user,
+                      zd_stats *out, int transport);

@@ -3,14 +3,18 @@
 The reference is single-process; its y<->z "transpose" is StoreBlock/LoadBlock on one big array
 (src/block_array.cpp:387-414,466-504).  Here rank g of G owns the half-space rows ky = g, g + G, g + 2G, ...
 (cyclic: the rows near ky = 0 carry most of the non-zero modes) during the Z stage and the planes
-[g*Zq,(g+1)*Zq) of each residue pass during the XY stage; the block exchange between the two is ONE all-to-all per pass (RCCL over xGMI through
-torch.distributed; gloo in the CPU tests).  No other collective is on the data path.
+[g*Zq,(g+1)*Zq) of each residue pass during the XY stage.  The send store is laid out
+[destination rank][plane][array|field][row slot][x]: the planes [p0, p1) of every chunk are contiguous, so the
+exchange runs in PLANE GROUPS into a two-slot ring — group j+1 travels while the y and x stages of group j run —
+and no second full-size store exists.  No other collective is on the data path.
 
-`engine` is anything with the staged interface of include/zeldovich_hip.h:
-    engine.R, engine.passes, engine.plane_step, engine.local_planes, engine.exchange_bytes, engine.record_size
-    engine.stage_z(residue, send), engine.stage_y(recv), engine.stage_x(residue, recv, p0, n, out)
-    engine.plane_z(residue, local_plane)
-On a GPU it is `HipEngine` (zeldovich_plt_amd.api.Plan on torch device buffers).
+On a GPU the whole pass (Z stage, exchange over RCCL/xGMI, XY stages) runs inside the library
+(`zd_plan_run_pass`, csrc/zd_multi.cpp); `SlabPipeline` then only owns the buffers.  The same pipeline written against
+an abstract `engine` (anything with the staged interface of include/zeldovich_hip.h) and torch.distributed
+point-to-point operations is what the CPU tests drive with gloo and a numpy stand-in engine:
+    engine.R, .passes, .plane_step, .local_planes, .exchange_bytes, .record_size, .world
+    engine.stage_z(residue, send), engine.stage_y_group(buf, chunk_planes, nplanes),
+    engine.stage_x_group(residue, buf, chunk_planes, plane0, gplane0, nplanes, out), engine.plane_z(residue, local_plane)
 """
 import torch
 
@@ -18,8 +22,11 @@ import torch
 class HipEngine:
     """The product engine: libzeldovich_hip.so plan on torch-owned HBM buffers (no CPU fallback)."""
 
-    def __init__(self, plan, ppd):
+    native = True
+
+    def __init__(self, plan, ppd, comm=None):
         self.plan = plan
+        self.comm = comm
         self.ppd = ppd
         self.R = plan.R
         self.passes = plan.passes
@@ -35,82 +42,100 @@ class HipEngine:
     def plane_z(self, residue, local_plane):
         return self.plan.plane_z(residue, local_plane)
 
-    def stage_z(self, residue, send):
-        self.plan.stage_z(residue, send.data_ptr(), self._stream())
-
-    def stage_y(self, recv):
-        self.plan.stage_y(recv.data_ptr(), self._stream())
-
-    def stage_x(self, residue, recv, plane0, nplanes, out):
-        self.plan.stage_x(residue, recv.data_ptr(), plane0, nplanes, out.data_ptr(), None, self._stream())
+    def run_pass(self, residue, store, ring, rec_planes, consume=None):
+        """Z stage -> exchange in plane groups (overlapped) -> y / x stages, all inside the library"""
+        self.plan.run_pass(residue, store.data_ptr(), ring.data_ptr(), rec_planes, comm=self.comm, consume=consume,
+                           stream=self._stream())
 
 
 class SlabPipeline:
-    """Runs residue passes: Z stage -> all-to-all -> y FFT -> x FFT + epilogue in plane chunks."""
+    """Runs residue passes: Z stage -> exchange of plane groups -> y FFT -> x FFT + epilogue per group."""
 
-    def __init__(self, engine, ppd, world=1, dist=None, device="cpu", chunk_bytes=8 << 30):
+    def __init__(self, engine, ppd, world=1, dist=None, device="cpu", chunk_bytes=8 << 30, group_bytes=4 << 30):
         # chunk_bytes: size of the record ring = planes finished per x-stage launch.  At PPD=4096 one plane of RVZel
-        # records is 537 MB; launches of a single store plane (4096 workgroups, 16 per CU) lose 13 % to launch tails
-        # (k_xfft 0.89 -> 0.77 s per step with 8 GB).
+        # records is 537 MB; launches of a single store plane (4096 workgroups, 16 per CU) lose 13 % to launch tails.
         self.e = engine
         self.ppd = ppd
         self.world = world
         self.dist = dist
-        if world > 1 and dist is None:
+        self.native = bool(getattr(engine, "native", False))
+        if world > 1 and dist is None and not self.native:
             raise ValueError("world > 1 needs torch.distributed")
-        # float64 elements: a dtype every backend (RCCL, gloo) moves natively, 8x fewer elements than bytes
         assert engine.exchange_bytes % (8 * world) == 0
         nel = engine.exchange_bytes // 8
+        # float64 elements: a dtype every backend moves natively
         self.send = torch.empty(nel, dtype=torch.float64, device=device)
-        self.recv = torch.empty(nel, dtype=torch.float64, device=device) if world > 1 else self.send
         plane_b = ppd * ppd * max(engine.record_size, 1)
-        step = getattr(engine, "plane_step", 1)  # a store plane may deliver two z planes (packed ZA store)
+        step = getattr(engine, "plane_step", 1)  # a store plane may deliver two z planes (packed ZA stores)
         self.chunk = int(max(step, min(engine.local_planes, chunk_bytes // plane_b) // step * step))
         self.ring = torch.empty(self.chunk * plane_b, dtype=torch.uint8, device=device)
+        # stand-in path only: receive ring of two slots, each [source rank][group planes] of a chunk
+        self.Zq = engine.local_planes // step
+        self.chunk_plane_el = nel // world // self.Zq  # float64 elements of one store plane inside one chunk
+        if world > 1 and not self.native:
+            gp = max(1, min(self.Zq, group_bytes // (self.chunk_plane_el * 8 * world)))
+            self.group_planes = int(gp)
+            self.recv = torch.empty(2 * world * gp * self.chunk_plane_el, dtype=torch.float64, device=device)
 
-    # largest single message of the exchange, in float64 elements: at PPD=4096 on 2 ranks a peer's chunk is
-    # 52 GB = 6.5e9 elements — past what a 32-bit element count anywhere inside a collective library could hold.
-    # Below the limit (e.g. 8 ranks: 1.6e9) the exchange is ONE all_to_all_single.
-    MAX_MSG_ELEMS = (1 << 31) - 1
-
-    def exchange(self):
-        if self.world <= 1:
-            return
-        # chunk d of `send` goes to rank d and arrives as chunk <my rank> there: exactly the
-        # y-slab-owner -> z-slab-owner block move of StoreBlock/LoadBlock
-        per = self.send.numel() // self.world
-        if per <= self.MAX_MSG_ELEMS:
-            self.dist.all_to_all_single(self.recv, self.send)
-            return
-        # same move in k rounds of equal contiguous pieces (piece i of every peer chunk per round)
-        k = -(-per // self.MAX_MSG_ELEMS)
-        while per % k:
-            k += 1
-        part = per // k
-        sv, rv = self.send.view(self.world, k, part), self.recv.view(self.world, k, part)
+    # ---- exchange of one plane group (stand-in path): chunk <me> of every peer, planes [p0, p0+np) -> ring slot ----
+    def _exchange_group(self, j):
+        w, gp, cpe = self.world, self.group_planes, self.chunk_plane_el
+        p0 = j * gp
+        npl = min(gp, self.Zq - p0)
+        slot = self.recv[(j & 1) * w * gp * cpe:((j & 1) + 1) * w * gp * cpe].view(w, gp * cpe)
+        sv = self.send.view(w, self.Zq * cpe)
         me = self.dist.get_rank()
-        for i in range(k):
-            ops = []
-            for d in range(self.world):
-                if d == me:
-                    rv[d, i].copy_(sv[d, i])
-                else:
-                    ops.append(self.dist.P2POp(self.dist.isend, sv[d, i], d))
-                    ops.append(self.dist.P2POp(self.dist.irecv, rv[d, i], d))
-            for req in self.dist.batch_isend_irecv(ops):
-                req.wait()
+        ops = []
+        for d in range(w):
+            src = sv[d, p0 * cpe:(p0 + npl) * cpe]          # what rank d will finish
+            dst = slot[d, :npl * cpe]                        # what rank d generated for me
+            if d == me:
+                dst.copy_(src)
+            else:
+                ops.append(self.dist.P2POp(self.dist.isend, src, d))
+                ops.append(self.dist.P2POp(self.dist.irecv, dst, d))
+        return (self.dist.batch_isend_irecv(ops) if ops else []), slot, npl
 
     def run_pass(self, residue, consume=None):
         """consume(z_list, ring_tensor) is called once per plane chunk with the global z of each plane"""
         e = self.e
-        e.stage_z(residue, self.send)
-        self.exchange()
-        e.stage_y(self.recv)
-        for p0 in range(0, e.local_planes, self.chunk):
-            n = min(self.chunk, e.local_planes - p0)
-            e.stage_x(residue, self.recv, p0, n, self.ring)
+        step = getattr(e, "plane_step", 1)
+        if self.native:
+            cb = None
             if consume is not None:
-                consume([e.plane_z(residue, p0 + i) for i in range(n)], self.ring)
+                def cb(first, n, recp, st):
+                    consume([e.plane_z(residue, first + i) for i in range(n)], self.ring)
+                    return 0
+            e.run_pass(residue, self.send, self.ring, self.chunk, cb)
+            return
+        e.stage_z(residue, self.send)
+        if self.world <= 1:
+            e.stage_y_group(self.send, self.Zq, self.Zq)
+            for p0 in range(0, e.local_planes, self.chunk):
+                n = min(self.chunk, e.local_planes - p0)
+                e.stage_x_group(residue, self.send, self.Zq, p0, p0, n, self.ring)
+                if consume is not None:
+                    consume([e.plane_z(residue, p0 + i) for i in range(n)], self.ring)
+            return
+        gp = self.group_planes
+        ngroups = -(-self.Zq // gp)
+        pending = self._exchange_group(0)
+        for j in range(ngroups):
+            reqs, slot, npl = pending
+            if j + 1 < ngroups:
+                pending = self._exchange_group(j + 1)  # the next group travels while this one is transformed
+            for r in reqs:
+                r.wait()
+            buf = slot.view(-1)
+            e.stage_y_group(buf, gp, npl)
+            for q0 in range(0, npl * step, self.chunk):
+                n = min(self.chunk, npl * step - q0)
+                g0 = j * gp * step + q0
+                e.stage_x_group(residue, buf, gp, q0, g0, n, self.ring)
+                if consume is not None:
+                    consume([e.plane_z(residue, g0 + i) for i in range(n)], self.ring)
+        # every peer has taken its planes before the next Z stage overwrites the send store
+        self.dist.barrier()
 
     def run(self, consume=None):
         for r in range(getattr(self.e, "passes", self.e.R)):
