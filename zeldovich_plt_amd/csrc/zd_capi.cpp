@@ -2,7 +2,12 @@
 // zd_generate (= ZeldovichZ + ZeldovichXY, src/zeldovich.cpp:517-695) and the device test hooks.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1021,32 +1026,85 @@ int zd_generate(const zd_params *p_in, const zd_pk *pk, const double *eig, int64
     const int64_t Pp = zd_plan_local_planes(pl);  // planes delivered per pass
     const bool want_rec = pl->narray >= 2, want_dens = p.qdensity != 0;
 
-    void *d_store = nullptr, *d_rec = nullptr;
-    float *d_dens = nullptr;
-    char *h_rec = nullptr;
-    float *h_dens = nullptr;
+    // Delivery (WriteParticlesSlab's role, src/output.cpp:207-224) is asynchronous: NB = 2 record buffers on the device
+    // and in pinned host memory; chunk i is produced into buffer i % 2 on the compute stream, copied D2H on a copy stream
+    // and handed to a writer thread that runs the callback plane by plane — the x stage of chunk i+1, the PCIe copy of
+    // chunk i and the callback of chunk i-1 overlap (round 1 serialised the three).  The callback is still invoked
+    // from ONE thread, in production order.
+    constexpr int NB = 2;
+    void *d_store = nullptr, *d_rec[NB] = {nullptr, nullptr};
+    float *d_dens[NB] = {nullptr, nullptr};
+    char *h_rec[NB] = {nullptr, nullptr};
+    float *h_dens[NB] = {nullptr, nullptr};
+    hipEvent_t ev_x[NB] = {nullptr, nullptr}, ev_c[NB] = {nullptr, nullptr};
+    hipStream_t s_copy = nullptr;
     int rc = 1;
     hipStream_t st = 0;
     // planes handed over per x-stage launch (a multiple of the plane step)
     const int64_t plane_b = N * N * (int64_t) (want_rec ? recsize : 0) + (want_dens ? N * N * 4 : 0);
-    // (with a host callback the ring is mirrored in pinned host memory: 1 GB; the NULL sink takes 8 GB so that an
+    // (with a host callback each buffer is mirrored in pinned host memory: 1 GB; the NULL sink takes 8 GB so that an
     // x-stage launch covers several planes even at PPD=4096, where one plane of records is 537 MB)
     const int64_t ring_b = cb ? ((int64_t) 1 << 30) : ((int64_t) 8 << 30);
     int chunk = (int) std::max<int64_t>(1, std::min<int64_t>(Pp, ring_b / std::max<int64_t>(plane_b, 1)));
     chunk     = std::max(pstep, chunk / pstep * pstep);
+    const int nbuf = cb ? NB : 1;
+    struct Item {
+        int slot, pass;
+        int64_t first, n, only;  // only >= 0: deliver just that local plane (ZD_qoneslab)
+    };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Item> queue;
+    bool slot_busy[NB] = {false, false}, done = false;
+    std::atomic<int> cb_failed{0};
+    std::thread writer;
     std::chrono::steady_clock::time_point t0;
     do {
         if (hipMalloc(&d_store, (size_t) zd_plan_exchange_bytes(pl)) != hipSuccess) {
             fprintf(stderr, "zeldovich_hip: cannot allocate the %.2f GB block store\n", zd_plan_exchange_bytes(pl) / 1e9);
             break;
         }
-        if (want_rec && hipMalloc(&d_rec, (size_t) chunk * N * N * recsize) != hipSuccess) break;
-        if (want_dens && hipMalloc((void **) &d_dens, (size_t) chunk * N * N * 4) != hipSuccess) break;
-        if (cb) {
-            if (want_rec && hipHostMalloc((void **) &h_rec, (size_t) chunk * N * N * recsize) != hipSuccess) break;
-            if (want_dens && hipHostMalloc((void **) &h_dens, (size_t) chunk * N * N * 4) != hipSuccess) break;
+        bool ok = true;
+        for (int b2 = 0; b2 < nbuf && ok; b2++) {
+            if (want_rec && hipMalloc(&d_rec[b2], (size_t) chunk * N * N * recsize) != hipSuccess) ok = false;
+            if (want_dens && hipMalloc((void **) &d_dens[b2], (size_t) chunk * N * N * 4) != hipSuccess) ok = false;
+            if (cb) {
+                if (want_rec && hipHostMalloc((void **) &h_rec[b2], (size_t) chunk * N * N * recsize) != hipSuccess) ok = false;
+                if (want_dens && hipHostMalloc((void **) &h_dens[b2], (size_t) chunk * N * N * 4) != hipSuccess) ok = false;
+                if (hipEventCreateWithFlags(&ev_x[b2], hipEventDisableTiming) != hipSuccess) ok = false;
+                if (hipEventCreateWithFlags(&ev_c[b2], hipEventDisableTiming) != hipSuccess) ok = false;
+            }
         }
+        if (!ok) break;
+        if (cb && hipStreamCreateWithFlags(&s_copy, hipStreamNonBlocking) != hipSuccess) break;
         if (hipDeviceSynchronize() != hipSuccess) break;
+        if (cb) {
+            writer = std::thread([&]() {
+                for (;;) {
+                    Item it;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return done || !queue.empty(); });
+                        if (queue.empty()) return;
+                        it = queue.front();
+                        queue.pop_front();
+                    }
+                    if (hipEventSynchronize(ev_c[it.slot]) != hipSuccess) cb_failed.store(1);
+                    for (int64_t i = 0; i < it.n && !cb_failed.load(); i++) {
+                        if (it.only >= 0 && it.first + i != it.only) continue;
+                        const int64_t z = zd_plan_plane_z(pl, it.pass, it.first + i);
+                        if (cb(user, z, N * N, want_rec ? h_rec[it.slot] + (size_t) i * N * N * recsize : nullptr,
+                               want_dens ? h_dens[it.slot] + (size_t) i * N * N : nullptr))
+                            cb_failed.store(1);
+                    }
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        slot_busy[it.slot] = false;
+                    }
+                    cv.notify_all();
+                }
+            });
+        }
         t0 = std::chrono::steady_clock::now();
         bool fail = false;
         // ZD_qoneslab (zeldovich.cpp:669): only that slab is wanted -> only its pass and its store plane are finished
@@ -1057,6 +1115,7 @@ int zd_generate(const zd_params *p_in, const zd_pk *pk, const double *eig, int64
             want_pass   = r % npass;
             want_plane  = (int64_t) (p.qoneslab / R) * pstep + r / npass;
         }
+        long long nchunk = 0;
         for (int r = 0; r < npass && !fail; r++) {
             if (want_pass >= 0 && r != want_pass) continue;
             if (zd_plan_stage_z(pl, r, d_store, st) || zd_plan_stage_y(pl, d_store, st)) {
@@ -1070,35 +1129,66 @@ int zd_generate(const zd_params *p_in, const zd_pk *pk, const double *eig, int64
                     first = want_plane / pstep * pstep;
                     n     = pstep;
                 }
-                if (zd_plan_stage_x(pl, r, d_store, first, n, d_rec, d_dens, st)) {
+                const int slot = cb ? (int) (nchunk++ % NB) : 0;
+                if (cb) {  // the writer has finished with this slot's host buffer (chunk i - 2) — and with it its D2H copy
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return !slot_busy[slot] || cb_failed.load(); });
+                    if (cb_failed.load()) {
+                        fail = true;
+                        break;
+                    }
+                    slot_busy[slot] = true;
+                }
+                if (zd_plan_stage_x(pl, r, d_store, first, n, d_rec[slot], d_dens[slot], st)) {
                     fail = true;
                     break;
                 }
                 if (cb) {
-                    if (want_rec && hipMemcpyAsync(h_rec, d_rec, (size_t) n * N * N * recsize, hipMemcpyDeviceToHost, st) != hipSuccess) fail = true;
-                    if (want_dens && hipMemcpyAsync(h_dens, d_dens, (size_t) n * N * N * 4, hipMemcpyDeviceToHost, st) != hipSuccess) fail = true;
-                    if (hipStreamSynchronize(st) != hipSuccess) fail = true;
-                    for (int64_t i = 0; i < n && !fail; i++) {
-                        if (want_plane >= 0 && first + i != want_plane) continue;
-                        const int64_t z = zd_plan_plane_z(pl, r, first + i);
-                        if (cb(user, z, N * N, want_rec ? h_rec + (size_t) i * N * N * recsize : nullptr,
-                               want_dens ? h_dens + (size_t) i * N * N : nullptr))
-                            fail = true;
+                    if (hipEventRecord(ev_x[slot], st) != hipSuccess || hipStreamWaitEvent(s_copy, ev_x[slot], 0) != hipSuccess) fail = true;
+                    if (want_rec && hipMemcpyAsync(h_rec[slot], d_rec[slot], (size_t) n * N * N * recsize, hipMemcpyDeviceToHost, s_copy) != hipSuccess) fail = true;
+                    if (want_dens && hipMemcpyAsync(h_dens[slot], d_dens[slot], (size_t) n * N * N * 4, hipMemcpyDeviceToHost, s_copy) != hipSuccess) fail = true;
+                    if (hipEventRecord(ev_c[slot], s_copy) != hipSuccess) fail = true;
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        queue.push_back(Item{slot, r, first, n, want_plane});
                     }
+                    cv.notify_all();
                 }
             }
+        }
+        if (cb) {  // drain
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return (queue.empty() && !slot_busy[0] && !slot_busy[1]) || cb_failed.load(); });
+            }
+            if (cb_failed.load()) fail = true;
         }
         if (fail) break;
         if (zd_plan_stats(pl, out)) break;
         out->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         rc = 0;
     } while (0);
+    if (writer.joinable()) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            done = true;
+            queue.clear();
+        }
+        cv.notify_all();
+        writer.join();
+    }
+    hipDeviceSynchronize();
     hipFree(d_phik);
     hipFree(d_store);
-    hipFree(d_rec);
-    hipFree(d_dens);
-    if (h_rec) hipHostFree(h_rec);
-    if (h_dens) hipHostFree(h_dens);
+    for (int b2 = 0; b2 < NB; b2++) {
+        hipFree(d_rec[b2]);
+        hipFree(d_dens[b2]);
+        if (h_rec[b2]) hipHostFree(h_rec[b2]);
+        if (h_dens[b2]) hipHostFree(h_dens[b2]);
+        if (ev_x[b2]) hipEventDestroy(ev_x[b2]);
+        if (ev_c[b2]) hipEventDestroy(ev_c[b2]);
+    }
+    if (s_copy) hipStreamDestroy(s_copy);
     zd_plan_destroy(pl);
     return rc;
 }

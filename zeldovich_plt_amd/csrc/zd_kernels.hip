@@ -2078,7 +2078,7 @@ int launch_zfft_fields(int L, const FieldLayout &F, const StoreLayout &S, int ky
         ZCASE(64, 16, 32)
         ZCASE(128, 16, 32)
         ZCASE(256, 16, 16)
-        ZCASE(512, 16, 16)
+        ZCASE(512, 16, 8)
         ZCASE(1024, 16, 8)
         ZCASE(2048, 16, 8)
         ZCASE(4096, 16, 4)
