@@ -182,7 +182,7 @@ def test_parseheader_grammar_features(zd, tmp_path):
     text = ('include "%s"\n' % inc) + text
     text += "##\nNP = 5   this whole block is a comment\n##\n"
     text += "ZD_qonemode = true\nZD_one_mode = 1 \\\n   2 \\\n  -3\n"
-    text += "vector a b\n1 2\n3 4\nmapvar m a\n"
+    text += "vcounter nrows\nvector a b\n1 2\n3 4\nmapvar m a\n"
     par = tmp_path / "g.par"
     par.write_text(text)
     p, s = zd.params_from_file(str(par))
@@ -192,3 +192,32 @@ def test_parseheader_grammar_features(zd, tmp_path):
         bad = tmp_path / "bad.par"
         bad.write_text('include "/nonexistent/file.par"\n' + text)
         zd.params_from_file(str(bad))
+
+
+def test_parseheader_vector_vcounter_mapvar(zd, tmp_path):
+    """`vcounter` / `vector` blocks and `mapvar` aliases (subprojects/ParseHeader/src/phParser.yy:74-166,
+    phDriver.cc:433-531) are parsed, not skipped: a vector block can fill an installed vector (ZD_one_mode), a mapvar
+    alias assigns its base variable, tables of variables this program does not know are accepted, and the grammar's
+    errors are errors"""
+    base = EXAMPLE % dict(out=tmp_path / "ic", eig="./eigmodes128", pk=WMAP, plt=0)
+    text = base.replace("ZD_Seed = 12346\n", "")
+    text += "mapvar ZD_Seed MasterSeed LegacySeed\nMasterSeed = 777      # assigns ZD_Seed\n"
+    text += "ZD_qonemode = 1\nvcounter nmode\nvector ZD_one_mode\n3\n5\n-7\n"
+    text += "vcounter nout\nvector OutputRedshift OutputLabel   # an Abacus-style table of another program\n3.0 'z3'\n1.5 \"z1.5\"\n0.0 z0\nnfinal = 3\n"
+    par = tmp_path / "v.par"
+    par.write_text(text)
+    p, s = zd.params_from_file(str(par))
+    assert p.seed == 777
+    assert p.qonemode == 1 and list(p.one_mode) == [3, 5, -7]
+
+    def fails(extra):
+        bad = tmp_path / "bad.par"
+        bad.write_text(base + extra)
+        with pytest.raises(ValueError):
+            zd.params_from_file(str(bad))
+
+    fails("vector a b\n1 2\n")                                  # vector before any vcounter (phDriver.cc:507-509)
+    fails("vcounter n\nvector a b\n1 2 3\n")                    # row length != number of variables
+    fails("mapvar ZD_Seed s1\nmapvar BoxSize s1\n")              # already mapped (phDriver.cc:442-446)
+    fails("BoxSize 720\n")                                       # statement without '=' (phParser.yy:95-99)
+    fails("vcounter n\nvector a\n1\n\n2\n")                    # a blank line ends the block: the next row is a syntax error

@@ -307,12 +307,67 @@ static double to_double(std::string s) {
     return strtod(s.c_str(), NULL);
 }
 
-// Reads `key = value ...` statements the way the reference's ParseHeader scanner does
-// (subprojects/ParseHeader/src/phScanner.ll:95-240): `#` comments, `##` block comments, quoted strings,
-// a trailing backslash continues the statement on the next line, `include "file"` splices another file
-// (depth <= 10, phScanner.ll:176-203), a ^B character ends the header.  Statements without `=`
-// (vector / mapvar / vcounter declarations and vector data rows) do not concern this program and are skipped.
-static int read_statements(const char *path, std::map<std::string, std::string> &kv, int depth) {
+// split a statement into tokens the way phScanner.ll does: blanks separate, quoted strings are one token
+static std::vector<std::string> tokens_of(const std::string &line) {
+    std::vector<std::string> out;
+    size_t i = 0;
+    while (i < line.size()) {
+        if (isspace((unsigned char) line[i])) {
+            i++;
+            continue;
+        }
+        size_t j = i;
+        if (line[i] == '"' || line[i] == '\'') {
+            const char q = line[i];
+            j = line.find(q, i + 1);
+            j = j == std::string::npos ? line.size() : j + 1;
+        } else {
+            while (j < line.size() && !isspace((unsigned char) line[j])) j++;
+        }
+        out.push_back(line.substr(i, j - i));
+        i = j;
+    }
+    return out;
+}
+
+struct HeaderState {
+    std::map<std::string, std::string> kv;
+    std::map<std::string, std::string> alias;  // mapvar: variable -> the variable whose storage it shares
+    std::string vcounter;                      // name of the current element counter (vcounter statement)
+    std::vector<std::string> vec_ids;          // open `vector` block: the variables its rows fill
+    std::vector<std::vector<std::string>> vec_cols;
+    bool in_vector = false;
+    void assign(const std::string &key, const std::string &val) {
+        auto it = alias.find(key);
+        kv[it == alias.end() ? key : it->second] = val;
+    }
+    // a vector block ends at the first statement that is not a row of values (phParser.yy:117-128): every variable gets
+    // its column (values separated by blanks, which is how the installed vectors are written with `=`), the counter the
+    // number of rows
+    void close_vector() {
+        if (!in_vector) return;
+        for (size_t i = 0; i < vec_ids.size(); i++) {
+            std::string v;
+            for (const auto &e : vec_cols[i]) v += (v.empty() ? "" : " ") + e;
+            assign(vec_ids[i], v);
+        }
+        if (!vcounter.empty()) kv[vcounter] = std::to_string(vec_cols.empty() ? 0 : vec_cols[0].size());
+        in_vector = false;
+        vec_ids.clear();
+        vec_cols.clear();
+    }
+};
+
+// Reads the statements of a parameter file the way the reference's ParseHeader does (scanner
+// subprojects/ParseHeader/src/phScanner.ll:95-240, grammar phParser.yy:74-166): `#` comments, `##` block comments,
+// quoted strings, a trailing backslash continues the statement on the next line, `include "file"` splices another file
+// (depth <= 10, phScanner.ll:176-203), a ^B character ends the header;
+//   id = value ...            assignment
+//   vcounter id               id counts the rows of the vector blocks that follow (phDriver.cc:469-485)
+//   vector id ...             the following lines of bare values are rows: column i fills variable i (:504-531)
+//   mapvar base id ...        the ids share base's storage: assigning one assigns base (:433-467)
+// anything else without `=` is the reference's syntax error "expecting '='".
+static int read_statements(const char *path, HeaderState &H, int depth) {
     if (depth > 10) {
         fprintf(stderr, "ERROR: exceeded maximum include stack depth: 10.\n");
         return 1;
@@ -324,7 +379,9 @@ static int read_statements(const char *path, std::map<std::string, std::string> 
     }
     std::string line, pending;
     bool in_block_comment = false;
+    int lineno = 0;
     while (std::getline(in, line)) {
+        lineno++;
         if (!line.empty() && line[0] == '\x02') break;  // ^B ends the header (ParseHeader convention)
         if (trim(line).rfind("##", 0) == 0 && line.rfind("##", 0) == 0) {  // `##` at line start toggles a block comment
             in_block_comment = !in_block_comment;
@@ -353,23 +410,100 @@ static int read_statements(const char *path, std::map<std::string, std::string> 
         line = pending + line;
         pending.clear();
         const std::string st = trim(line);
-        if (st.compare(0, 7, "include") == 0 && st.size() > 7 && (isspace((unsigned char) st[7]) || st[7] == '"' || st[7] == '\'')) {
-            const std::string inc = unquote(st.substr(7));
-            if (read_statements(inc.c_str(), kv, depth + 1)) return 1;
+        if (st.empty()) {  // a bare end of statement closes an open vector block
+            H.close_vector();
             continue;
         }
-        const size_t eq = line.find('=');
-        if (eq == std::string::npos) continue;
-        const std::string key = trim(line.substr(0, eq));
-        if (key.empty()) continue;
-        kv[key] = trim(line.substr(eq + 1));
+        if (st.compare(0, 7, "include") == 0 && st.size() > 7 && (isspace((unsigned char) st[7]) || st[7] == '"' || st[7] == '\'')) {
+            H.close_vector();
+            const std::string inc = unquote(st.substr(7));
+            if (read_statements(inc.c_str(), H, depth + 1)) return 1;
+            continue;
+        }
+        size_t eq = std::string::npos;  // first `=` outside quotes
+        {
+            char qc = 0;
+            for (size_t i = 0; i < line.size(); i++) {
+                if (qc) {
+                    if (line[i] == qc) qc = 0;
+                } else if (line[i] == '"' || line[i] == '\'')
+                    qc = line[i];
+                else if (line[i] == '=') {
+                    eq = i;
+                    break;
+                }
+            }
+        }
+        if (eq != std::string::npos) {
+            H.close_vector();
+            const std::string key = trim(line.substr(0, eq));
+            if (key.empty()) continue;
+            H.assign(key, trim(line.substr(eq + 1)));
+            continue;
+        }
+        const std::vector<std::string> tok = tokens_of(st);
+        if (tok[0] == "vcounter") {
+            H.close_vector();
+            if (tok.size() != 2) {
+                fprintf(stderr, "%s:%d: ERROR: vcounter takes one variable name\n", path, lineno);
+                return 1;
+            }
+            H.vcounter = tok[1];
+            H.kv[tok[1]] = "0";
+            continue;
+        }
+        if (tok[0] == "vector") {
+            H.close_vector();
+            if (H.vcounter.empty()) {
+                fprintf(stderr, "%s:%d: ERROR: must specify a vcounter variable before vector statement.\n", path, lineno);
+                return 1;
+            }
+            if (tok.size() < 2) {
+                fprintf(stderr, "%s:%d: ERROR: vector statement without variables\n", path, lineno);
+                return 1;
+            }
+            H.vec_ids.assign(tok.begin() + 1, tok.end());
+            H.vec_cols.assign(H.vec_ids.size(), {});
+            H.in_vector = true;
+            continue;
+        }
+        if (tok[0] == "mapvar") {
+            H.close_vector();
+            if (tok.size() < 3) {
+                fprintf(stderr, "%s:%d: ERROR: mapvar needs a base variable and at least one name\n", path, lineno);
+                return 1;
+            }
+            for (size_t i = 2; i < tok.size(); i++) {
+                auto it = H.alias.find(tok[i]);
+                if (it != H.alias.end()) {
+                    fprintf(stderr, "%s:%d: ERROR: variable \"%s\" already mapped to \"%s\"\n", path, lineno, tok[i].c_str(), it->second.c_str());
+                    return 1;
+                }
+                H.alias[tok[i]] = tok[1];
+            }
+            continue;
+        }
+        if (H.in_vector) {  // one row: value i goes to variable i (extra values / short rows: phDriver's stuffit complains)
+            if (tok.size() != H.vec_ids.size()) {
+                fprintf(stderr, "%s:%d: ERROR: vector row has %zu values for %zu variables\n", path, lineno, tok.size(), H.vec_ids.size());
+                return 1;
+            }
+            for (size_t i = 0; i < tok.size(); i++) H.vec_cols[i].push_back(tok[i]);
+            continue;
+        }
+        fprintf(stderr, "%s:%d: ERROR: syntax error, unexpected %s \"%s\", expecting '%s='\n", path, lineno,
+                (isalpha((unsigned char) tok[0][0]) || tok[0][0] == '_' || tok[0][0] == '.' || tok[0][0] == '$') ? "string" : "value",
+                tok[0].c_str(), isalpha((unsigned char) tok[0][0]) ? "" : "identifier ");
+        return 1;
     }
+    H.close_vector();
     return 0;
 }
 
 int zd_params_from_file(const char *path, zd_params *p, zd_param_strings *s) {
-    std::map<std::string, std::string> kv;
-    if (read_statements(path, kv, 0)) return 1;
+    HeaderState H;
+    if (read_statements(path, H, 0)) return 1;
+    std::map<std::string, std::string> &kv = H.kv;
 
     // defaults: src/parameters.cpp:13-44
     memset(p, 0, sizeof(*p));
