@@ -1,0 +1,15 @@
+"""PPD=8192 ZD_k_cutoff=2 (BASELINE C5 workload) on one GPU through zd_generate with the NULL sink: wall time, stream factor"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import zeldovich_plt_amd.api as zd
+WMAP = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "wmap1new.pow")
+ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+kc = float(sys.argv[2]) if len(sys.argv) > 2 else 2.0
+mode = sys.argv[3] if len(sys.argv) > 3 else "auto"
+p = zd.make_params(n, k_cutoff=kc, icformat="RVZel", profile=1, store_mode=mode)
+t0 = time.time()
+out = zd.generate(p, ps, collect=False)
+print("PPD=%d k_cutoff=%g store=%s: R=%d  %.2f s (library), wall %.1f s; kernel ms %s; dens var %.17g max_disp %s" % (
+    n, kc, mode, out["stream_factor"], out["seconds_total"], time.time() - t0, {k: round(v) for k, v in out["kernel_ms"].items()},
+    out["density_variance"], out["max_disp"]), flush=True)

@@ -192,7 +192,6 @@ static int pack_mode(const zd_params *p, int R) {
     if (p->store_mode == ZD_STORE_REFERENCE) return zd::PACK_NONE;
     if (p->qdensity != 0 || p->f_NL != 0.) return zd::PACK_NONE;
     if (p->qoneslab >= 0) return zd::PACK_NONE;  // density_variance is then the sum over that one slab (output.cpp:197)
-    if (p->ppd > 4096) return zd::PACK_NONE;  // the x pass of 3 arrays at PPD=8192 needs > 160 KB of LDS
     {   // The packed stores treat every field as the transform of a REAL field (Hermitian modes) and take
         // density_variance from sum |D|^2.  That needs every mode with a component on the Nyquist plane |k_i| = N/2 to
         // be zero: the |k_i| == kmax rule does it when kmax == N/2 (k_cutoff = 1), the spherical cut when k_cutoff >= 1
@@ -202,9 +201,12 @@ static int pack_mode(const zd_params *p, int R) {
         const bool nyquist_dead = kmax == half || (!p->corner_modes && p->k_cutoff >= 1.0);
         if (!nyquist_dead) return zd::PACK_NONE;
     }
-    if (p->qPLT) return zd::PACK_PLT3;
+    // PPD = 8192: three lines of a row no longer fit a workgroup of the x pass; only the field store has an x kernel that
+    // takes them in sequence (k_xfft_seq)
+    if (p->qPLT) return p->ppd > 4096 ? zd::PACK_NONE : zd::PACK_PLT3;
     if (R < 2) return zd::PACK_NONE;  // the ZA packings carry two z-residues per pass
-    return p->store_mode == ZD_STORE_PACKED ? zd::PACK_ZAPAIR : zd::PACK_ZAFIELD;
+    if (p->store_mode == ZD_STORE_PACKED) return p->ppd > 4096 ? zd::PACK_NONE : zd::PACK_ZAPAIR;
+    return zd::PACK_ZAFIELD;
 }
 static int store_arrays(const zd_params *p, int R) {
     if (pack_mode(p, R) != zd::PACK_NONE) return 3;

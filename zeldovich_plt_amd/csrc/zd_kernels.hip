@@ -1486,6 +1486,13 @@ constexpr int XFFT_NH(int N, int NA, int ROWS) {
     return nh;
 }
 
+// passes over x of k_xfft_seq's epilogue: the staged fields (2*NA*N/NH doubles) reuse the FFT's LDS (lds_dbl doubles)
+constexpr int XFFT_SEQ_NH(int N, int NA, int lds_dbl) {
+    int nh = 1;
+    while (2 * NA * (N / nh) > lds_dbl && nh < 16) nh *= 2;
+    return nh;
+}
+
 __device__ __forceinline__ unsigned long long dbits(double v) { return (unsigned long long) __double_as_longlong(v); }
 
 // one particle record (include/output.h:19-49; WriteParticlesSlab output.cpp:128-141: i = z, j = y, k = x,
@@ -1533,54 +1540,13 @@ __device__ __forceinline__ void emit_record(char *__restrict__ records, long lon
     }
 }
 
-template <int N, int E, int NA, int ROWS>
-__global__ __launch_bounds__(ROWS *NA *N / E, (ROWS * NA * N / E == 512 ? 4 : 1)) void k_xfft(StoreLayout S, EpiConst ec, const cplx *__restrict__ tw,
-                                                         const cplx *__restrict__ data, int plane0,
-                                                         int z_first, int z_step, char *__restrict__ records,
-                                                         float *__restrict__ density, Reduce *__restrict__ red) {
-    using PL = zdfft::Plan<N, E>;
-    constexpr int WL = ROWS * NA;  // lines per workgroup
-    using LDS = zdfft::LineInner<N, WL>;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr int T = PL::T, NT = WL * T;
-    const int t = threadIdx.x % T, line = threadIdx.x / T;
-    const int row = line / NA, a = line % NA;
-    const int y  = blockIdx.x * ROWS + row;
-    const int pl = plane0 + blockIdx.y;  // local plane index inside the store
-    const cplx *src = data + row_offset(S, pl, a, y);
-    double re[E], im[E];
-#pragma unroll
-    for (int e = 0; e < E; e++) {
-        const cplx v = ld_stream(src + t + T * e, ZD_TUNE(S.nt & 4));
-        re[e] = v.x;
-        im[e] = v.y;
-    }
-    if (!ZD_TUNE(S.prune & 32)) zdfft::fft_line<PL, LDS>(re, im, t, line, lds, tw);  // bit 5: tuning ablation
-    if (ZD_TUNE(S.prune & 64) && re[0] != 123.456) return;                           // bit 6: tuning ablation (no epilogue)
-
-    // ---- WriteParticlesSlab (src/output.cpp:86-203) ----
-    // The unpacked fields go through LDS in NH passes over x so that the staging area stays <= 64 KB
-    // (two workgroups per CU): pass h covers x in [h*N/NH, (h+1)*N/NH) = elements e in [h*E/NH, ...).
-    constexpr int NH = XFFT_NH(N, NA, ROWS), NXH = N / NH, EH = E / NH;
-    const int z = z_first + z_step * (int) blockIdx.y;
-    double ssq = 0.0, mp[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
-    const long long plane_rec0 = (long long) blockIdx.y * N * N;
-    double *fld = lds;  // fld[(row*2*NA + 2a + {0,1})*NXH + x - h*NXH]
-    int t2 = t;
-    asm volatile("" : "+v"(t2));  // keep the staging-address arithmetic after the FFT (register pressure)
-#pragma unroll
-    for (int h = 0; h < NH; h++) {
-        __syncthreads();
-#pragma unroll
-        for (int e2 = 0; e2 < EH; e2++) {
-            const int e = h * EH + e2, xl = t2 + T * e - h * NXH;
-            fld[(row * 2 * NA + 2 * a) * NXH + xl]     = re[e];
-            fld[(row * 2 * NA + 2 * a + 1) * NXH + xl] = im[e];
-        }
-        __syncthreads();
-        // (Writing 32-byte records by lane pairs — 16 B per lane, 1 KB of consecutive bytes per wave — was measured
-        // 15 % SLOWER than one lane per record: the extra LDS reads cost more than the store pattern gains.)
-        for (int i = threadIdx.x; i < ROWS * NXH; i += NT) {
+// the part of WriteParticlesSlab (src/output.cpp:86-203) that consumes the staged fields of x pass h:
+// fld[(row*2*NA + 2a + {0,1})*NXH + x - h*NXH] -> records / density / running reductions
+template <int N, int NA, int ROWS, int NXH, int NT>
+__device__ __forceinline__ void xfft_consume(const EpiConst &ec, const double *__restrict__ fld, int h, int z, long long plane_rec0,
+                                             char *__restrict__ records, float *__restrict__ density, double &ssq,
+                                             double (&mp)[3], double (&mn)[3]) {
+    for (int i = threadIdx.x; i < ROWS * NXH; i += NT) {
             const int r = i / NXH, xl = i - r * NXH, xx = xl + h * NXH;
             const int yy = blockIdx.x * ROWS + r;
             const double *f = fld + (r * 2 * NA) * NXH + xl;
@@ -1633,8 +1599,11 @@ __global__ __launch_bounds__(ROWS *NA *N / E, (ROWS * NA * N / E == 512 ? 4 : 1)
                 }
             }
         }
-    }
-    // workgroup reduction -> one atomic per quantity into a replicated slot
+}
+
+// workgroup reduction of the epilogue -> one atomic per quantity into a replicated slot
+template <int NT, int NA>
+__device__ __forceinline__ void xfft_reduce(double *lds, Reduce *__restrict__ red, double ssq, double (&mp)[3], double (&mn)[3]) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         ssq += __shfl_down(ssq, off);
@@ -1674,6 +1643,125 @@ __global__ __launch_bounds__(ROWS *NA *N / E, (ROWS * NA * N / E == 512 ? 4 : 1)
             }
         }
     }
+}
+
+template <int N, int E, int NA, int ROWS>
+__global__ __launch_bounds__(ROWS *NA *N / E, (ROWS * NA * N / E == 512 ? 4 : 1)) void k_xfft(StoreLayout S, EpiConst ec, const cplx *__restrict__ tw,
+                                                         const cplx *__restrict__ data, int plane0,
+                                                         int z_first, int z_step, char *__restrict__ records,
+                                                         float *__restrict__ density, Reduce *__restrict__ red) {
+    using PL = zdfft::Plan<N, E>;
+    constexpr int WL = ROWS * NA;  // lines per workgroup
+    using LDS = zdfft::LineInner<N, WL>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int T = PL::T, NT = WL * T;
+    const int t = threadIdx.x % T, line = threadIdx.x / T;
+    const int row = line / NA, a = line % NA;
+    const int y  = blockIdx.x * ROWS + row;
+    const int pl = plane0 + blockIdx.y;  // local plane index inside the store
+    const cplx *src = data + row_offset(S, pl, a, y);
+    double re[E], im[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const cplx v = ld_stream(src + t + T * e, ZD_TUNE(S.nt & 4));
+        re[e] = v.x;
+        im[e] = v.y;
+    }
+    if (!ZD_TUNE(S.prune & 32)) zdfft::fft_line<PL, LDS>(re, im, t, line, lds, tw);  // bit 5: tuning ablation
+    if (ZD_TUNE(S.prune & 64) && re[0] != 123.456) return;                           // bit 6: tuning ablation (no epilogue)
+
+    // ---- WriteParticlesSlab (src/output.cpp:86-203) ----
+    // The unpacked fields go through LDS in NH passes over x so that the staging area stays <= 64 KB
+    // (two workgroups per CU): pass h covers x in [h*N/NH, (h+1)*N/NH) = elements e in [h*E/NH, ...).
+    constexpr int NH = XFFT_NH(N, NA, ROWS), NXH = N / NH, EH = E / NH;
+    const int z = z_first + z_step * (int) blockIdx.y;
+    double ssq = 0.0, mp[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
+    const long long plane_rec0 = (long long) blockIdx.y * N * N;
+    double *fld = lds;  // fld[(row*2*NA + 2a + {0,1})*NXH + x - h*NXH]
+    int t2 = t;
+    asm volatile("" : "+v"(t2));  // keep the staging-address arithmetic after the FFT (register pressure)
+#pragma unroll
+    for (int h = 0; h < NH; h++) {
+        __syncthreads();
+#pragma unroll
+        for (int e2 = 0; e2 < EH; e2++) {
+            const int e = h * EH + e2, xl = t2 + T * e - h * NXH;
+            fld[(row * 2 * NA + 2 * a) * NXH + xl]     = re[e];
+            fld[(row * 2 * NA + 2 * a + 1) * NXH + xl] = im[e];
+        }
+        __syncthreads();
+        // (Writing 32-byte records by lane pairs — 16 B per lane, 1 KB of consecutive bytes per wave — was measured
+        // 15 % SLOWER than one lane per record: the extra LDS reads cost more than the store pattern gains.)
+        xfft_consume<N, NA, ROWS, NXH, NT>(ec, fld, h, z, plane_rec0, records, density, ssq, mp, mn);
+    }
+    xfft_reduce<NT, NA>(lds, red, ssq, mp, mn);
+}
+
+// k_xfft_seq: the x pass of the field store for sizes where the three lines of a row do not fit a workgroup (PPD = 8192:
+// 1536 threads, 209 KB of LDS).  N/E threads own ONE row and transform its arrays one after the other.  The ring holds
+// (qx + i qy)_r0 | (qx + i qy)_r1 | qz_r0 + i qz_r1, so the two delivered planes need {array 0, Re array 2} and
+// {array 1, Im array 2}: array 2 is transformed first and kept in registers, then each of the other two is transformed
+// and its plane's records are written at once — never more than two arrays' results are live.
+//   grid: (N, nplanes)   block: N/E
+template <int N, int E>
+__global__ __launch_bounds__(N / E) void k_xfft_seq(StoreLayout S, EpiConst ec, const cplx *__restrict__ tw,
+                                                   const cplx *__restrict__ data, int plane0, int z_first, int z_step,
+                                                   char *__restrict__ records, Reduce *__restrict__ red) {
+    using PL  = zdfft::Plan<N, E>;
+    using LDS = zdfft::LineInner<N, 1>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int T = PL::T, NT = T;
+    const int t = threadIdx.x;
+    const int y = blockIdx.x, pl = plane0 + blockIdx.y;
+    auto load_fft = [&](int a, double (&re)[E], double (&im)[E]) {
+        const cplx *src = data + row_offset(S, pl, a, y);
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const cplx v = src[t + T * e];
+            re[e] = v.x;
+            im[e] = v.y;
+        }
+        zdfft::fft_line<PL, LDS>(re, im, t, 0, lds, tw);
+    };
+    double cr[E], ci[E];
+    load_fft(2, cr, ci);
+    constexpr int NH = XFFT_SEQ_NH(N, 2, LDS::SIZE);  // three real fields per pass of N/NH columns (2*2 >= 3)
+    constexpr int NXH = N / NH, EH = E / NH;
+    static_assert(EH >= 1 && 3 * NXH <= LDS::SIZE, "epilogue staging must fit the FFT's LDS");
+    const int z = z_first + z_step * (int) blockIdx.y;
+    double mp[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
+    const long long plane_rec0 = 2 * (long long) blockIdx.y * N * N;
+    double *fld = lds;
+#pragma unroll
+    for (int w2 = 0; w2 < 2; w2++) {
+        double ar[E], ai[E];
+        __syncthreads();
+        load_fft(w2, ar, ai);
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            __syncthreads();
+#pragma unroll
+            for (int e2 = 0; e2 < EH; e2++) {
+                const int e = h * EH + e2, xl = t + T * e - h * NXH;
+                fld[xl]           = ar[e];
+                fld[NXH + xl]     = ai[e];
+                fld[2 * NXH + xl] = w2 ? ci[e] : cr[e];
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < NXH; i += NT) {
+                const int xx = i + h * NXH;
+                const double pos[3] = {fld[i], fld[NXH + i], fld[2 * NXH + i]};
+                const double vel[3] = {pos[0] * ec.vnorm, pos[1] * ec.vnorm, pos[2] * ec.vnorm};
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    mp[j] = fmax(mp[j], pos[j]);
+                    mn[j] = fmax(mn[j], -pos[j]);
+                }
+                if (records) emit_record(records, plane_rec0 + (long long) w2 * N * N + (long long) y * N + xx, ec, z + w2 * ec.z_pair, y, xx, pos, vel);
+            }
+        }
+    }
+    xfft_reduce<NT, 3>(lds, red, 0.0, mp, mn);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2117,6 +2205,7 @@ int launch_yfft_fields(const FieldLayout &F, const StoreLayout &S, const void *t
         YCASE(1024, 16, 8)
         YCASE(2048, 16, 8)
         YCASE(4096, 16, 4)
+        YCASE(8192, 16, 2)
     }
 #undef YCASE
     fprintf(stderr, "zeldovich_hip: field store unsupported for PPD %d\n", S.N);
@@ -2167,8 +2256,28 @@ static int launch_xfft_t(const StoreLayout &S, const EpiConst &ec, const void *t
     ZD_LAUNCH_CHECK();
     return 0;
 }
+template <int N, int E>
+static int launch_xfft_seq_t(const StoreLayout &S, const EpiConst &ec, const void *tw, const void *data, int plane0,
+                             int nplanes, int z_first, int z_step, void *records, Reduce *red, hipStream_t st) {
+    const size_t shmem = sizeof(double) * zdfft::LineInner<N, 1>::SIZE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void *) k_xfft_seq<N, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+        attr_set = true;
+    }
+    dim3 grid(N, nplanes), block(N / E);
+    hipLaunchKernelGGL((k_xfft_seq<N, E>), grid, block, shmem, st, S, ec, (const cplx *) tw, (const cplx *) data, plane0, z_first,
+                       z_step, (char *) records, red);
+    ZD_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_xfft(const StoreLayout &S, const EpiConst &ec, const void *tw, const void *data, int plane0, int nplanes,
                 int z_first, int z_step, void *records, float *density, Reduce *red, hipStream_t st) {
+    // PPD = 8192 with the field store's ring: three lines of a row are 1536 threads / 209 KB of LDS -> one row per
+    // workgroup, its arrays in sequence
+    if (S.N == 8192 && S.narray == 3 && ec.pack == PACK_ZAFIELD)
+        return launch_xfft_seq_t<8192, 16>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, red, st);
 #define XCASE(n, e, rows1, rows2, rows4, rows3z, rows3p)                                                              \
     case n:                                                                                                           \
         if (S.narray == 1) return launch_xfft_t<n, e, 1, rows1>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, density, red, st); \
