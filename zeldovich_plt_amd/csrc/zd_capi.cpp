@@ -224,17 +224,19 @@ static void prune_rule(const zd_params *p, zd::StoreLayout &S) {
     S.k2_cutoff = p->corner_modes ? 0.0 : p->nyquist * p->nyquist / (p->k_cutoff * p->k_cutoff);  // CornerModes: only |k_i| == kmax prunes
 }
 
-// Row table of the field store (zd_device.h FieldLayout) for `nranks` ranks: slot i stands for the rows ky = c + nranks*i
-// of every rank c and is sized by the longest of them (ky = nranks*i).  Returns the elements per (plane, field) image.
+// Block table of the field store (zd_device.h FieldLayout) for `nranks` ranks: block b stands for the row slots 8b .. 8b+7
+// (rows ky = c + nranks*slot) of every rank c and is sized by the longest of them (ky = nranks*8b).  Returns the elements
+// per (plane, field) image.
 static int64_t field_rows(const zd_params *p, int nranks, std::vector<zd::FieldRow> *rows) {
     zd::StoreLayout S;
     memset(&S, 0, sizeof(S));
     prune_rule(p, S);
-    const int N = S.N, half = S.half, Hq = half / nranks, CW = zd::FIELD_CW, NT = std::max(1, N / CW);
+    const int N = S.N, half = S.half, Hq = half / nranks, CW = zd::FIELD_CW, NT = std::max(1, N / CW), RB = zd::FIELD_RB;
+    const int nblk = (Hq + RB - 1) / RB;
     int64_t total = 0;
-    if (rows) rows->resize(Hq);
-    for (int i = 0; i < Hq; i++) {
-        const int ky = i * nranks;
+    if (rows) rows->resize(nblk);
+    for (int i = 0; i < nblk; i++) {
+        const int ky = i * RB * nranks;
         // live columns are kx in (-c, c): tiles [0, tl) on the low side, [th, NT) on the high side
         int tl = 0, th = NT;
         if (N >= 2 * CW) {
@@ -264,8 +266,7 @@ static int64_t field_rows(const zd_params *p, int nranks, std::vector<zd::FieldR
         r.gap   = (unsigned short) (tl >= th ? 0 : (th - tl) * CW);
         if (rows) (*rows)[i] = r;
         // 384 B of padding per row as in the other stores: the first ~N/11 rows are complete (64 KiB apart at PPD = 4096)
-        // and the y stage reads 16 consecutive rows per wave — without the pad they all sit on one HBM channel
-        total += N - r.gap + store_row_pad(N);
+        total += (int64_t) (N - r.gap + store_row_pad(N)) * RB;
     }
     return total;
 }
@@ -341,6 +342,8 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
     pl->half    = (int) (N / 2);
     pl->narray  = (phi_mode == 1 || p->qdensity == 2) ? 1 : (p->qPLT ? 4 : 2);  // zeldovich.cpp:871-876
     if (phi_mode == 0 && phik == nullptr && pl->narray >= 2) pl->pack = pack_mode(p, R);
+    if (pl->pack == zd::PACK_ZAFIELD && ((pl->half / nranks) % zd::FIELD_RB || N / R > 2048))  // row blocks of 8, z FFT <= 2048
+        pl->pack = N > 4096 ? zd::PACK_NONE : zd::PACK_ZAPAIR;
     if (pl->pack != zd::PACK_NONE) pl->narray = 3;
     pl->pstep   = (pl->pack == zd::PACK_ZAPAIR || pl->pack == zd::PACK_ZAFIELD) ? 2 : 1;
     pl->npass   = R / pl->pstep;
@@ -660,6 +663,10 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         if (const char *env = tune_env("ZD_SLAB_MB")) slab_b = (int64_t) atoll(env) << 20;
         int rows = (int) std::max<int64_t>(1, slab_b / row_b);
         rows     = std::min(rows, pl->Hq);
+        if (pl->pack == zd::PACK_ZAFIELD) {  // whole row blocks
+            rows = std::max(zd::FIELD_RB, rows / zd::FIELD_RB * zd::FIELD_RB);
+            while (pl->Hq % rows) rows -= zd::FIELD_RB;
+        }
         while (pl->Hq % rows) rows--;
         pl->slab_rows = rows;
         pl->overlap   = p->serial_z == 0;

@@ -57,6 +57,12 @@ __device__ __forceinline__ u128 advance_bits(u128 s, uint64_t delta) {
     return s;
 }
 
+// folded inputs of the field store: Y[field j][row group][k2][x][8 rows] (k_zfft_fb reads 128-byte lines: one column, the
+// 8 rows of a group)
+__device__ __forceinline__ unsigned y_index_blocked(int j, int kyl, int nky, int L, int k2, int N, int x) {
+    return (unsigned) (((((j * (nky / FIELD_RB) + kyl / FIELD_RB) * L + k2) * N + x) * FIELD_RB) + (kyl & (FIELD_RB - 1)));
+}
+
 // PowerSpectrum::power (src/power_spectrum.cpp:225-261) with SplineFunction::val
 // (include/spline_function.h:141-163).  The reference bisects for the segment; here a uniform-cell
 // table over ln k gives a start index and a short forward scan lands on exactly the segment the
@@ -449,7 +455,7 @@ __global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, JobList 
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
             // a slab holds < 2^31 elements (1.5 GB / 16 B): 32-bit index arithmetic
-            const unsigned idx = (unsigned) (((j * nky + kyl) * L + k2) * N + x);
+            const unsigned idx = jobs.pack == PACK_ZAFIELD ? y_index_blocked(j, kyl, nky, L, k2, N, x) : (unsigned) (((j * nky + kyl) * L + k2) * N + x);
             Y[idx] = cplx{outr[j], outi[j]};
         }
     }
@@ -851,7 +857,7 @@ __device__ __forceinline__ double genf_tile(const GenConst &g, const GenJumps &J
             }
         }
         auto put = [&](int j, double vr, double vi) {
-            const unsigned idx = (unsigned) (((j * nky + kyl) * L + k2) * N + x);
+            const unsigned idx = KIND == GENF_ZAF ? y_index_blocked(j, kyl, nky, L, k2, N, x) : (unsigned) (((j * nky + kyl) * L + k2) * N + x);
             Y[idx] = cplx{vr, vi};
         };
         auto putp = [&](int j, double vr, double vi) { put(j, vr * pr - vi * pi, vr * pi + vi * pr); };
@@ -915,21 +921,36 @@ __device__ __forceinline__ double genf_tile(const GenConst &g, const GenJumps &J
 // genf_tile: their eigenvectors differ between +kx and -kx and their field sums already fill the registers.)
 template <int ZR, int KIND, bool PLAW>
 __device__ __forceinline__ double genf_tile_mirror(const GenConst &g, const GenJumps &J, const StoreLayout &S, const double *T,
-                                                   int zW, int ky0, int kyl, int nky, int L, int residue, int residue2, int bx,
-                                                   int by, const cplx *__restrict__ twN, cplx *__restrict__ Y) {
+                                                   int zW, int ky0, int kyl_arg, int kyl_first, int nky, int L, int residue,
+                                                   int residue2, int bx, int by, const cplx *__restrict__ twN,
+                                                   cplx *__restrict__ Y) {
     static_assert(KIND == GENF_DENS || KIND == GENF_ZA || KIND == GENF_ZAP || KIND == GENF_ZAF, "ZA kinds only");
     constexpr bool ZA2 = KIND == GENF_ZAP || KIND == GENF_ZAF;  // two residues per pass
     constexpr int NACC = KIND == GENF_DENS ? 1 : KIND == GENF_ZA ? 3 : 4;
     double vsum = 0.0;
     const int N = g.N, half = g.half, R = N / L;
-    const int xh  = bx * GEN_BX + threadIdx.x;  // 0 .. N/2
+    // Field store (GENF_ZAF): the folded inputs and the store are laid out in blocks of FIELD_RB = 8 rows x 1 column (one
+    // 128-byte line, zd_device.h), so a workgroup takes 8 rows x 32 columns (kyl_arg = the row GROUP) and a lane's 7
+    // neighbours hold the other rows of its column; elsewhere a workgroup is one row x GEN_BX columns.
+    constexpr bool BLK = KIND == GENF_ZAF;
+    const int rsub = BLK ? (int) (threadIdx.x & (FIELD_RB - 1)) : 0;
+    const int xh   = BLK ? bx * (GEN_BX / FIELD_RB) + (int) (threadIdx.x / FIELD_RB) : bx * GEN_BX + (int) threadIdx.x;  // 0 .. N/2
+    const int kyl  = BLK ? kyl_arg * FIELD_RB + rsub : kyl_arg;
     const int k20 = by * ZR;
     const int ky  = ky0 + kyl * S.ky_stride;  // >= 1
-    if (xh > half) return 0.0;
+    if (xh > half || kyl < kyl_first) return 0.0;  // (the row ky = 0 of a first group belongs to k_gen)
     const bool hasB = xh > 0 && xh < half;  // x = 0 and x = N/2 are their own mirrors
     const int xA = xh, xB = hasB ? N - xh : xh;
-    auto tile_zero = [&](int x) {  // see k_gen: the k_zfft tiles (self and shifted twin) this column belongs to are all zero
+    auto tile_zero = [&](int x) {  // see k_gen: the z-FFT tile(s) this column belongs to are all zero
         bool all_zero = true;
+        if constexpr (BLK) {  // k_zfft_fb tile: zW columns x the 8 rows of the group
+            const int xt0 = x - x % zW;
+            for (int i = 0; i < zW; i++)
+                for (int r = 0; r < FIELD_RB; r++)
+                    all_zero = all_zero && column_is_zero(S, (xt0 + i) > half ? xt0 + i - N : xt0 + i,
+                                                          ky0 + (kyl_arg * FIELD_RB + r) * S.ky_stride);
+            return all_zero;
+        }
         const int xt0 = x - x % zW;
         for (int i = -1; i <= zW; i++) {
             const int xi = (xt0 + i) & (N - 1);
@@ -1053,7 +1074,7 @@ __device__ __forceinline__ double genf_tile_mirror(const GenConst &g, const GenJ
         }
         auto emit = [&](int x, double dkx, const double (&ar)[NACC], const double (&ai)[NACC]) {
             auto put = [&](int j, double vr, double vi) {
-                const unsigned idx = (unsigned) (((j * nky + kyl) * L + k2) * N + x);
+                const unsigned idx = BLK ? y_index_blocked(j, kyl, nky, L, k2, N, x) : (unsigned) (((j * nky + kyl) * L + k2) * N + x);
                 Y[idx] = cplx{vr, vi};
             };
             auto putp = [&](int j, double vr, double vi) { put(j, vr * pr - vi * pi, vr * pi + vi * pr); };
@@ -1105,8 +1126,11 @@ __global__ __launch_bounds__(GEN_BX) void k_genf(GenConst g, GenJumps J, StoreLa
     for (int i = threadIdx.x; i < g.genf_n / 2; i += GEN_BX)
         reinterpret_cast<double2 *>(T)[i] = reinterpret_cast<const double2 *>(g.genf_tab)[i];
     unsigned *slot = reinterpret_cast<unsigned *>(T + g.genf_n);
-    const int gx = ((MIRROR ? g.N / 2 + 1 : g.N) + GEN_BX - 1) / GEN_BX, gy = L / ZR;
-    const unsigned ntiles = (unsigned) (gx * gy * nrows);
+    constexpr bool BLK = MIRROR && KIND == GENF_ZAF;  // 8 rows x 32 columns per workgroup (genf_tile_mirror)
+    constexpr int XW = BLK ? GEN_BX / FIELD_RB : GEN_BX;
+    const int gx = ((MIRROR ? g.N / 2 + 1 : g.N) + XW - 1) / XW, gy = L / ZR;
+    const int gz = BLK ? nky / FIELD_RB : nrows;  // row groups of the whole slab (lanes of rows < kyl0 idle), or rows
+    const unsigned ntiles = (unsigned) (gx * gy * gz);
     double vsum = 0.0;
     for (;;) {
         __syncthreads();  // table image complete / previous tile index consumed
@@ -1116,7 +1140,8 @@ __global__ __launch_bounds__(GEN_BX) void k_genf(GenConst g, GenJumps J, StoreLa
         if (tile >= ntiles) break;
         const int bx = tile % gx, by = (tile / gx) % gy, bz = tile / (gx * gy);
         if constexpr (MIRROR)
-            vsum += genf_tile_mirror<ZR, KIND, PLAW>(g, J, S, T, zW, ky0, kyl0 + bz, nky, L, residue, residue2, bx, by, twN, Y);
+            vsum += genf_tile_mirror<ZR, KIND, PLAW>(g, J, S, T, zW, ky0, BLK ? bz : kyl0 + bz, kyl0, nky, L, residue, residue2, bx, by,
+                                                     twN, Y);
         else
             vsum += genf_tile<ZR, KIND, PLAW>(g, J, S, T, zW, ky0, kyl0 + bz, nky, L, residue, residue2, bx, by, twN, Y);
     }
@@ -1321,29 +1346,31 @@ __global__ __launch_bounds__(W *N / E, MINW) void k_yfft(StoreLayout S, const cp
 // ------------------------------------------------------------------------------------------------
 // Field store (PACK_ZAFIELD, zd_device.h): z stage and y stage.
 //
-// k_zfft_f: length-L FFT of one potential (E or Z of one residue) for a W-wide column tile of a half-space row, stored
-// at (row slot, compact column).  No Hermitian twins are written: the y stage rebuilds them from the symmetry
+// k_zfft_f: length-L FFT of one potential (E or Z of one residue) for NC columns x the FIELD_RB = 8 rows of a row group,
+// read from Y[field][group][k2][x][8 rows] and stored at (row block, compact column, row in block): both sides move whole
+// 128-byte lines (one column x 8 rows).  No Hermitian twins are written: the y stage rebuilds them from the symmetry
 //      E(-ky, -kx) = conj E(ky, kx),   Z(-ky, -kx) = -conj Z(ky, kx)      (E, i Z: z-transforms of real fields)
-//   grid: (N/W, nky, 4)   block: W*L/E
-template <int L, int E, int W>
-__global__ __launch_bounds__(W *L / E) void k_zfft_f(FieldLayout F, StoreLayout S, int ky0, int kyloc0, int nky,
-                                                    const cplx *__restrict__ Y, const cplx *__restrict__ twL,
-                                                    cplx *__restrict__ out) {
-    static_assert(W <= FIELD_CW && FIELD_CW % W == 0, "a z tile must not straddle a compaction boundary");
+//   grid: (N/NC, row groups, 4)   block: NC*8*L/E
+template <int L, int E, int NC>
+__global__ __launch_bounds__(NC *FIELD_RB *L / E) void k_zfft_f(FieldLayout F, StoreLayout S, int ky0, int kyloc0, int nky,
+                                                              const cplx *__restrict__ Y, const cplx *__restrict__ twL,
+                                                              cplx *__restrict__ out) {
+    static_assert(NC <= FIELD_CW && FIELD_CW % NC == 0, "a z tile must not straddle a compaction boundary");
+    constexpr int W = NC * FIELD_RB;  // lines per workgroup: line w = column w / 8, row w % 8
     using PL  = zdfft::Plan<L, E>;
     using LDS = zdfft::ColsInner<L, W>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int T = PL::T;
     const int N = S.N;
     const int w = threadIdx.x % W, t = threadIdx.x / W;
-    const int kyl = blockIdx.y;
-    const int ky  = ky0 + kyl * S.ky_stride;
-    const int x   = blockIdx.x * W + w;
+    const int grp = blockIdx.y;
+    const int r = w & (FIELD_RB - 1), x = blockIdx.x * NC + w / FIELD_RB;
+    const int ky = ky0 + (grp * FIELD_RB + r) * S.ky_stride;
     if (S.prune & 2) {  // tile of identically-zero columns: the generator produced nothing, the y stage will not read it
         if (__syncthreads_and(column_is_zero(S, x > S.half ? x - N : x, ky))) return;
     }
-    const char *src = reinterpret_cast<const char *>(Y + (((long long) blockIdx.z * nky + kyl) * L) * N);
-    const unsigned xb = (unsigned) x * 16u, rb = (unsigned) N * 16u;
+    const char *src = reinterpret_cast<const char *>(Y + ((((long long) blockIdx.z * (nky / FIELD_RB) + grp) * L) * N) * FIELD_RB);
+    const unsigned xb = (unsigned) (x * FIELD_RB + r) * 16u, rb = (unsigned) N * FIELD_RB * 16u;
     double re[E], im[E];
 #pragma unroll
     for (int e = 0; e < E; e++) {
@@ -1352,8 +1379,8 @@ __global__ __launch_bounds__(W *L / E) void k_zfft_f(FieldLayout F, StoreLayout 
         im[e] = v.y;
     }
     zdfft::fft_line<PL, LDS>(re, im, t, w, lds, twL);
-    const FieldRow row = F.rows[kyloc0 + kyl];  // workgroup-uniform
-    const unsigned pos = (unsigned) (x < row.split ? x : x - row.gap);
+    const FieldRow row = F.rows[kyloc0 / FIELD_RB + grp];  // workgroup-uniform: the row block
+    const unsigned pos = ((unsigned) (x < row.split ? x : x - row.gap)) * FIELD_RB + r;
     const int Zq = 1 << F.lZq;
     int t2 = t;
     asm volatile("" : "+v"(t2));  // keep the store-address arithmetic after the FFT (register pressure)
@@ -1422,7 +1449,7 @@ __global__ __launch_bounds__(W *N / E) void k_yfft_f(FieldLayout F, StoreLayout 
         const int y = t + T * e;
         int kyp = y > N / 2 ? N - y : y;
         kyp = kyp < N / 2 ? kyp : N / 2 - 1;  // the Nyquist row is never used: any valid record
-        rows[e] = F.rows[kyp >> F.lG];
+        rows[e] = F.rows[(kyp >> F.lG) / FIELD_RB];  // the row block
     }
     constexpr int BATCH = 4;
 #pragma unroll
@@ -1438,7 +1465,8 @@ __global__ __launch_bounds__(W *N / E) void k_yfft_f(FieldLayout F, StoreLayout 
             skip[j] = (y == N / 2) || ((S.prune & 4) && column_is_zero(S, kx, kyp));
             const int split = rows[e].split, gap = rows[e].gap;
             // skipped rows read element 0 of the chunk image (their own record may describe an empty row at the very end)
-            const unsigned off = skip[j] ? 0u : (unsigned) rows[e].base + (unsigned) (xs < split ? xs : xs - gap);
+            const unsigned off = skip[j] ? 0u : (unsigned) rows[e].base + (unsigned) (xs < split ? xs : xs - gap) * FIELD_RB
+                                                    + (unsigned) ((kyp >> F.lG) & (FIELD_RB - 1));
             const cplx *q = p0 + ((long long) (kyp & gmask) * F.chunk_elems + off);
             u[j] = q[0];
             if (a == 2) v[j] = q[d01];  // workgroup-uniform: the A arrays issue one load per row
@@ -1933,6 +1961,7 @@ __global__ void k_copy16(const uint4 *__restrict__ in, uint4 *__restrict__ out, 
 namespace zd {
 
 int zfft_tile_width(int L);
+int zfft_fields_tile_columns(int L);
 
 template <int NJ, bool PLT, bool PLAW>
 static int launch_gen_t(const GenConst &g, const GenJumps &J, const JobList &jobs, const StoreLayout &S, int ky0, int nky,
@@ -1955,14 +1984,17 @@ static int launch_genf_t(const GenConst &g, const GenJumps &J, const StoreLayout
 #else
     constexpr bool mirror_off = false;
 #endif
-    const bool mirror = za && !mirror_off;
-    const int gx = ((mirror ? N / 2 + 1 : N) + GEN_BX - 1) / GEN_BX;
-    const long long ntiles = (long long) gx * (L / GEN_ZR) * nrows;
+    const bool mirror = za && (!mirror_off || KIND == GENF_ZAF);  // the field store's blocked layout exists in the mirror form only
+    const bool blk = mirror && KIND == GENF_ZAF;
+    const int xw = blk ? GEN_BX / FIELD_RB : GEN_BX;
+    const int gx = ((mirror ? N / 2 + 1 : N) + xw - 1) / xw;
+    const long long ntiles = (long long) gx * (L / GEN_ZR) * (blk ? nky / FIELD_RB : nrows);
     dim3 grid((unsigned) std::min<long long>(ntiles, max_wgs)), block(GEN_BX);
     const size_t shmem = sizeof(double) * (size_t) (g.genf_n + 2);
     if constexpr (za) {
         if (mirror) {
-            hipLaunchKernelGGL((k_genf<GEN_ZR, KIND, PLAW, true>), grid, block, shmem, st, g, J, S, zfft_tile_width(L), ky0, kyl0,
+            hipLaunchKernelGGL((k_genf<GEN_ZR, KIND, PLAW, true>), grid, block, shmem, st, g, J, S,
+                               KIND == GENF_ZAF ? zfft_fields_tile_columns(L) : zfft_tile_width(L), ky0, kyl0,
                                nky, nrows, L, residue, residue2, (const cplx *) twN, (cplx *) Y, tile_ctr);
             ZD_LAUNCH_CHECK();
             return 0;
@@ -2141,38 +2173,47 @@ static int launch_yfft_t(const StoreLayout &S, int nplanes, const void *tw, void
     ZD_LAUNCH_CHECK();
     return 0;
 }
-template <int L, int E, int W>
+template <int L, int E, int NC>
 static int launch_zfft_f_t(const FieldLayout &F, const StoreLayout &S, int ky0, int kyloc0, int nky, const void *Y,
                            const void *twL, void *out, hipStream_t st) {
-    constexpr int threads = W * L / E;
+    constexpr int W = NC * FIELD_RB, threads = W * L / E;
     const size_t shmem = sizeof(double) * zdfft::ColsInner<L, W>::SIZE;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void *) k_zfft_f<L, E, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+        hipFuncSetAttribute((const void *) k_zfft_f<L, E, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
         attr_set = true;
     }
-    dim3 grid(S.N / W, nky, 4), block(threads);
-    hipLaunchKernelGGL((k_zfft_f<L, E, W>), grid, block, shmem, st, F, S, ky0, kyloc0, nky, (const cplx *) Y,
+    if (nky % FIELD_RB || kyloc0 % FIELD_RB) return 2;
+    dim3 grid(S.N / NC, nky / FIELD_RB, 4), block(threads);
+    hipLaunchKernelGGL((k_zfft_f<L, E, NC>), grid, block, shmem, st, F, S, ky0, kyloc0, nky, (const cplx *) Y,
                        (const cplx *) twL, (cplx *) out);
     ZD_LAUNCH_CHECK();
     return 0;
 }
+// columns per z-FFT workgroup of the field store (x 8 rows = lines per workgroup); the generator prunes by it
+int zfft_fields_tile_columns(int L) {
+    switch (L) {
+        case 32: case 64: case 128: return 4;
+        case 256: return 2;
+        case 512: case 1024: case 2048: return 1;  // 8 lines: 256 threads at L = 512 fit beside three generator workgroups
+    }
+    return 0;
+}
 int launch_zfft_fields(int L, const FieldLayout &F, const StoreLayout &S, int ky0, int kyloc0, int nky, const void *Y,
                        const void *twL, void *out, hipStream_t st) {
-#define ZCASE(l, e, w) \
-    case l: return launch_zfft_f_t<l, e, w>(F, S, ky0, kyloc0, nky, Y, twL, out, st);
-    switch (L) {  // the tile widths of launch_zfft / zfft_tile_width (the generator prunes by them)
-        ZCASE(32, 16, 32)
-        ZCASE(64, 16, 32)
-        ZCASE(128, 16, 32)
-        ZCASE(256, 16, 16)
-        ZCASE(512, 16, 8)
-        ZCASE(1024, 16, 8)
-        ZCASE(2048, 16, 8)
-        ZCASE(4096, 16, 4)
+#define ZCASE(l, e, nc) \
+    case l: return launch_zfft_f_t<l, e, nc>(F, S, ky0, kyloc0, nky, Y, twL, out, st);
+    switch (L) {  // = zfft_fields_tile_columns
+        ZCASE(32, 16, 4)
+        ZCASE(64, 16, 4)
+        ZCASE(128, 16, 4)
+        ZCASE(256, 16, 2)
+        ZCASE(512, 16, 1)
+        ZCASE(1024, 16, 1)
+        ZCASE(2048, 16, 1)
     }
 #undef ZCASE
-    fprintf(stderr, "zeldovich_hip: unsupported z-FFT length %d (power of two in [32,4096] required)\n", L);
+    fprintf(stderr, "zeldovich_hip: field store: unsupported z-FFT length %d (power of two in [32,2048] required)\n", L);
     return 2;
 }
 

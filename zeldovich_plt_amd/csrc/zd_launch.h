@@ -18,6 +18,7 @@ int launch_test_modes_table(const GenConst &g, long long n, const int *kxyz, dou
 int launch_zfft(int L, const JobList &jobs, const StoreLayout &S, int ky0, int kyloc0, int nky, int Zq, const void *Y,
                 const void *twL, void *out, hipStream_t st);
 int zfft_tile_width(int L);
+int zfft_fields_tile_columns(int L);
 int launch_zfft_fields(int L, const FieldLayout &F, const StoreLayout &S, int ky0, int kyloc0, int nky, const void *Y,
                        const void *twL, void *out, hipStream_t st);
 int launch_yfft_fields(const FieldLayout &F, const StoreLayout &S, const void *tw, const void *store, int plane0,
