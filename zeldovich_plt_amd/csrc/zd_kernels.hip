@@ -1699,12 +1699,48 @@ __global__ __launch_bounds__(ROWS *NA *N / E, (ROWS * NA * N / E == 512 ? 4 : 1)
     if (ZD_TUNE(S.prune & 64) && re[0] != 123.456) return;                           // bit 6: tuning ablation (no epilogue)
 
     // ---- WriteParticlesSlab (src/output.cpp:86-203) ----
-    // The unpacked fields go through LDS in NH passes over x so that the staging area stays <= 64 KB
-    // (two workgroups per CU): pass h covers x in [h*N/NH, (h+1)*N/NH) = elements e in [h*E/NH, ...).
-    constexpr int NH = XFFT_NH(N, NA, ROWS), NXH = N / NH, EH = E / NH;
     const int z = z_first + z_step * (int) blockIdx.y;
     double ssq = 0.0, mp[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
     const long long plane_rec0 = (long long) blockIdx.y * N * N;
+    if constexpr (NA == 3) {
+        if (ec.pack == PACK_ZAFIELD) {
+            // Field-store ring: (qx + i qy)_r0 | (qx + i qy)_r1 | qz_r0 + i qz_r1.  The threads of lines 0 and 1 already
+            // hold qx, qy of THEIR plane at their columns x = t + T*e; only the shared third array goes through LDS
+            // (16 B per column instead of staging all six fields in NH rounds), and records leave straight from the
+            // registers, consecutive lanes = consecutive records.
+            double2 *cz = reinterpret_cast<double2 *>(lds);  // [row][x] = {qz_r0, qz_r1}
+            if (a == 2) {
+#pragma unroll
+                for (int e = 0; e < E; e++) cz[row * N + t + T * e] = double2{re[e], im[e]};
+            }
+            __syncthreads();
+            if (a < 2) {
+                int t2 = t;
+                asm volatile("" : "+v"(t2));
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    const int xx = t2 + T * e;
+                    const double2 c = cz[row * N + xx];
+                    const double pos[3] = {re[e], im[e], a ? c.y : c.x};
+                    const double vel[3] = {pos[0] * ec.vnorm, pos[1] * ec.vnorm, pos[2] * ec.vnorm};
+#pragma unroll
+                    for (int j = 0; j < 3; j++) {
+                        mp[j] = fmax(mp[j], pos[j]);
+                        mn[j] = fmax(mn[j], -pos[j]);
+                    }
+                    if (records)
+                        emit_record(records, 2 * plane_rec0 + (long long) a * N * N + (long long) y * N + xx, ec, z + a * ec.z_pair, y, xx,
+                                    pos, vel);
+                }
+            }
+            __syncthreads();
+            xfft_reduce<NT, NA>(lds, red, ssq, mp, mn);
+            return;
+        }
+    }
+    // The unpacked fields go through LDS in NH passes over x so that the staging area stays <= 64 KB
+    // (two workgroups per CU): pass h covers x in [h*N/NH, (h+1)*N/NH) = elements e in [h*E/NH, ...).
+    constexpr int NH = XFFT_NH(N, NA, ROWS), NXH = N / NH, EH = E / NH;
     double *fld = lds;  // fld[(row*2*NA + 2a + {0,1})*NXH + x - h*NXH]
     int t2 = t;
     asm volatile("" : "+v"(t2));  // keep the staging-address arithmetic after the FFT (register pressure)
