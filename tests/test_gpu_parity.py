@@ -474,3 +474,62 @@ def test_rccl_communicator_single_rank(zd, ps):
     assert seen == [(0, plan.local_planes)]
     plan.close()
     comm.close()
+
+
+def test_randomised_option_sweep_vs_oracle(zd, oracle, wmap_path):
+    """a seeded sweep over option combinations (size, record format, stream factor, store mode, ZD_k_cutoff, CornerModes,
+    fixed amplitudes, smoothing, PLT / rescale / f_cluster, seed, box) — every run against the oracle"""
+    rng = np.random.default_rng(20261003)
+    fmts = ["RVdoubleZel", "RVZel", "Zeldovich", "ZelSimple"]
+    done = 0
+    for trial in range(28):
+        n = int(rng.choice([64, 64, 128, 128, 256]))
+        plt = bool(rng.integers(0, 2)) and n <= 128
+        kw = dict(seed=int(rng.integers(1, 2 ** 31 - 1)), k_cutoff=float(rng.choice([1.0, 1.0, 1.5, 2.0, 4.0])),
+                  corner_modes=int(rng.integers(0, 2)), f_cluster=float(rng.choice([1.0, 0.93])),
+                  boxsize=float(rng.choice([720.0, 720.0, 90.0, 2000.0])))
+        R = int(rng.choice([1, 2, 4]))
+        if n // R < 32:
+            R = 1
+        kw["stream_factor"] = R
+        kw["store_mode"] = str(rng.choice(["auto", "auto", "reference", "packed"]))
+        if rng.integers(0, 4) == 0:
+            kw["qdensity"] = int(rng.choice([1, 2]))
+        eig = None
+        if plt and kw.get("qdensity", 0) != 2:
+            eig = oracle.synthetic_eigenmodes(int(rng.choice([16, 24, 32, 48, 64])), seed=int(rng.integers(0, 100)))
+            kw.update(qPLT=1, qPLTrescale=int(rng.integers(0, 2)), PLT_target_z=float(rng.choice([3.0, 9.0])))
+        pkw = dict(fix_to_mean=int(rng.integers(0, 2)), Pk_smooth=float(rng.choice([0.0, 0.0, 0.5])))
+        box = kw["boxsize"]
+        ps = zd.PowerSpectrum.from_file(wmap_path, box, **pkw)
+        opk = oracle.pk_from_file(wmap_path, box, **pkw)
+        fmt = str(rng.choice(fmts))
+        print("trial", trial, n, fmt, kw, pkw, "eig" if eig is not None else "")
+        _compare(zd, oracle, ps, opk, n, fmt=fmt, eig=eig, **kw)
+        done += 1
+    assert done == 28
+
+
+def test_two_ranks_equal_one_rank_at_1024(zd, ps):
+    """ZD_NumGPU = 2 (ranks sharing this GPU, several exchange groups) against the single-rank run at PPD = 1024: the same
+    records on sample planes, the same reductions"""
+    n = 1024
+    got = {}
+    for ngpu in (1, 2):
+        planes = {}
+
+        def keep(z, rec):
+            if z in (3, 517, 1022):
+                planes[z] = rec.copy()
+
+        p = zd.make_params(n, icformat="RVZel", ngpu=ngpu, exchange_planes=100 if ngpu > 1 else 0)
+        out = zd.generate_planes(p, ps, keep)
+        got[ngpu] = (planes, out)
+    for z in (3, 517, 1022):
+        a, b = got[1][0][z], got[2][0][z]
+        assert np.array_equal(a["ijk"], b["ijk"])
+        assert np.abs(a["d"] - b["d"]).max() <= 1e-6 * np.abs(a["d"]).max()
+    a, b = got[1][1], got[2][1]
+    assert abs(a["density_variance"] - b["density_variance"]) <= 1e-11 * a["density_variance"]
+    assert np.abs(a["max_disp"] - b["max_disp"]).max() <= 1e-11 * np.abs(a["max_disp"]).max()
+    assert a["planes"] == b["planes"] == n

@@ -287,6 +287,35 @@ def generate(params, ps, eig=None, collect=True):
     return out
 
 
+def generate_planes(params, ps, on_plane, eig=None):
+    """zd_generate with a per-plane consumer: on_plane(z, records[y, x]) sees a VIEW valid only during the call (like the
+    reference's single output buffer); nothing is accumulated here.  Returns the statistics + the number of planes."""
+    L = load_library()
+    n = int(params.ppd)
+    dt = RECORD_DTYPES[_fmt_name(params.icformat)]
+    st = ZdStats()
+    eigp, eig_ppd = (None, 0)
+    if eig is not None:
+        eig = np.ascontiguousarray(eig, dtype=np.float64)
+        eigp, eig_ppd = eig.ctypes.data, eig.shape[0]
+    count = [0]
+
+    def _cb(user, z, nrec, recp, densp):
+        count[0] += 1
+        if recp:
+            buf = (C.c_char * (nrec * dt.itemsize)).from_address(recp)
+            on_plane(int(z), np.frombuffer(buf, dtype=dt).reshape(n, n))
+        return 0
+
+    cb = SLAB_CB(_cb)
+    rc = L.zd_generate(C.byref(params), C.byref(ps.pk), eigp, eig_ppd, cb, None, C.byref(st))
+    if rc:
+        raise RuntimeError("zd_generate failed (rc=%d); see stderr" % rc)
+    out = _stats_dict(st)
+    out["planes"] = count[0]
+    return out
+
+
 class Plan:
     """Staged API: one rank's share of the Z and XY stages on device pointers (see the header)."""
 
