@@ -206,12 +206,16 @@ ZD_HD int out_index(int t, int q, int r) {
 // compile-time offsets (ds_read/ds_write immediates) instead of 16 separately computed addresses.
 //   lin(delta): idx(o + delta, w) == idx(o, w) + step(delta) for every o
 //   unit16:     idx(o + r, w) == idx(o, w) + ustep(r) when o % 16 == 0 and 0 <= r < 16
+// ColsInner pads one group of W doubles per 16 elements (like LineInner's one double): in the exchange after pass 0 the
+// lanes of one column write element 16 j + r for consecutive j, i.e. 16*W doubles apart — a multiple of the 256-byte bank
+// row for every W >= 2, a 16-way bank conflict on every ds_write; with the pad the 16 lanes x W columns spread over all
+// banks (measured: PPD=4096 y pass ... see profiles/r02_tuning_notes.md).
 template <int N, int W>
 struct ColsInner {
-    static constexpr int SIZE = N * W;
-    static ZD_HD int idx(int o, int w) { return o * W + w; }
-    static constexpr bool lin(int) { return true; }
-    static constexpr int step(int delta) { return delta * W; }
+    static constexpr int SIZE = (N + N / 16) * W;
+    static ZD_HD int idx(int o, int w) { return (o + (o >> 4)) * W + w; }
+    static constexpr bool lin(int delta) { return delta % 16 == 0; }
+    static constexpr int step(int delta) { return (delta + delta / 16) * W; }
     static constexpr int ustep(int r) { return r * W; }
 };
 template <int N, int W>
