@@ -182,10 +182,13 @@ def test_packed_za_pairs_sweep(zd, oracle, ps, opk, n, kw, store):
 
 
 @pytest.mark.parametrize("R,ppd_e,resc", [(1, 64, 1), (4, 24, 0), (2, 128, 1)])
-def test_packed_plt_sweep(zd, oracle, ps, opk, R, ppd_e, resc):
-    """PLT without ZD_qdensity: qx + i vx | qy + i qz | vy + i vz, any R; exact-stride and interpolated eigenmodes"""
+@pytest.mark.parametrize("store", ["auto", "fields"])
+def test_packed_plt_sweep(zd, oracle, ps, opk, R, ppd_e, resc, store):
+    """PLT without ZD_qdensity: qx + i vx | qy + i qz | vy + i vz, any R; exact-stride and interpolated eigenmodes.
+    store = fields: the opt-in PLT field store (the six sums X, Y, Z, fX, fY, fZ of the half-space rows; measured slower than
+    the three packed arrays, which stay the default)"""
     eig = oracle.synthetic_eigenmodes(ppd_e)
-    kw = dict(qPLT=1, qPLTrescale=resc, PLT_target_z=3.0, f_cluster=0.95, stream_factor=R)
+    kw = dict(qPLT=1, qPLTrescale=resc, PLT_target_z=3.0, f_cluster=0.95, stream_factor=R, store_mode=store)
     plan = zd.Plan(zd.make_params(128, **kw), ps, eig=eig)
     assert plan.narray == 3 and plan.plane_step == 1 and plan.passes == R
     plan.close()

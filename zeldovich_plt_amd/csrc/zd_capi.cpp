@@ -203,7 +203,10 @@ static int pack_mode(const zd_params *p, int R) {
     }
     // PPD = 8192: three lines of a row no longer fit a workgroup of the x pass; only the field store has an x kernel that
     // takes them in sequence (k_xfft_seq)
-    if (p->qPLT) return p->ppd > 4096 ? zd::PACK_NONE : zd::PACK_PLT3;
+    // PLT: the three packed arrays by default; its field store (six half-space sums) only on request — measured slower
+    // (PPD=2048 PLT+rescale 0.553 -> 0.609 s: every array of the y stage needs two potentials, each fetched twice, and the
+    // 148-VGPR PLT generator leaves no room for the z FFT beside it anyway)
+    if (p->qPLT) return p->ppd > 4096 ? zd::PACK_NONE : (p->store_mode == ZD_STORE_FIELDS ? zd::PACK_PLTFIELD : zd::PACK_PLT3);
     if (R < 2) return zd::PACK_NONE;  // the ZA packings carry two z-residues per pass
     if (p->store_mode == ZD_STORE_PACKED) return p->ppd > 4096 ? zd::PACK_NONE : zd::PACK_ZAPAIR;
     return zd::PACK_ZAFIELD;
@@ -274,7 +277,8 @@ static int64_t field_rows(const zd_params *p, int nranks, std::vector<zd::FieldR
 // bytes of the block store one rank holds per pass (send side; nranks > 1 doubles it with the receive buffer)
 static int64_t store_bytes(const zd_params *p, int R, int nranks) {
     const int64_t N = p->ppd;
-    if (pack_mode(p, R) == zd::PACK_ZAFIELD) return (N / R) * 4 * field_rows(p, nranks, nullptr) * 16;
+    const int pm = pack_mode(p, R);
+    if (zd::pack_is_fields(pm)) return (N / R) * (pm == zd::PACK_PLTFIELD ? 6 : 4) * field_rows(p, nranks, nullptr) * 16;
     return N * (N + store_row_pad(N)) * (N / R) / nranks * 16 * store_arrays(p, R);
 }
 // ring between the y and x stages of the field store: planes of the three PACK_ZAPAIR arrays
@@ -293,7 +297,7 @@ int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes
         if (N / R > 4096) continue;  // z-FFT kernels exist up to length 4096
         int64_t store = store_bytes(p, R, nranks);
         if (nranks > 1) store += std::min<int64_t>(store, (int64_t) 9 << 30);  // + the two-slot exchange ring (zd_multi.cpp), not a second store
-        if (pack_mode(p, R) == zd::PACK_ZAFIELD)
+        if (zd::pack_is_fields(pack_mode(p, R)))
             store += (int64_t) field_ring_planes(N, N / R / nranks) * 3 * N * (N + store_row_pad(N)) * 16;
         if (store <= budget_bytes) return R;
     }
@@ -342,8 +346,8 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
     pl->half    = (int) (N / 2);
     pl->narray  = (phi_mode == 1 || p->qdensity == 2) ? 1 : (p->qPLT ? 4 : 2);  // zeldovich.cpp:871-876
     if (phi_mode == 0 && phik == nullptr && pl->narray >= 2) pl->pack = pack_mode(p, R);
-    if (pl->pack == zd::PACK_ZAFIELD && ((pl->half / nranks) % zd::FIELD_RB || N / R > 2048))  // row blocks of 8, z FFT <= 2048
-        pl->pack = N > 4096 ? zd::PACK_NONE : zd::PACK_ZAPAIR;
+    if (zd::pack_is_fields(pl->pack) && ((pl->half / nranks) % zd::FIELD_RB || N / R > 2048))  // row blocks of 8, z FFT <= 2048
+        pl->pack = N > 4096 ? zd::PACK_NONE : (pl->pack == zd::PACK_PLTFIELD ? zd::PACK_PLT3 : zd::PACK_ZAPAIR);
     if (pl->pack != zd::PACK_NONE) pl->narray = 3;
     pl->pstep   = (pl->pack == zd::PACK_ZAPAIR || pl->pack == zd::PACK_ZAFIELD) ? 2 : 1;
     pl->npass   = R / pl->pstep;
@@ -531,7 +535,14 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
             jl.res[jl.n]  = res;
             jl.n++;
         };
-        if (pl->pack == zd::PACK_ZAFIELD) {  // the potentials E, Z of the two residues (k_zfft_f: job index = field index)
+        if (pl->pack == zd::PACK_PLTFIELD) {  // the six sums (k_zfft_f: job index = field index)
+            add(zd::JOB_PX, 0, 0, 0);
+            add(zd::JOB_PY, 1, 0, 0);
+            add(zd::JOB_PZ, 2, 0, 0);
+            add(zd::JOB_PFX, 3, 0, 0);
+            add(zd::JOB_PFY, 4, 0, 0);
+            add(zd::JOB_PFZ, 5, 0, 0);
+        } else if (pl->pack == zd::PACK_ZAFIELD) {  // the potentials E, Z of the two residues (k_zfft_f: job index = field index)
             add(zd::JOB_E, 0, 0, 0);
             add(zd::JOB_Z, 1, 0, 0);
             add(zd::JOB_E, 2, 0, 1);
@@ -617,10 +628,10 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
     pl->ec.qPLT     = p->qPLT;
     pl->ec.qdensity = p->qdensity;
     pl->ec.vnorm    = p->qPLT ? 1.0 : (sqrt(1. + 24 * p->f_cluster) - 1) * .25;  // output.cpp:78-82
-    pl->ec.pack     = pl->pack;
+    pl->ec.pack     = pl->pack == zd::PACK_PLTFIELD ? zd::PACK_PLT3 : pl->pack;  // the y stage builds the PLT3 arrays in the ring
     pl->ec.z_pair   = R / 2;
     pl->store_bytes_ = (int64_t) S.chunk_rows * S.pitch * nranks * 16;
-    if (pl->pack == zd::PACK_ZAFIELD) {
+    if (zd::pack_is_fields(pl->pack)) {
         std::vector<zd::FieldRow> rows;
         const int64_t fe = field_rows(p, nranks, &rows);
         PLCHECK(hipMalloc((void **) &pl->d_fieldrows, sizeof(zd::FieldRow) * rows.size()));
@@ -629,7 +640,8 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         pl->F.lZq         = 0;
         while ((1 << pl->F.lZq) < pl->Zq) pl->F.lZq++;
         pl->F.field_elems = fe;
-        pl->F.chunk_elems = (int64_t) pl->Zq * 4 * fe;
+        pl->F.nfield      = pl->pack == zd::PACK_PLTFIELD ? 6 : 4;
+        pl->F.chunk_elems = (int64_t) pl->Zq * pl->F.nfield * fe;
         pl->F.rows        = pl->d_fieldrows;
         pl->store_bytes_  = pl->F.chunk_elems * nranks * 16;
         // ring: `ring_planes` store planes of the three arrays, laid out as a single-rank block store (one_block)
@@ -663,7 +675,7 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         if (const char *env = tune_env("ZD_SLAB_MB")) slab_b = (int64_t) atoll(env) << 20;
         int rows = (int) std::max<int64_t>(1, slab_b / row_b);
         rows     = std::min(rows, pl->Hq);
-        if (pl->pack == zd::PACK_ZAFIELD) {  // whole row blocks
+        if (zd::pack_is_fields(pl->pack)) {  // whole row blocks
             rows = std::max(zd::FIELD_RB, rows / zd::FIELD_RB * zd::FIELD_RB);
             while (pl->Hq % rows) rows -= zd::FIELD_RB;
         }
@@ -748,7 +760,7 @@ void zd_plan_destroy(zd_plan *pl) {
 
 int32_t zd_plan_narray(const zd_plan *pl) { return pl->narray; }
 int32_t zd_plan_store_mode(const zd_plan *pl) {
-    return pl->pack == zd::PACK_NONE ? ZD_STORE_REFERENCE : pl->pack == zd::PACK_ZAFIELD ? ZD_STORE_FIELDS : ZD_STORE_PACKED;
+    return pl->pack == zd::PACK_NONE ? ZD_STORE_REFERENCE : zd::pack_is_fields(pl->pack) ? ZD_STORE_FIELDS : ZD_STORE_PACKED;
 }
 int32_t zd_plan_stream_factor(const zd_plan *pl) { return pl->R; }
 int32_t zd_plan_record_size(const zd_plan *pl) { return pl->ec.recsize; }
@@ -765,7 +777,7 @@ int64_t zd_plan_plane_z(const zd_plan *pl, int pass, int64_t local_plane) {
 // z FFT of one slab of generated rows into the block store (reference / packed arrays with Hermitian twins, or the
 // potentials of the field store)
 static int launch_zstage_fft(zd_plan *pl, int ky0, int kyloc0, int nky, const void *Y, void *d_send, hipStream_t st) {
-    if (pl->pack == zd::PACK_ZAFIELD) return zd::launch_zfft_fields(pl->L, pl->F, pl->S, ky0, kyloc0, nky, Y, pl->d_twL, d_send, st);
+    if (zd::pack_is_fields(pl->pack)) return zd::launch_zfft_fields(pl->L, pl->F, pl->S, ky0, kyloc0, nky, Y, pl->d_twL, d_send, st);
     return zd::launch_zfft(pl->L, pl->jobs, pl->S, ky0, kyloc0, nky, pl->Zq, Y, pl->d_twL, d_send, st);
 }
 
@@ -864,14 +876,14 @@ static zd::StoreLayout layout_for_chunks(const zd_plan *pl, int chunk_planes) {
 }
 static zd::FieldLayout fields_for_chunks(const zd_plan *pl, int chunk_planes) {
     zd::FieldLayout F = pl->F;
-    F.chunk_elems     = (long long) chunk_planes * 4 * F.field_elems;
+    F.chunk_elems     = (long long) chunk_planes * F.nfield * F.field_elems;
     return F;
 }
 
 // y stage on a store (or ring slot) whose chunks hold `chunk_planes` planes, for its planes [0, nplanes)
 int zd_plan_stage_y_group(zd_plan *pl, void *d_recv, int chunk_planes, int nplanes, void *hip_stream) {
     hipStream_t st = (hipStream_t) hip_stream;
-    if (pl->pack == zd::PACK_ZAFIELD) return 0;  // field store: the y transform runs plane group by plane group in stage_x
+    if (zd::pack_is_fields(pl->pack)) return 0;  // field stores: the y transform runs plane group by plane group in stage_x
     tick(pl, ZD_K_YFFT, st, true);
     if (zd::launch_yfft(layout_for_chunks(pl, chunk_planes), nplanes, pl->d_twN, d_recv, st)) return 1;
     tick(pl, ZD_K_YFFT, st, false);
@@ -892,7 +904,7 @@ int zd_plan_stage_x_group(zd_plan *pl, int residue, const void *d_recv, int chun
         return 1;
     }
     if (d_density && pl->pack != zd::PACK_NONE) return 1;  // packed stores carry no density field
-    if (pl->pack == zd::PACK_ZAFIELD) {
+    if (zd::pack_is_fields(pl->pack)) {
         // y stage (potentials -> the three displacement arrays of a group of store planes, into the ring) + x stage
         const zd::FieldLayout F = fields_for_chunks(pl, chunk_planes);
         const int p0 = (int) (plane0 / ps), np = (int) (nplanes / ps);

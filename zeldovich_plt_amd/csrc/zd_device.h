@@ -158,7 +158,10 @@ enum JobKind {
     JOB_FX      = 10, // i sx D of one residue; the two residues of a pass are combined into qx_r0 + i qx_r1
     // field store (PACK_ZAFIELD): the two potentials of the ZA displacement, per z-residue of the pass
     JOB_E       = 11, // (fundamental / k^2) D          q_x = d/dx, q_y = d/dy of its transform
-    JOB_Z       = 12  // kz (fundamental / k^2) D       q_z = i x its transform
+    JOB_Z       = 12, // kz (fundamental / k^2) D       q_z = i x its transform
+    // PLT field store (PACK_PLTFIELD): the six coefficient sums of the displacement / velocity components
+    JOB_PX = 13, JOB_PY = 14, JOB_PZ = 15,      // s_x D, s_y D, s_z D          (q_j = i x its transform)
+    JOB_PFX = 16, JOB_PFY = 17, JOB_PFZ = 18    // f s_x D, f s_y D, f s_z D    (v_j = i x its transform)
 };
 // What the store holds.  The reference always transforms the density (Re of its array 0) although only
 // ZD_qdensity writes it out and only its sum of squares is reported; without ZD_qdensity the density is not
@@ -175,10 +178,16 @@ enum JobKind {
 //                PPD = 4096 run in 4 passes instead of 8 on one 288 GB GPU and halves the all-to-all volume between
 //                GPUs.  The y pass builds, plane by plane, the three arrays (qx + i qy)_r0 | (qx + i qy)_r1 | qz_r0 + i qz_r1
 //                (each potential feeds exactly one of them) into a small ring that the x pass consumes.
-enum { PACK_NONE = 0, PACK_ZAPAIR = 1, PACK_PLT3 = 2, PACK_ZAFIELD = 3 };
+//   PACK_PLTFIELD the same for PLT: its six real fields are independent, so the store keeps the six sums X, Y, Z, fX, fY, fZ
+//                (s_j D and f s_j D summed over kz; each anti-Hermitian in (kx, ky)) for the half-space rows — the size of
+//                PACK_PLT3 minus the zero columns, but no mirrored twin stores in the z stage, 8-line z-FFT workgroups that
+//                fit beside the generator, and whole-line reads in the y stage, which builds qx + i vx = i X - fX,
+//                qy + i qz = i Y - Z, vy + i vz = i fY - fZ.
+enum { PACK_NONE = 0, PACK_ZAPAIR = 1, PACK_PLT3 = 2, PACK_ZAFIELD = 3, PACK_PLTFIELD = 4 };
+ZD_HD bool pack_is_fields(int pack) { return pack == PACK_ZAFIELD || pack == PACK_PLTFIELD; }
 
 // Field store addressing.  chunk c = the rank that generated the rows (ky = c + G*slot), inside a chunk
-// [plane zl][field f < 4][row block][compact x][row in block].  A block keeps the columns x < split and x >= split + gap
+// [plane zl][field f < nfield][row block][compact x][row in block].  A block keeps the columns x < split and x >= split + gap
 // (kx in (-w, w) rounded out to FIELD_CW columns; the same table for every chunk, taken from the longest row of the
 // block, ky = G * 8 * block), at position x (x < split) or x - gap.
 constexpr int FIELD_CW = 32;  // compaction granularity in columns: a multiple of every z / y tile width
@@ -194,7 +203,8 @@ struct FieldRow {  // one record per BLOCK of FIELD_RB rows, 8 bytes: one load p
 };
 struct FieldLayout {
     int lG, lZq;                 // log2(ranks), log2(planes per chunk)
-    long long chunk_elems;       // elements per chunk = Zq * 4 * field_elems
+    int nfield;                  // 4 (ZA: E0, Z0, E1, Z1) or 6 (PLT: X, Y, Z, fX, fY, fZ)
+    long long chunk_elems;       // elements per chunk = Zq * nfield * field_elems
     long long field_elems;       // elements per (plane, field) image = sum of the row lengths
     const FieldRow *rows;        // [Hq / FIELD_RB] device table
 };

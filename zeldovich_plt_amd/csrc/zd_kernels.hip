@@ -420,6 +420,12 @@ __global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, JobList 
                     case JOB_FX: cr = 0.0; ci = sx; break;
                     case JOB_E: cr = se; ci = 0.0; break;
                     case JOB_Z: cr = sz; ci = 0.0; break;
+                    case JOB_PX: cr = sx; ci = 0.0; break;
+                    case JOB_PY: cr = sy; ci = 0.0; break;
+                    case JOB_PZ: cr = sz; ci = 0.0; break;
+                    case JOB_PFX: cr = f * sx; ci = 0.0; break;
+                    case JOB_PFY: cr = f * sy; ci = 0.0; break;
+                    case JOB_PFZ: cr = f * sz; ci = 0.0; break;
                     default: cr = 1.0; ci = 0.0; break;
                 }
                 const double ur = jobs.res[j] ? d2r : dr, ui = jobs.res[j] ? d2i : di;
@@ -455,7 +461,7 @@ __global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, JobList 
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
             // a slab holds < 2^31 elements (1.5 GB / 16 B): 32-bit index arithmetic
-            const unsigned idx = jobs.pack == PACK_ZAFIELD ? y_index_blocked(j, kyl, nky, L, k2, N, x) : (unsigned) (((j * nky + kyl) * L + k2) * N + x);
+            const unsigned idx = pack_is_fields(jobs.pack) ? y_index_blocked(j, kyl, nky, L, k2, N, x) : (unsigned) (((j * nky + kyl) * L + k2) * N + x);
             Y[idx] = cplx{outr[j], outi[j]};
         }
     }
@@ -644,7 +650,8 @@ __device__ __forceinline__ double genf_power(const GenConst &g, const double *T,
 //     4 ZA jobs; PLT keeps 7 because its eigenvectors differ mode by mode).
 // grid: (ceil(N/GEN_BX), L/ZR, nrows)  block: GEN_BX          row kyl = kyl0 + blockIdx.z of the slab
 enum { GENF_DENS = 0, GENF_ZA = 1, GENF_PLT = 2, GENF_ZAP = 3 /* PACK_ZAPAIR */, GENF_PLTN = 4 /* PACK_PLT3 */,
-       GENF_ZAF = 5 /* PACK_ZAFIELD: the sums of GENF_ZAP written out as they are (E, Z of both residues) */ };
+       GENF_ZAF = 5 /* PACK_ZAFIELD: the sums of GENF_ZAP written out as they are (E, Z of both residues) */,
+       GENF_PLTF = 6 /* PACK_PLTFIELD: the sums of GENF_PLTN written out as they are */ };
 
 __device__ __forceinline__ void cmac(double &ar, double &ai, double c, double dr, double di) {
     ar = fma(c, dr, ar);
@@ -716,26 +723,37 @@ __device__ __forceinline__ void eigenmode_fast(const GenConst &g, int kx, int ky
 
 template <int ZR, int KIND, bool PLAW>
 __device__ __forceinline__ double genf_tile(const GenConst &g, const GenJumps &J, const StoreLayout &S, const double *T, int zW,
-                                            int ky0, int kyl, int nky, int L, int residue, int residue2, int bx, int by,
-                                            const cplx *__restrict__ twN, cplx *__restrict__ Y) {
+                                            int ky0, int kyl_arg, int kyl_first, int nky, int L, int residue, int residue2, int bx,
+                                            int by, const cplx *__restrict__ twN, cplx *__restrict__ Y) {
     // field sums per k2:  DENS {S0}  ZA {S0, SE, SZ}  PLT {S0, X, Y, Z, fX, fY, fZ}  ZAP {SE, SZ}(r0), {SE, SZ}(r1)
     //                     PLTN {X, Y, Z, fX, fY, fZ}
     constexpr bool ZA2 = KIND == GENF_ZAP || KIND == GENF_ZAF;  // two residues per pass
     constexpr int NACC = KIND == GENF_DENS ? 1 : KIND == GENF_ZA ? 3 : KIND == GENF_PLT ? 7 : ZA2 ? 4 : 6;
-    constexpr bool IS_PLT = KIND == GENF_PLT || KIND == GENF_PLTN;
+    constexpr bool IS_PLT = KIND == GENF_PLT || KIND == GENF_PLTN || KIND == GENF_PLTF;
+    // field stores: a workgroup takes the 8 rows of a row GROUP (kyl_arg) x 32 columns, see genf_tile_mirror
+    constexpr bool BLK = KIND == GENF_PLTF || KIND == GENF_ZAF;
     double vsum = 0.0;  // sum |D|^2 of this thread's modes (packed stores: density_variance by Parseval)
     const int N = g.N, half = g.half, R = N / L;
-    const int x   = bx * GEN_BX + threadIdx.x;
+    const int rsub = BLK ? (int) (threadIdx.x & (FIELD_RB - 1)) : 0;
+    const int x    = BLK ? bx * (GEN_BX / FIELD_RB) + (int) (threadIdx.x / FIELD_RB) : bx * GEN_BX + (int) threadIdx.x;
+    const int kyl  = BLK ? kyl_arg * FIELD_RB + rsub : kyl_arg;
     const int k20 = by * ZR;
     const int ky  = ky0 + kyl * S.ky_stride;  // >= 1
-    if (x >= N) return 0.0;
+    if (x >= N || kyl < kyl_first) return 0.0;
     const int kx = x > half ? x - N : x;
-    if (S.prune & 1) {  // see k_gen: skip columns whose k_zfft tiles (self and shifted twin) are all zero
+    if (S.prune & 1) {  // see k_gen: skip columns whose z-FFT tiles are all zero
         bool all_zero = true;
         const int xt0 = x - x % zW;
-        for (int i = -1; i <= zW; i++) {
-            const int xi = (xt0 + i) & (N - 1);
-            all_zero = all_zero && column_is_zero(S, xi > half ? xi - N : xi, ky);
+        if constexpr (BLK) {  // k_zfft_f tile: zW columns x the 8 rows of the group
+            for (int i = 0; i < zW; i++)
+                for (int r = 0; r < FIELD_RB; r++)
+                    all_zero = all_zero && column_is_zero(S, (xt0 + i) > half ? xt0 + i - N : xt0 + i,
+                                                          ky0 + (kyl_arg * FIELD_RB + r) * S.ky_stride);
+        } else {
+            for (int i = -1; i <= zW; i++) {
+                const int xi = (xt0 + i) & (N - 1);
+                all_zero = all_zero && column_is_zero(S, xi > half ? xi - N : xi, ky);
+            }
         }
         if (all_zero) return 0.0;
     }
@@ -827,7 +845,7 @@ __device__ __forceinline__ double genf_tile(const GenConst &g, const GenJumps &J
                 acci[2] += e2i;
                 cmac(accr[3], acci[3], dkz, e2r, e2i);
             } else if constexpr (IS_PLT) {
-                constexpr int B = KIND == GENF_PLT ? 1 : 0;  // index of the X sum
+                constexpr int B = KIND == GENF_PLT ? 1 : 0;  // index of the X sum (PLTN, PLTF: the six sums only)
                 double e[4];
                 eigenmode_fast(g, kx, ky, kz, exy, eig_axis(g, eig_index_z(g, kz)), e);
                 const double f = (sqrt_pos(1. + 24 * e[3] * g.f_cluster) - 1) * .25;
@@ -857,7 +875,7 @@ __device__ __forceinline__ double genf_tile(const GenConst &g, const GenJumps &J
             }
         }
         auto put = [&](int j, double vr, double vi) {
-            const unsigned idx = KIND == GENF_ZAF ? y_index_blocked(j, kyl, nky, L, k2, N, x) : (unsigned) (((j * nky + kyl) * L + k2) * N + x);
+            const unsigned idx = BLK ? y_index_blocked(j, kyl, nky, L, k2, N, x) : (unsigned) (((j * nky + kyl) * L + k2) * N + x);
             Y[idx] = cplx{vr, vi};
         };
         auto putp = [&](int j, double vr, double vi) { put(j, vr * pr - vi * pi, vr * pi + vi * pr); };
@@ -883,6 +901,9 @@ __device__ __forceinline__ double genf_tile(const GenConst &g, const GenJumps &J
             const double f1r = g1r * qr - g1i * qi, f1i = g1r * qi + g1i * qr;  // F_x(r1) W_N^{k2 r1}
             put(4, f0r - f1i, f0i + f1r);  // X_self       = F_x(r0) + i F_x(r1)
             put(5, f0r + f1i, f0i - f1r);  // X_twin input = F_x(r0) - i F_x(r1)
+        } else if constexpr (KIND == GENF_PLTF) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) putp(j, accr[j], acci[j]);  // X, Y, Z, fX, fY, fZ
         } else if constexpr (KIND == GENF_PLTN) {
             putp(0, -acci[0] - accr[3], accr[0] - acci[3]);   // JOB_XV_SELF (i - f) s_x D = i X - fX
             putp(1, -acci[0] + accr[3], accr[0] + acci[3]);   // JOB_XV_TWIN (i + f) s_x D = i X + fX
@@ -1126,7 +1147,7 @@ __global__ __launch_bounds__(GEN_BX) void k_genf(GenConst g, GenJumps J, StoreLa
     for (int i = threadIdx.x; i < g.genf_n / 2; i += GEN_BX)
         reinterpret_cast<double2 *>(T)[i] = reinterpret_cast<const double2 *>(g.genf_tab)[i];
     unsigned *slot = reinterpret_cast<unsigned *>(T + g.genf_n);
-    constexpr bool BLK = MIRROR && KIND == GENF_ZAF;  // 8 rows x 32 columns per workgroup (genf_tile_mirror)
+    constexpr bool BLK = (MIRROR && KIND == GENF_ZAF) || KIND == GENF_PLTF;  // 8 rows x 32 columns per workgroup
     constexpr int XW = BLK ? GEN_BX / FIELD_RB : GEN_BX;
     const int gx = ((MIRROR ? g.N / 2 + 1 : g.N) + XW - 1) / XW, gy = L / ZR;
     const int gz = BLK ? nky / FIELD_RB : nrows;  // row groups of the whole slab (lanes of rows < kyl0 idle), or rows
@@ -1143,7 +1164,7 @@ __global__ __launch_bounds__(GEN_BX) void k_genf(GenConst g, GenJumps J, StoreLa
             vsum += genf_tile_mirror<ZR, KIND, PLAW>(g, J, S, T, zW, ky0, BLK ? bz : kyl0 + bz, kyl0, nky, L, residue, residue2, bx, by,
                                                      twN, Y);
         else
-            vsum += genf_tile<ZR, KIND, PLAW>(g, J, S, T, zW, ky0, kyl0 + bz, nky, L, residue, residue2, bx, by, twN, Y);
+            vsum += genf_tile<ZR, KIND, PLAW>(g, J, S, T, zW, ky0, BLK ? bz : kyl0 + bz, kyl0, nky, L, residue, residue2, bx, by, twN, Y);
     }
     if (g.accum_var) {  // every lane is back here: wave sum, one atomic per wave; rows ky >= 1 stand for their twins too
 #pragma unroll
@@ -1388,7 +1409,7 @@ __global__ __launch_bounds__(NC *FIELD_RB *L / E) void k_zfft_f(FieldLayout F, S
     for (int e = 0; e < E; e++) {
         const int z2  = t2 + T * e;
         const int dst = z2 >> F.lZq, zl = z2 & (Zq - 1);
-        out[(long long) dst * F.chunk_elems + (long long) (zl * 4 + (int) blockIdx.z) * F.field_elems + (unsigned) row.base + pos]
+        out[(long long) dst * F.chunk_elems + (long long) (zl * F.nfield + (int) blockIdx.z) * F.field_elems + (unsigned) row.base + pos]
             = cplx{re[e], im[e]};
     }
 }
@@ -1433,10 +1454,13 @@ __global__ __launch_bounds__(W *N / E) void k_yfft_f(FieldLayout F, StoreLayout 
     const int x = tile * W + w, xm = (N - x) & (N - 1);
     const int zl = plane0 + blockIdx.z;
     const int kx = x > N / 2 ? x - N : x;
-    // potentials this array is made of: E_a alone, or (Z_0, Z_1)
-    const int f0 = a == 2 ? 1 : 2 * a;
-    const cplx *p0 = store + (long long) (zl * 4 + f0) * F.field_elems;
-    const long long d01 = a == 2 ? 2 * F.field_elems : 0;  // Z_1 sits two fields after Z_0
+    // potentials this array is made of.  ZA: E_a alone (a < 2), or (Z_0, Z_1).  PLT: the pairs (X, fX), (Y, Z), (fY, fZ) of
+    // the fields X, Y, Z, fX, fY, fZ — every array is i P - Q like the ZA one of two
+    const bool plt = F.nfield == 6, two = plt || a == 2;
+    const int f0 = plt ? (a == 0 ? 0 : (a == 1 ? 1 : 4)) : (a == 2 ? 1 : 2 * a);
+    const int f1 = plt ? (a == 0 ? 3 : (a == 1 ? 2 : 5)) : 3;
+    const cplx *p0 = store + (long long) (zl * F.nfield + f0) * F.field_elems;
+    const long long d01 = two ? (long long) (f1 - f0) * F.field_elems : 0;
     const int gmask = (1 << F.lG) - 1;
     double re[E], im[E];
     // Branch-free in three steps so that the loads of many rows are in flight together (as `if (!skip) { table load,
@@ -1469,7 +1493,7 @@ __global__ __launch_bounds__(W *N / E) void k_yfft_f(FieldLayout F, StoreLayout 
                                                     + (unsigned) ((kyp >> F.lG) & (FIELD_RB - 1));
             const cplx *q = p0 + ((long long) (kyp & gmask) * F.chunk_elems + off);
             u[j] = q[0];
-            if (a == 2) v[j] = q[d01];  // workgroup-uniform: the A arrays issue one load per row
+            if (two) v[j] = q[d01];  // workgroup-uniform: the ZA arrays of one potential issue one load per row
         }
 #pragma unroll
         for (int j = 0; j < BATCH; j++) {
@@ -1477,7 +1501,7 @@ __global__ __launch_bounds__(W *N / E) void k_yfft_f(FieldLayout F, StoreLayout 
             const bool mir = y > N / 2;
             const double s = mir ? -1.0 : 1.0;
             double vr, vi;
-            if (a == 2) {  // u = Z_0, v = Z_1:  i u - v,  mirrored -i conj u + conj v
+            if (two) {  // (u, v) = (Z_0, Z_1) or a PLT pair (P, Q):  i u - v,  mirrored -i conj u + conj v (anti-Hermitian sums)
                 vr = -u[j].y - s * v[j].x;
                 vi = s * u[j].x - v[j].y;
             } else {  // u = E_r:  (i kx - ky) u,  mirrored (i kx + (N - y)) conj u
@@ -2021,7 +2045,7 @@ static int launch_genf_t(const GenConst &g, const GenJumps &J, const StoreLayout
     constexpr bool mirror_off = false;
 #endif
     const bool mirror = za && (!mirror_off || KIND == GENF_ZAF);  // the field store's blocked layout exists in the mirror form only
-    const bool blk = mirror && KIND == GENF_ZAF;
+    const bool blk = (mirror && KIND == GENF_ZAF) || KIND == GENF_PLTF;
     const int xw = blk ? GEN_BX / FIELD_RB : GEN_BX;
     const int gx = ((mirror ? N / 2 + 1 : N) + xw - 1) / xw;
     const long long ntiles = (long long) gx * (L / GEN_ZR) * (blk ? nky / FIELD_RB : nrows);
@@ -2036,7 +2060,8 @@ static int launch_genf_t(const GenConst &g, const GenJumps &J, const StoreLayout
             return 0;
         }
     }
-    hipLaunchKernelGGL((k_genf<GEN_ZR, KIND, PLAW, false>), grid, block, shmem, st, g, J, S, zfft_tile_width(L), ky0, kyl0, nky,
+    hipLaunchKernelGGL((k_genf<GEN_ZR, KIND, PLAW, false>), grid, block, shmem, st, g, J, S,
+                       KIND == GENF_PLTF ? zfft_fields_tile_columns(L) : zfft_tile_width(L), ky0, kyl0, nky,
                        nrows, L, residue, residue2, (const cplx *) twN, (cplx *) Y, tile_ctr);
     ZD_LAUNCH_CHECK();
     return 0;
@@ -2055,6 +2080,7 @@ static int genf_kind(const JobList &jobs, bool plt) {
     static const int zap[6]  = {JOB_B_SELF, JOB_B_TWIN, JOB_B_SELF, JOB_B_TWIN, JOB_FX, JOB_FX};
     static const int pln[6]  = {JOB_XV_SELF, JOB_XV_TWIN, JOB_B_SELF, JOB_B_TWIN, JOB_D_SELF, JOB_D_TWIN};
     static const int zaf[4]  = {JOB_E, JOB_Z, JOB_E, JOB_Z};
+    static const int plf[6]  = {JOB_PX, JOB_PY, JOB_PZ, JOB_PFX, JOB_PFY, JOB_PFZ};
     auto same = [&](const int *ref, int n) {
         if (jobs.n != n) return false;
         for (int j = 0; j < n; j++)
@@ -2064,6 +2090,7 @@ static int genf_kind(const JobList &jobs, bool plt) {
     if (jobs.n == 1 && jobs.kind[0] == JOB_DENS) return GENF_DENS;
     if (jobs.pack == PACK_ZAPAIR) return (!plt && same(zap, 6)) ? GENF_ZAP : -1;
     if (jobs.pack == PACK_ZAFIELD) return (!plt && same(zaf, 4)) ? GENF_ZAF : -1;
+    if (jobs.pack == PACK_PLTFIELD) return (plt && same(plf, 6)) ? GENF_PLTF : -1;
     if (jobs.pack == PACK_PLT3) return (plt && same(pln, 6)) ? GENF_PLTN : -1;
     if (!plt && same(std7, 4)) return GENF_ZA;
     if (plt && same(std7, 7)) return GENF_PLT;
@@ -2095,6 +2122,7 @@ int launch_gen(const GenConst &g, const GenJumps &J, const JobList &jobs, const 
             FCASE(GENF_ZAP)
             FCASE(GENF_PLTN)
             FCASE(GENF_ZAF)
+            FCASE(GENF_PLTF)
 #undef FCASE
             if (rc) return rc;
         }
@@ -2220,7 +2248,7 @@ static int launch_zfft_f_t(const FieldLayout &F, const StoreLayout &S, int ky0, 
         attr_set = true;
     }
     if (nky % FIELD_RB || kyloc0 % FIELD_RB) return 2;
-    dim3 grid(S.N / NC, nky / FIELD_RB, 4), block(threads);
+    dim3 grid(S.N / NC, nky / FIELD_RB, F.nfield), block(threads);
     hipLaunchKernelGGL((k_zfft_f<L, E, NC>), grid, block, shmem, st, F, S, ky0, kyloc0, nky, (const cplx *) Y,
                        (const cplx *) twL, (cplx *) out);
     ZD_LAUNCH_CHECK();

@@ -215,7 +215,7 @@ int64_t zd_plan_ring_bytes(const zd_plan *pl, int32_t *group_planes) {
     const int64_t per_plane = chunk_plane_bytes(pl) * pl->nranks;  // one store plane from every source rank
     int gp = (int) std::max<int64_t>(1, std::min<int64_t>(pl->Zq, ((int64_t) 4 << 30) / per_plane));  // ~4 GB per slot
     // field store: whole y->x ring loads per group
-    if (pl->pack == zd::PACK_ZAFIELD && gp > pl->ring_planes) gp = gp / pl->ring_planes * pl->ring_planes;
+    if (zd::pack_is_fields(pl->pack) && gp > pl->ring_planes) gp = gp / pl->ring_planes * pl->ring_planes;
     if (pl->p.exchange_planes > 0) gp = std::min<int>(pl->Zq, pl->p.exchange_planes);
     if (group_planes) *group_planes = gp;
     return 2 * per_plane * gp;
