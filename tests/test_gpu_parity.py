@@ -536,3 +536,18 @@ def test_two_ranks_equal_one_rank_at_1024(zd, ps):
     assert abs(a["density_variance"] - b["density_variance"]) <= 1e-11 * a["density_variance"]
     assert np.abs(a["max_disp"] - b["max_disp"]).max() <= 1e-11 * np.abs(a["max_disp"]).max()
     assert a["planes"] == b["planes"] == n
+
+
+@pytest.mark.parametrize("n", [24, 72, 216, 48, 144, 432, 96, 288, 864, 192, 576, 1728, 384, 1152, 3456, 768, 2304, 6912,
+                               1536, 4608, 3072])
+@pytest.mark.parametrize("kind", [0, 1])
+def test_fft_lines_composite_lengths(zd, n, kind):
+    """lengths 2^a 3^b (b <= 3): Q = 3^b decimated sub-lines through the power-of-two register engine + Q-point outer
+    transforms (csrc/zd_fft_q.h), both LDS layouts, vs numpy"""
+    rng = np.random.default_rng(n + kind)
+    lines = 8
+    x = rng.standard_normal((lines, n)) + 1j * rng.standard_normal((lines, n))
+    got = zd.test_fft(x, kind)
+    ref = np.fft.ifft(x, axis=1) * n
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    assert err < 2e-14, err

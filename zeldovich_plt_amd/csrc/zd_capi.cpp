@@ -1299,7 +1299,38 @@ int zd_test_modes_table(const zd_params *p, const zd_pk *pk, int64_t n, const in
     return rc;
 }
 
+static int test_fft_composite(int32_t n, int64_t lines, int32_t axis_kind, const double *in, double *out) {
+    int P = 0, Q = 0;
+    const int W = zd::test_fftq_tile_width(n);
+    if (!zd::np2_split(n, &P, &Q) || W == 0 || lines % W) {
+        fprintf(stderr, "zd_test_fft: n=%d is not 2^a 3^b (b <= 3), or lines %% %d != 0\n", n, W);
+        return 1;
+    }
+    std::vector<cplx> twP = make_twiddles(P), twN = make_twiddles(n), twQ = make_twiddles(Q);
+    cplx *d_tw = nullptr, *d_in = nullptr, *d_out = nullptr;
+    const size_t nb = sizeof(cplx) * (size_t) n * lines;
+    int rc = 1;
+    do {
+        if (hipMalloc((void **) &d_tw, sizeof(cplx) * (P + n + Q)) != hipSuccess) break;
+        if (hipMalloc((void **) &d_in, nb) != hipSuccess) break;
+        if (hipMalloc((void **) &d_out, nb) != hipSuccess) break;
+        if (hipMemcpy(d_tw, twP.data(), sizeof(cplx) * P, hipMemcpyHostToDevice) != hipSuccess) break;
+        if (hipMemcpy(d_tw + P, twN.data(), sizeof(cplx) * n, hipMemcpyHostToDevice) != hipSuccess) break;
+        if (hipMemcpy(d_tw + P + n, twQ.data(), sizeof(cplx) * Q, hipMemcpyHostToDevice) != hipSuccess) break;
+        if (hipMemcpy(d_in, in, nb, hipMemcpyHostToDevice) != hipSuccess) break;
+        if (zd::launch_test_fftq(n, axis_kind, d_tw, d_tw + P, d_tw + P + n, d_in, d_out, lines, 0)) break;
+        if (hipDeviceSynchronize() != hipSuccess) break;
+        if (hipMemcpy(out, d_out, nb, hipMemcpyDeviceToHost) != hipSuccess) break;
+        rc = 0;
+    } while (0);
+    hipFree(d_tw);
+    hipFree(d_in);
+    hipFree(d_out);
+    return rc;
+}
+
 int zd_test_fft(int32_t n, int64_t lines, int32_t axis_kind, const double *in, double *out) {
+    if (!is_pow2(n)) return test_fft_composite(n, lines, axis_kind, in, out);
     const int W = zd::test_fft_tile_width(n);
     if (W == 0 || lines % W) {
         fprintf(stderr, "zd_test_fft: n=%d needs lines %% %d == 0\n", n, W);

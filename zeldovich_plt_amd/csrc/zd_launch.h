@@ -31,6 +31,11 @@ int launch_fnl_table(const GenConst &g, int n, void *tab, hipStream_t st);
 int launch_fnl_stage(int which, const StoreLayout &S, double f_NL, const void *tw, void *data, void *phik, hipStream_t st);
 int launch_test_fft(int n, int kind, const void *tw, const void *in, void *out, long long lines, hipStream_t st);
 int test_fft_tile_width(int n);
+// ---- PPD = 2^a 3^b (zd_kernels_np2.hip) ----
+bool np2_split(int n, int *P, int *Q);
+int test_fftq_tile_width(int n);
+int launch_test_fftq(int n, int kind, const void *twP, const void *twN, const void *twQ, const void *in, void *out, long long lines,
+                     hipStream_t st);
 int launch_copy16(const void *in, void *out, long long n16, hipStream_t st);
 }  // namespace zd
 
