@@ -551,3 +551,45 @@ def test_fft_lines_composite_lengths(zd, n, kind):
     ref = np.fft.ifft(x, axis=1) * n
     err = np.abs(got - ref).max() / np.abs(ref).max()
     assert err < 2e-14, err
+
+
+@pytest.mark.parametrize("n,kw", [
+    (96, dict(stream_factor=2)),                               # 96 = 32 * 3, z lines of 48
+    (192, dict(stream_factor=2, fmt="RVZel")),                  # 192 = 64 * 3
+    (192, dict(stream_factor=4, k_cutoff=2.0)),
+    (288, dict(stream_factor=2)),                              # 288 = 32 * 9
+    (384, dict(stream_factor=8, fmt="Zeldovich", k_cutoff=1.5)),
+    (864, dict(stream_factor=2, k_cutoff=4.0, fmt="ZelSimple")),  # 864 = 32 * 27 (band-limited so that the oracle's O(n^2) DFTs stay cheap? no: full DFTs)
+])
+def test_non_power_of_two_ppd_vs_oracle(zd, oracle, ps, opk, n, kw):
+    """PPD = 2^a 3^b (the reference plans any length with FFTW, src/zeldovich.cpp:61-66): composite-length
+    transforms on the ZA field store against the oracle (whose non-power-of-two path is a plain DFT)"""
+    kw = dict(kw)
+    fmt = kw.pop("fmt", "RVdoubleZel")
+    if n > 400:
+        pytest.skip("the oracle's O(N^4) plain DFT is too slow beyond ~400; larger sizes are covered by the invariance tests")
+    plan = zd.Plan(zd.make_params(n, icformat=fmt, **kw), ps)
+    assert plan.store_mode == "fields" and plan.plane_step == 2
+    plan.close()
+    got, _ = _compare(zd, oracle, ps, opk, n, fmt=fmt, **kw)
+    assert sorted(got["planes_seen"]) == list(range(n))
+
+
+def test_non_power_of_two_oversampling_invariance(zd, ps):
+    """PPD = 2N with k_cutoff = 2 at even sites == PPD = N (README), across the composite sizes: 192 <-> 96, 576 <-> 288,
+    1728 <-> 864 (27 * 64 / 27 * 32), on sample planes (a full PPD = 1728 record array would be 290 GB of host memory);
+    R-invariance of the reductions at 1152"""
+    for n in (96, 288, 864):
+        zs = (1, n // 2 + 1, n - 1)
+        lo, hi = {}, {}
+        zd.generate_planes(zd.make_params(n, icformat="Zeldovich", stream_factor=2), ps,
+                           lambda z, rec: lo.__setitem__(z, rec["d"].copy()) if z in zs else None)
+        zd.generate_planes(zd.make_params(2 * n, icformat="Zeldovich", k_cutoff=2.0, stream_factor=4), ps,
+                           lambda z, rec: hi.__setitem__(z // 2, rec["d"][::2, ::2].copy()) if (z % 2 == 0 and z // 2 in zs) else None)
+        assert sorted(lo) == sorted(hi) == sorted(zs)
+        for z in zs:
+            assert np.abs(hi[z] - lo[z]).max() < 1e-12 * np.abs(lo[z]).max() + 1e-15, (n, z)
+    a = zd.generate(zd.make_params(1152, icformat="RVZel", stream_factor=2), ps, collect=False)
+    b = zd.generate(zd.make_params(1152, icformat="RVZel", stream_factor=8), ps, collect=False)
+    assert abs(a["density_variance"] - b["density_variance"]) <= 1e-11 * a["density_variance"]
+    assert np.abs(a["max_disp"] - b["max_disp"]).max() <= 1e-11 * np.abs(a["max_disp"]).max()

@@ -292,9 +292,15 @@ int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes
     // ZA without density: two residues share a pass, so R = 2 is preferred over R = 1 whenever the z FFT is long enough
     int R0 = 1;
     if (!p->qPLT && pack_mode(p, 2) != zd::PACK_NONE && N / 2 >= 32 && (N / 2) % nranks == 0) R0 = 2;
-    for (int R = R0; N / R >= 32; R *= 2) {
+    const bool np2 = !is_pow2(N);
+    if (np2 && (nranks != 1 || R0 != 2 || !zd::np2_supported_ppd((int) N))) return -1;
+    for (int R = R0; N / R >= 32 && N % R == 0; R *= 2) {
         if ((N / R) % nranks) break;
         if (N / R > 4096) continue;  // z-FFT kernels exist up to length 4096
+        if (np2 && !zd::np2_supported_zlen((int) (N / R))) {
+            if (N / R < 48) break;
+            continue;
+        }
         int64_t store = store_bytes(p, R, nranks);
         if (nranks > 1) store += std::min<int64_t>(store, (int64_t) 9 << 30);  // + the two-slot exchange ring (zd_multi.cpp), not a second store
         if (zd::pack_is_fields(pack_mode(p, R)))
@@ -320,8 +326,10 @@ int zd_plan_create(const zd_params *p, const zd_pk *pk, const double *eig, int64
 static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig, int64_t eig_ppd, int rank, int nranks,
                           int phi_mode, const cplx *phik, zd_plan **out) {
     const int64_t N = p->ppd;
-    if (!is_pow2(N) || N < 32 || N > 8192) {
-        fprintf(stderr, "zeldovich_hip: PPD = %lld unsupported (power of two in [32, 8192] required)\n", (long long) N);
+    const bool np2 = !is_pow2(N);  // PPD = 2^a 3^b: the composite-transform kernels (zd_kernels_np2.hip), field store only
+    if (np2 ? !zd::np2_supported_ppd((int) N) : (N < 32 || N > 8192)) {
+        fprintf(stderr, "zeldovich_hip: PPD = %lld unsupported (a power of two in [32, 8192], or 2^a 3^b with a >= 5, b <= 3 up to 6912)\n",
+                (long long) N);
         return 1;
     }
     if (p->qPLT && (eig == NULL || eig_ppd <= 0)) {
@@ -329,8 +337,14 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         return 1;
     }
     int R = p->stream_factor > 0 ? p->stream_factor : 1;
-    if (!is_pow2(R) || N / R < 32 || N / R > 4096) {
+    if (np2 && p->stream_factor <= 0) R = 2;
+    if (!is_pow2(R) || N % R || N / R < 32 || N / R > 4096 || (np2 && !zd::np2_supported_zlen((int) (N / R)))) {
         fprintf(stderr, "zeldovich_hip: stream factor %d invalid for PPD %lld\n", R, (long long) N);
+        return 1;
+    }
+    if (np2 && (nranks != 1 || phi_mode != 0 || phik != nullptr || pack_mode(p, R) != zd::PACK_ZAFIELD)) {
+        fprintf(stderr, "zeldovich_hip: PPD = %lld (not a power of two) runs on the ZA field store only: one rank, ZD_StreamFactor >= 2, no "
+                        "ZD_qdensity / ZD_qPLT / ZD_f_NL / ZD_qoneslab, store_mode auto\n", (long long) N);
         return 1;
     }
     if (nranks < 1 || !is_pow2(nranks) || rank < 0 || rank >= nranks || (N / 2) % nranks || (N / R) % nranks) {
@@ -477,6 +491,22 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         PLCHECK(hipMemcpy(pl->d_twN, twN.data(), sizeof(cplx) * twN.size(), hipMemcpyHostToDevice));
         PLCHECK(hipMalloc((void **) &pl->d_twL, sizeof(cplx) * twL.size()));
         PLCHECK(hipMemcpy(pl->d_twL, twL.data(), sizeof(cplx) * twL.size(), hipMemcpyHostToDevice));
+        if (np2) {  // composite transforms (zd_fft_q.h): exp(2 pi i k / P) | exp(2 pi i k / len) | exp(2 pi i k / Q) per length
+            auto upload = [&](int len, cplx **dst) -> int {
+                int P = 0, Q = 0;
+                if (!zd::np2_split(len, &P, &Q)) return 1;
+                std::vector<cplx> t = make_twiddles(P), b = make_twiddles(len), c = make_twiddles(Q);
+                t.insert(t.end(), b.begin(), b.end());
+                t.insert(t.end(), c.begin(), c.end());
+                if (hipMalloc((void **) dst, sizeof(cplx) * t.size()) != hipSuccess) return 1;
+                return hipMemcpy(*dst, t.data(), sizeof(cplx) * t.size(), hipMemcpyHostToDevice) != hipSuccess;
+            };
+            if (upload(pl->N, &pl->d_twq_n) || upload(pl->L, &pl->d_twq_l)) {
+                fprintf(stderr, "zeldovich_hip: composite twiddle tables failed\n");
+                zd_plan_destroy(pl);
+                return 1;
+            }
+        }
         // LDS image of k_genf (layout: GenfTab in zd_kernels.hip).  Spline tables beyond 512 segments do not
         // fit: such runs use the general generator.
         const int nseg = pk->is_powerlaw ? 0 : pk->n - 1;
@@ -742,6 +772,8 @@ void zd_plan_destroy(zd_plan *pl) {
     hipFree(pl->d_rowstate);
     hipFree(pl->d_twN);
     hipFree(pl->d_twL);
+    hipFree(pl->d_twq_n);
+    hipFree(pl->d_twq_l);
     hipFree(pl->d_genf);
     hipFree(pl->d_tilectr);
     hipFree(pl->d_red);
@@ -777,6 +809,7 @@ int64_t zd_plan_plane_z(const zd_plan *pl, int pass, int64_t local_plane) {
 // z FFT of one slab of generated rows into the block store (reference / packed arrays with Hermitian twins, or the
 // potentials of the field store)
 static int launch_zstage_fft(zd_plan *pl, int ky0, int kyloc0, int nky, const void *Y, void *d_send, hipStream_t st) {
+    if (pl->d_twq_l) return zd::launch_zfft_fields_np2(pl->L, pl->F, pl->S, ky0, kyloc0, nky, Y, pl->d_twq_l, d_send, st);
     if (zd::pack_is_fields(pl->pack)) return zd::launch_zfft_fields(pl->L, pl->F, pl->S, ky0, kyloc0, nky, Y, pl->d_twL, d_send, st);
     return zd::launch_zfft(pl->L, pl->jobs, pl->S, ky0, kyloc0, nky, pl->Zq, Y, pl->d_twL, d_send, st);
 }
@@ -910,14 +943,16 @@ int zd_plan_stage_x_group(zd_plan *pl, int residue, const void *d_recv, int chun
         const int p0 = (int) (plane0 / ps), np = (int) (nplanes / ps);
         for (int g0 = 0; g0 < np; g0 += pl->ring_planes) {
             const int ng = std::min(pl->ring_planes, np - g0);
-            tick(pl, ZD_K_YFFT, st, true);
-            if (zd::launch_yfft_fields(F, pl->S, pl->d_twN, d_recv, p0 + g0, ng, pl->SR.pitch, pl->d_ring, st)) return 1;
-            tick(pl, ZD_K_YFFT, st, false);
+            char *rec_g = d_records ? (char *) d_records + (size_t) g0 * ps * pl->N * pl->N * pl->ec.recsize : nullptr;
             const int z_first = (int) zd_plan_plane_z(pl, residue, gplane0 + (int64_t) g0 * ps);
+            tick(pl, ZD_K_YFFT, st, true);
+            if (pl->d_twq_n ? zd::launch_yfft_fields_np2(F, pl->S, pl->d_twq_n, d_recv, p0 + g0, ng, pl->SR.pitch, pl->d_ring, st)
+                            : zd::launch_yfft_fields(F, pl->S, pl->d_twN, d_recv, p0 + g0, ng, pl->SR.pitch, pl->d_ring, st))
+                return 1;
+            tick(pl, ZD_K_YFFT, st, false);
             tick(pl, ZD_K_XFFT, st, true);
-            if (zd::launch_xfft(pl->SR, pl->ec, pl->d_twN, pl->d_ring, 0, ng, z_first, pl->R,
-                                d_records ? (char *) d_records + (size_t) g0 * ps * pl->N * pl->N * pl->ec.recsize : nullptr,
-                                nullptr, pl->d_red, st))
+            if (pl->d_twq_n ? zd::launch_xfft_np2(pl->N, pl->ec, pl->d_twq_n, pl->d_ring, pl->SR.pitch, ng, z_first, pl->R, rec_g, pl->d_red, st)
+                            : zd::launch_xfft(pl->SR, pl->ec, pl->d_twN, pl->d_ring, 0, ng, z_first, pl->R, rec_g, nullptr, pl->d_red, st))
                 return 1;
             tick(pl, ZD_K_XFFT, st, false);
         }

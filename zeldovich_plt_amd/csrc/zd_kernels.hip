@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "zd_device.h"
+#include "zd_epi.h"
 #include "zd_launch.h"
 
 using namespace zd;
@@ -48,6 +49,9 @@ extern "C" int zdk_upload_bit_table(const zdpcg::BitTable *host) {
 
 // ------------------------------------------------------------------------------------------------
 // device math for one mode
+
+// i mod N for 0 <= i < 2^31 (N a power of two on the production path; PPD = 2^a 3^b takes the division)
+__device__ __forceinline__ int modn(int N, int i) { return (N & (N - 1)) == 0 ? (i & (N - 1)) : (int) ((unsigned) i % (unsigned) N); }
 
 __device__ __forceinline__ u128 advance_bits(u128 s, uint64_t delta) {
     for (int i = 0; i < zdpcg::NBITS; i++) {
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, JobList 
         bool all_zero = true;
         const int xt0 = x - x % zW;
         for (int i = -1; i <= zW; i++) {
-            const int xi = (xt0 + i) & (N - 1);
+            const int xi = modn(N, xt0 + i + N);
             all_zero = all_zero && column_is_zero(S, xi > half ? xi - N : xi, ky);
         }
         if (all_zero) return;
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, JobList 
             } else {
                 if (z > half) {
                     zs = N - z;
-                    xs = (N - x) & (N - 1);
+                    xs = x ? N - x : 0;
                     cj = true;
                 } else if (z == 0) {
                     if (x == 0)
@@ -393,10 +397,10 @@ __global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, JobList 
             const double se = g.fundamental * ik2;  // even in k: the conjugated copy keeps its sign (JOB_E)
             double d2r = dr, d2i = di;  // PACK_ZAPAIR / PACK_ZAFIELD: the same mode folded for the second residue of the pass
             if (R > 1) {  // W_R^{k1 r}
-                const cplx w = twN[(int) (((long long) k1 * residue * L) & (N - 1))];
+                const cplx w = twN[modn(N, k1 * residue * L)];
                 const double a = dr * w.x - di * w.y, b = dr * w.y + di * w.x;
                 if (jobs.pack == PACK_ZAPAIR || jobs.pack == PACK_ZAFIELD) {
-                    const cplx w2 = twN[(int) (((long long) k1 * residue2 * L) & (N - 1))];
+                    const cplx w2 = twN[modn(N, k1 * residue2 * L)];
                     const double a2 = dr * w2.x - di * w2.y, b2 = dr * w2.y + di * w2.x;
                     d2r = a2;
                     d2i = b2;
@@ -435,10 +439,10 @@ __global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, JobList 
         }
         double pr = 1.0, pi = 0.0, qr = 1.0, qi = 0.0;  // W_N^{k2 r}, and the same for the second residue
         if (R > 1) {
-            const cplx w = twN[(int) (((long long) k2 * residue) & (N - 1))];
+            const cplx w = twN[modn(N, k2 * residue)];
             pr = w.x;
             pi = w.y;
-            const cplx w2 = twN[(int) (((long long) k2 * residue2) & (N - 1))];
+            const cplx w2 = twN[modn(N, k2 * residue2)];
             qr = w2.x;
             qi = w2.y;
         }
@@ -751,7 +755,7 @@ __device__ __forceinline__ double genf_tile(const GenConst &g, const GenJumps &J
                                                           ky0 + (kyl_arg * FIELD_RB + r) * S.ky_stride);
         } else {
             for (int i = -1; i <= zW; i++) {
-                const int xi = (xt0 + i) & (N - 1);
+                const int xi = modn(N, xt0 + i + N);
                 all_zero = all_zero && column_is_zero(S, xi > half ? xi - N : xi, ky);
             }
         }
@@ -815,10 +819,10 @@ __device__ __forceinline__ double genf_tile(const GenConst &g, const GenJumps &J
             vsum = fma(dr, dr, fma(di, di, vsum));
             double d2r = dr, d2i = di;  // ZAP: the mode folded for the second residue of the pass
             if (R > 1) {  // W_R^{k1 r}
-                const cplx w = twN[(int) (((long long) k1 * residue * L) & (N - 1))];
+                const cplx w = twN[modn(N, k1 * residue * L)];
                 const double a = dr * w.x - di * w.y, b = dr * w.y + di * w.x;
                 if constexpr (ZA2) {
-                    const cplx w2 = twN[(int) (((long long) k1 * residue2 * L) & (N - 1))];
+                    const cplx w2 = twN[modn(N, k1 * residue2 * L)];
                     d2r = dr * w2.x - di * w2.y;
                     d2i = dr * w2.y + di * w2.x;
                 }
@@ -865,11 +869,11 @@ __device__ __forceinline__ double genf_tile(const GenConst &g, const GenJumps &J
         // ---- job inputs from the field sums, times W_N^{k2 r}; Y[((j*nky + kyl)*L + k2)*N + x] ----
         double pr = 1.0, pi = 0.0, qr = 1.0, qi = 0.0;
         if (R > 1) {
-            const cplx w = twN[(int) (((long long) k2 * residue) & (N - 1))];
+            const cplx w = twN[modn(N, k2 * residue)];
             pr = w.x;
             pi = w.y;
             if constexpr (ZA2) {
-                const cplx w2 = twN[(int) (((long long) k2 * residue2) & (N - 1))];
+                const cplx w2 = twN[modn(N, k2 * residue2)];
                 qr = w2.x;
                 qi = w2.y;
             }
@@ -974,7 +978,7 @@ __device__ __forceinline__ double genf_tile_mirror(const GenConst &g, const GenJ
         }
         const int xt0 = x - x % zW;
         for (int i = -1; i <= zW; i++) {
-            const int xi = (xt0 + i) & (N - 1);
+            const int xi = modn(N, xt0 + i + N);
             all_zero = all_zero && column_is_zero(S, xi > half ? xi - N : xi, ky);
         }
         return all_zero;
@@ -1034,11 +1038,11 @@ __device__ __forceinline__ double genf_tile_mirror(const GenConst &g, const GenJ
             // W_R^{k1 r} (and the second residue's)
             double wr = 1.0, wi = 0.0, w2r = 1.0, w2i = 0.0;
             if (R > 1) {
-                const cplx w = twN[(int) (((long long) k1 * residue * L) & (N - 1))];
+                const cplx w = twN[modn(N, k1 * residue * L)];
                 wr = w.x;
                 wi = w.y;
                 if constexpr (ZA2) {
-                    const cplx w2 = twN[(int) (((long long) k1 * residue2 * L) & (N - 1))];
+                    const cplx w2 = twN[modn(N, k1 * residue2 * L)];
                     w2r = w2.x;
                     w2i = w2.y;
                 }
@@ -1084,11 +1088,11 @@ __device__ __forceinline__ double genf_tile_mirror(const GenConst &g, const GenJ
         // ---- job inputs from the field sums (genf_tile), for column xA with kx = +xh and column xB with kx = -xh ----
         double pr = 1.0, pi = 0.0, qr = 1.0, qi = 0.0;
         if (R > 1) {
-            const cplx w = twN[(int) (((long long) k2 * residue) & (N - 1))];
+            const cplx w = twN[modn(N, k2 * residue)];
             pr = w.x;
             pi = w.y;
             if constexpr (ZA2) {
-                const cplx w2 = twN[(int) (((long long) k2 * residue2) & (N - 1))];
+                const cplx w2 = twN[modn(N, k2 * residue2)];
                 qr = w2.x;
                 qi = w2.y;
             }
@@ -1545,53 +1549,6 @@ constexpr int XFFT_SEQ_NH(int N, int NA, int lds_dbl) {
     return nh;
 }
 
-__device__ __forceinline__ unsigned long long dbits(double v) { return (unsigned long long) __double_as_longlong(v); }
-
-// one particle record (include/output.h:19-49; WriteParticlesSlab output.cpp:128-141: i = z, j = y, k = x,
-// displ = (qz, qy, qx), vel = (vz, vy, vx)); pos/vel are in this code's x, y, z order
-__device__ __forceinline__ void emit_record(char *__restrict__ records, long long pidx, const EpiConst &ec, int z, int yy,
-                                            int xx, const double (&pos)[3], const double (&vel)[3]) {
-    char *rec = records + pidx * ec.recsize;
-    const unsigned int ij = ((unsigned int) z & 0xffffu) | (((unsigned int) yy & 0xffffu) << 16);
-    const unsigned int k0 = ((unsigned int) xx & 0xffffu);
-    if (ec.icformat == 1) {  // RVZel: u16 i,j,k + pad, float displ[3], vel[3]
-        uint4 q0, q1;
-        q0.x = ij;
-        q0.y = k0;
-        q0.z = __float_as_uint((float) pos[2]);
-        q0.w = __float_as_uint((float) pos[1]);
-        q1.x = __float_as_uint((float) pos[0]);
-        q1.y = __float_as_uint((float) vel[2]);
-        q1.z = __float_as_uint((float) vel[1]);
-        q1.w = __float_as_uint((float) vel[0]);
-        reinterpret_cast<uint4 *>(rec)[0] = q0;
-        reinterpret_cast<uint4 *>(rec)[1] = q1;
-    } else if (ec.icformat == 2) {  // RVdoubleZel: 56 B
-        unsigned long long *r8 = reinterpret_cast<unsigned long long *>(rec);
-        r8[0] = (unsigned long long) ij | ((unsigned long long) k0 << 32);
-        double *d = reinterpret_cast<double *>(rec + 8);
-        d[0] = pos[2];
-        d[1] = pos[1];
-        d[2] = pos[0];
-        d[3] = vel[2];
-        d[4] = vel[1];
-        d[5] = vel[0];
-    } else if (ec.icformat == 0) {  // Zeldovich: u16 i,j,k + pad, double displ[3]
-        double2 q0, q1;
-        q0.x = __longlong_as_double((long long) ((unsigned long long) ij | ((unsigned long long) k0 << 32)));
-        q0.y = pos[2];
-        q1.x = pos[1];
-        q1.y = pos[0];
-        reinterpret_cast<double2 *>(rec)[0] = q0;
-        reinterpret_cast<double2 *>(rec)[1] = q1;
-    } else {  // ZelSimple: float displ[3]
-        float *d = reinterpret_cast<float *>(rec);
-        d[0] = (float) pos[2];
-        d[1] = (float) pos[1];
-        d[2] = (float) pos[0];
-    }
-}
-
 // the part of WriteParticlesSlab (src/output.cpp:86-203) that consumes the staged fields of x pass h:
 // fld[(row*2*NA + 2a + {0,1})*NXH + x - h*NXH] -> records / density / running reductions
 template <int N, int NA, int ROWS, int NXH, int NT>
@@ -1651,50 +1608,6 @@ __device__ __forceinline__ void xfft_consume(const EpiConst &ec, const double *_
                 }
             }
         }
-}
-
-// workgroup reduction of the epilogue -> one atomic per quantity into a replicated slot
-template <int NT, int NA>
-__device__ __forceinline__ void xfft_reduce(double *lds, Reduce *__restrict__ red, double ssq, double (&mp)[3], double (&mn)[3]) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        ssq += __shfl_down(ssq, off);
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            mp[j] = fmax(mp[j], __shfl_down(mp[j], off));
-            mn[j] = fmax(mn[j], __shfl_down(mn[j], off));
-        }
-    }
-    __syncthreads();
-    double *scr = lds;  // 7 doubles per wave
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) {
-        scr[wave * 7 + 0] = ssq;
-        for (int j = 0; j < 3; j++) {
-            scr[wave * 7 + 1 + j] = mp[j];
-            scr[wave * 7 + 4 + j] = mn[j];
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        constexpr int NW = (NT + 63) / 64;
-        double tot = 0, a3[3] = {0, 0, 0}, b3[3] = {0, 0, 0};
-        for (int i = 0; i < NW; i++) {
-            tot += scr[i * 7];
-            for (int j = 0; j < 3; j++) {
-                a3[j] = fmax(a3[j], scr[i * 7 + 1 + j]);
-                b3[j] = fmax(b3[j], scr[i * 7 + 4 + j]);
-            }
-        }
-        const int slot = (blockIdx.x + blockIdx.y * 7) % NSLOT;
-        if (NA != 3) atomicAdd(&red->sumsq[slot], tot);
-        if (NA >= 2) {
-            for (int j = 0; j < 3; j++) {
-                atomicMax(&red->maxpos[j][slot], dbits(fabs(a3[j])));
-                atomicMax(&red->maxneg[j][slot], dbits(fabs(b3[j])));
-            }
-        }
-    }
 }
 
 template <int N, int E, int NA, int ROWS>
@@ -2028,7 +1941,8 @@ static int launch_gen_t(const GenConst &g, const GenJumps &J, const JobList &job
                         int nrows, int L, int residue, int residue2, const void *twN, void *Y, hipStream_t st) {
     const int N = g.N;
     dim3 grid((N + GEN_BX - 1) / GEN_BX, L / GEN_ZR, nrows), block(GEN_BX);
-    hipLaunchKernelGGL((k_gen<GEN_ZR, NJ, PLT, PLAW>), grid, block, 0, st, g, J, jobs, S, zfft_tile_width(L), ky0, nky,
+    const int zw = zfft_tile_width(L) > 0 ? zfft_tile_width(L) : 16;  // (composite L: any width is a safe neighbourhood)
+    hipLaunchKernelGGL((k_gen<GEN_ZR, NJ, PLT, PLAW>), grid, block, 0, st, g, J, jobs, S, zw, ky0, nky,
                        L, residue, residue2, (const cplx *) twN, (cplx *) Y);
     ZD_LAUNCH_CHECK();
     return 0;
@@ -2256,6 +2170,7 @@ static int launch_zfft_f_t(const FieldLayout &F, const StoreLayout &S, int ky0, 
 }
 // columns per z-FFT workgroup of the field store (x 8 rows = lines per workgroup); the generator prunes by it
 int zfft_fields_tile_columns(int L) {
+    if (L & (L - 1)) return zfft_fields_np2_columns(L);  // composite lengths: zd_kernels_np2.hip
     switch (L) {
         case 32: case 64: case 128: return 4;
         case 256: return 2;

@@ -6,6 +6,7 @@
 #include <stdio.h>
 
 #include "zd_device.h"
+#include "zd_epi.h"
 #include "zd_fft_q.h"
 #include "zd_launch.h"
 
@@ -69,7 +70,292 @@ __global__ __launch_bounds__(W *Q *P / E) void k_test_fftq_lines(const cplx *__r
     for (int e = 0; e < E; e++) out[line * N + (t + T * e) + P * n2] = cplx{re[e], im[e]};
 }
 
+// ------------------------------------------------------------------------------------------------
+// Field-store pipeline for PPD = P*Q (ZA, one rank): the roles of k_zfft_f, k_yfft_f and k_xfft_seq of zd_kernels.hip with
+// the composite line transform.  A thread enters a transform with elements Q (t + T e) + n2 of its line and leaves with
+// elements (t + T e) + P n2: the load stage of every kernel uses the first index, the store stage the second.
+
+// z stage: lines of length L = P*Q (the folded z direction) for NC columns x the 8 rows of a row group.
+//   grid: (N/NC, row groups, nfield)   block: NC*8*Q*P/E
+template <int P, int E, int Q, int NC>
+__global__ __launch_bounds__(NC *FIELD_RB *Q *P / E) void k_zfft_fq(FieldLayout F, StoreLayout S, int ky0, int kyloc0, int nky,
+                                                                  const cplx *__restrict__ Y, const cplx *__restrict__ twP,
+                                                                  const cplx *__restrict__ twL, const cplx *__restrict__ twQ,
+                                                                  cplx *__restrict__ out) {
+    constexpr int W = NC * FIELD_RB, L = P * Q;
+    using LQ = zdfft::LineQ<P, E, Q, W, false>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int T = LQ::T;
+    const int N = S.N;
+    const int c = threadIdx.x % (W * Q), t = threadIdx.x / (W * Q);
+    const int w = c % W, n2 = c / W;
+    const int grp = blockIdx.y;
+    const int r = w & (FIELD_RB - 1), x = blockIdx.x * NC + w / FIELD_RB;
+    const int ky = ky0 + (grp * FIELD_RB + r) * S.ky_stride;
+    if (S.prune & 2) {
+        if (__syncthreads_and(column_is_zero(S, x > S.half ? x - N : x, ky))) return;
+    }
+    const cplx *src = Y + ((((long long) blockIdx.z * (nky / FIELD_RB) + grp) * L) * N) * FIELD_RB;
+    double re[E], im[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int k2 = Q * (t + T * e) + n2;
+        const cplx v = src[((long long) k2 * N + x) * FIELD_RB + r];
+        re[e] = v.x;
+        im[e] = v.y;
+    }
+    LQ::run(re, im, t, w, n2, lds, twP, twL, twQ);
+    const FieldRow row = F.rows[kyloc0 / FIELD_RB + grp];
+    const unsigned pos = ((unsigned) (x < row.split ? x : x - row.gap)) * FIELD_RB + r;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int zl = (t + T * e) + P * n2;  // one rank: every plane is local
+        out[(long long) (zl * F.nfield + (int) blockIdx.z) * F.field_elems + (unsigned) row.base + pos] = cplx{re[e], im[e]};
+    }
+}
+
+// y stage: builds (qx + i qy)_r0 | (qx + i qy)_r1 | qz_r0 + i qz_r1 from the potentials (see k_yfft_f) and transforms
+// along y; ring rows are indexed by y directly.
+//   grid: (3*N/W, 1, planes)   block: W*Q*P/E
+template <int P, int E, int Q, int W>
+__global__ __launch_bounds__(W *Q *P / E) void k_yfft_fq(FieldLayout F, StoreLayout S, const cplx *__restrict__ twP,
+                                                        const cplx *__restrict__ twN, const cplx *__restrict__ twQ,
+                                                        const cplx *__restrict__ store, int plane0, int ring_pitch,
+                                                        cplx *__restrict__ ring) {
+    constexpr int N = P * Q, NT = N / W;
+    using LQ = zdfft::LineQ<P, E, Q, W, false>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int T = LQ::T;
+    const int c = threadIdx.x % (W * Q), t = threadIdx.x / (W * Q);
+    const int w = c % W, n2 = c / W;
+    const int tile = blockIdx.x % NT, a = blockIdx.x / NT;
+    const int x = tile * W + w, xm = x ? N - x : 0;
+    const int zl = plane0 + blockIdx.z;
+    const int kx = x > N / 2 ? x - N : x;
+    const bool two = a == 2;  // (Z_0, Z_1); a < 2: E_a alone
+    const int f0 = a == 2 ? 1 : 2 * a;
+    const cplx *p0 = store + (long long) (zl * F.nfield + f0) * F.field_elems;
+    const long long d01 = two ? 2 * F.field_elems : 0;
+    double re[E], im[E];
+    FieldRow rows[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int y = Q * (t + T * e) + n2;
+        int kyp = y > N / 2 ? N - y : y;
+        kyp = kyp < N / 2 ? kyp : N / 2 - 1;
+        rows[e] = F.rows[kyp / FIELD_RB];
+    }
+    constexpr int BATCH = E >= 4 ? 4 : E;
+#pragma unroll
+    for (int b = 0; b < E; b += BATCH) {
+        cplx u[BATCH], v[BATCH];
+        bool skip[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; j++) {
+            const int e = b + j, y = Q * (t + T * e) + n2;
+            const bool mir = y > N / 2;
+            const int kyp = mir ? N - y : y;
+            const int xs  = mir ? xm : x;
+            skip[j] = (2 * y == N) || ((S.prune & 4) && column_is_zero(S, kx, kyp));
+            const int split = rows[e].split, gap = rows[e].gap;
+            const unsigned off = skip[j] ? 0u : (unsigned) rows[e].base + (unsigned) (xs < split ? xs : xs - gap) * FIELD_RB
+                                                    + (unsigned) (kyp & (FIELD_RB - 1));
+            const cplx *q = p0 + off;
+            u[j] = q[0];
+            if (two) v[j] = q[d01];
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; j++) {
+            const int e = b + j, y = Q * (t + T * e) + n2;
+            const bool mir = y > N / 2;
+            const double s = mir ? -1.0 : 1.0;
+            double vr, vi;
+            if (two) {
+                vr = -u[j].y - s * v[j].x;
+                vi = s * u[j].x - v[j].y;
+            } else {
+                const double dky = (double) (mir ? N - y : y), dkx = (double) kx;
+                vr = -s * (dky * u[j].x + dkx * u[j].y);
+                vi = dkx * u[j].x - dky * u[j].y;
+            }
+            re[e] = skip[j] ? 0.0 : vr;
+            im[e] = skip[j] ? 0.0 : vi;
+        }
+    }
+    LQ::run(re, im, t, w, n2, lds, twP, twN, twQ);
+    cplx *base = ring + ((long long) ((int) blockIdx.z * 3 + a) * N) * ring_pitch + x;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int y = (t + T * e) + P * n2;
+        base[(long long) y * ring_pitch] = cplx{re[e], im[e]};
+    }
+}
+
+// x stage + epilogue: one row per workgroup, its three arrays in sequence; the third (qz_r0 + i qz_r1) first and kept in
+// registers, then each (qx + i qy)_r with the records of its plane straight from registers.
+//   grid: (N, planes)   block: Q*P/E
+template <int P, int E, int Q>
+__global__ __launch_bounds__(Q *P / E) void k_xfft_seq_q(EpiConst ec, const cplx *__restrict__ twP, const cplx *__restrict__ twN,
+                                                       const cplx *__restrict__ twQ, const cplx *__restrict__ ring,
+                                                       int ring_pitch, int z_first, int z_step, char *__restrict__ records,
+                                                       Reduce *__restrict__ red) {
+    constexpr int N = P * Q;
+    using LQ = zdfft::LineQ<P, E, Q, 1, true>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int T = LQ::T, NT = T * Q;
+    const int t = threadIdx.x % T, n2 = threadIdx.x / T;
+    const int y = blockIdx.x, pl = blockIdx.y;
+    auto load_fft = [&](int a, double (&re)[E], double (&im)[E]) {
+        const cplx *src = ring + ((long long) (pl * 3 + a) * N + y) * ring_pitch;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const cplx v = src[Q * (t + T * e) + n2];
+            re[e] = v.x;
+            im[e] = v.y;
+        }
+        LQ::run(re, im, t, 0, n2, lds, twP, twN, twQ);
+    };
+    double cr[E], ci[E];
+    load_fft(2, cr, ci);
+    const int z = z_first + z_step * (int) blockIdx.y;
+    double mp[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
+    const long long plane_rec0 = 2 * (long long) blockIdx.y * N * N;
+#pragma unroll 1
+    for (int w2 = 0; w2 < 2; w2++) {
+        double ar[E], ai[E];
+        load_fft(w2, ar, ai);
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int xx = (t + T * e) + P * n2;
+            const double pos[3] = {ar[e], ai[e], w2 ? ci[e] : cr[e]};
+            const double vel[3] = {pos[0] * ec.vnorm, pos[1] * ec.vnorm, pos[2] * ec.vnorm};
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                mp[j] = fmax(mp[j], pos[j]);
+                mn[j] = fmax(mn[j], -pos[j]);
+            }
+            if (records) emit_record(records, plane_rec0 + (long long) w2 * N * N + (long long) y * N + xx, ec, z + w2 * ec.z_pair, y, xx, pos, vel);
+        }
+    }
+    // workgroup reduction through LDS (the workgroup is N/16 threads: not a whole number of waves, so no wave shuffles)
+    __syncthreads();
+    for (int j = 0; j < 3; j++) {
+        lds[threadIdx.x * 6 + j]     = mp[j];
+        lds[threadIdx.x * 6 + 3 + j] = mn[j];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a3[3] = {0, 0, 0}, b3[3] = {0, 0, 0};
+        for (int i = 0; i < NT; i++)
+            for (int j = 0; j < 3; j++) {
+                a3[j] = fmax(a3[j], lds[i * 6 + j]);
+                b3[j] = fmax(b3[j], lds[i * 6 + 3 + j]);
+            }
+        const int slot = (blockIdx.x + blockIdx.y * 7) % NSLOT;
+        for (int j = 0; j < 3; j++) {
+            atomicMax(&red->maxpos[j][slot], dbits(fabs(a3[j])));
+            atomicMax(&red->maxneg[j][slot], dbits(fabs(b3[j])));
+        }
+    }
+}
+
 namespace zd {
+
+// ---- launchers of the field-store pipeline ----
+template <int P, int E, int Q, int NC>
+static int launch_zfft_fq_t(const FieldLayout &F, const StoreLayout &S, int ky0, int kyloc0, int nky, const void *Y, const cplx *tw,
+                            void *out, hipStream_t st) {
+    constexpr int W = NC * FIELD_RB, threads = W * Q * P / E;
+    static_assert(threads <= 1024, "workgroup too large");
+    const size_t shmem = sizeof(double) * zdfft::LineQ<P, E, Q, W, false>::LDS_DOUBLES;
+    if (shmem > 160 * 1024 || nky % FIELD_RB || kyloc0 % FIELD_RB) return 2;
+    hipFuncSetAttribute((const void *) k_zfft_fq<P, E, Q, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+    dim3 grid(S.N / NC, nky / FIELD_RB, F.nfield), block(threads);
+    hipLaunchKernelGGL((k_zfft_fq<P, E, Q, NC>), grid, block, shmem, st, F, S, ky0, kyloc0, nky, (const cplx *) Y, tw, tw + P,
+                       tw + P + P * Q, (cplx *) out);
+    ZD_LAUNCH_CHECK();
+    return 0;
+}
+// tw: exp(2 pi i k/P) | exp(2 pi i k/L) | exp(2 pi i k/Q), consecutive (np2_twiddle_count entries)
+int launch_zfft_fields_np2(int L, const FieldLayout &F, const StoreLayout &S, int ky0, int kyloc0, int nky, const void *Y,
+                           const void *tw, void *out, hipStream_t st) {
+#define ZC(p, q, nc) \
+    if (L == (p) * (q)) return launch_zfft_fq_t<p, 16, q, nc>(F, S, ky0, kyloc0, nky, Y, (const cplx *) tw, out, st);
+    ZC(16, 3, 4) ZC(32, 3, 4) ZC(64, 3, 4) ZC(128, 3, 2) ZC(256, 3, 1) ZC(512, 3, 1)
+    ZC(16, 9, 4) ZC(32, 9, 2) ZC(64, 9, 1) ZC(128, 9, 1)
+    ZC(16, 27, 2) ZC(32, 27, 1) ZC(64, 27, 1)
+#undef ZC
+    fprintf(stderr, "zeldovich_hip: no z transform of length %d (16*2^k * {3, 9, 27} up to 1728)\n", L);
+    return 2;
+}
+int zfft_fields_np2_columns(int L) {
+    switch (L) {
+        case 48: case 96: case 192: case 144: return 4;
+        case 384: case 288: case 432: return 2;
+        default: return 1;
+    }
+}
+
+template <int P, int E, int Q, int W>
+static int launch_yfft_fq_t(const FieldLayout &F, const StoreLayout &S, const cplx *tw, const void *store, int plane0, int nplanes,
+                            int ring_pitch, void *ring, hipStream_t st) {
+    constexpr int threads = W * Q * P / E, N = P * Q;
+    static_assert(threads <= 1024, "workgroup too large");
+    const size_t shmem = sizeof(double) * zdfft::LineQ<P, E, Q, W, false>::LDS_DOUBLES;
+    if (shmem > 160 * 1024) return 2;
+    hipFuncSetAttribute((const void *) k_yfft_fq<P, E, Q, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+    dim3 grid(3 * (N / W), 1, nplanes), block(threads);
+    hipLaunchKernelGGL((k_yfft_fq<P, E, Q, W>), grid, block, shmem, st, F, S, tw, tw + P, tw + P + N, (const cplx *) store, plane0,
+                       ring_pitch, (cplx *) ring);
+    ZD_LAUNCH_CHECK();
+    return 0;
+}
+template <int P, int E, int Q>
+static int launch_xfft_q_t(const EpiConst &ec, const cplx *tw, const void *ring, int ring_pitch, int nplanes, int z_first, int z_step,
+                           void *records, Reduce *red, hipStream_t st) {
+    constexpr int N = P * Q, threads = Q * P / E;
+    const size_t shmem = sizeof(double) * zdfft::LineQ<P, E, Q, 1, true>::LDS_DOUBLES;
+    hipFuncSetAttribute((const void *) k_xfft_seq_q<P, E, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+    dim3 grid(N, nplanes), block(threads);
+    hipLaunchKernelGGL((k_xfft_seq_q<P, E, Q>), grid, block, shmem, st, ec, tw, tw + P, tw + P + N, (const cplx *) ring, ring_pitch,
+                       z_first, z_step, (char *) records, red);
+    ZD_LAUNCH_CHECK();
+    return 0;
+}
+// the PPDs with a y / x transform: N = P*Q
+#define NP2_SIZES(X)                                                                                                   \
+    X(32, 3, 16) X(64, 3, 16) X(128, 3, 16) X(256, 3, 8) X(512, 3, 8) X(1024, 3, 4) X(32, 9, 16) X(64, 9, 16) X(128, 9, 8) \
+    X(256, 9, 4) X(512, 9, 2) X(32, 27, 8) X(64, 27, 8) X(128, 27, 4) X(256, 27, 2)
+int launch_yfft_fields_np2(const FieldLayout &F, const StoreLayout &S, const void *tw, const void *store, int plane0, int nplanes,
+                           int ring_pitch, void *ring, hipStream_t st) {
+#define YC(p, q, w) \
+    if (S.N == (p) * (q)) return launch_yfft_fq_t<p, 16, q, w>(F, S, (const cplx *) tw, store, plane0, nplanes, ring_pitch, ring, st);
+    NP2_SIZES(YC)
+#undef YC
+    fprintf(stderr, "zeldovich_hip: PPD %d is not among the supported 2^a 3^b sizes\n", S.N);
+    return 2;
+}
+int launch_xfft_np2(int N, const EpiConst &ec, const void *tw, const void *ring, int ring_pitch, int nplanes, int z_first, int z_step,
+                    void *records, Reduce *red, hipStream_t st) {
+#define XC(p, q, w) \
+    if (N == (p) * (q)) return launch_xfft_q_t<p, 16, q>(ec, (const cplx *) tw, ring, ring_pitch, nplanes, z_first, z_step, records, red, st);
+    NP2_SIZES(XC)
+#undef XC
+    fprintf(stderr, "zeldovich_hip: PPD %d is not among the supported 2^a 3^b sizes\n", N);
+    return 2;
+}
+bool np2_supported_ppd(int N) {
+#define SC(p, q, w) \
+    if (N == (p) * (q)) return true;
+    NP2_SIZES(SC)
+#undef SC
+    return false;
+}
+bool np2_supported_zlen(int L) {
+    int P, Q;
+    if (!np2_split(L, &P, &Q) || P < 16) return false;
+    return (Q == 3 && P <= 512) || (Q == 9 && P <= 128) || (Q == 27 && P <= 64);
+}
 
 template <int P, int E, int Q, int W>
 static int launch_test_fftq_t(int kind, const void *twP, const void *twN, const void *twQ, const void *in, void *out, long long lines,

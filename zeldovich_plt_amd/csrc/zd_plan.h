@@ -40,6 +40,7 @@ struct zd_plan {
     double *d_eig = nullptr;
     zdpcg::u128 *d_rowstate = nullptr;
     zdfft::cplx *d_twN = nullptr, *d_twL = nullptr;
+    zdfft::cplx *d_twq_n = nullptr, *d_twq_l = nullptr;  // PPD = 2^a 3^b: twiddle sets of the composite transforms (lengths N, L)
     double *d_genf = nullptr;  // LDS image of k_genf
     unsigned *d_tilectr = nullptr;  // one work counter per k_genf launch of a pass
     int n_tilectr = 0, gen_max_wgs = 0;
