@@ -156,10 +156,11 @@ def _planes(zd, ps, n, zs, **kw):
     return res, info
 
 
-@pytest.mark.parametrize("n", [2048, 4096])
+@pytest.mark.parametrize("n", [2048, 4096, 3456])
 def test_oversampled_planes_exact_at_full_size(zd, n):
     """PPD = 2n, ZD_k_cutoff = 2 at even lattice sites == PPD = n, ZD_k_cutoff = 1 (8192 <-> 4096: BASELINE C5 / C4,
-    4096 <-> 2048: C3 size), records compared exactly (1e-13 of the field maximum) on planes of three different passes"""
+    4096 <-> 2048: C3 size; 6912 <-> 3456: the production Abacus size 6912 = 2^8 3^3 on the composite-transform kernels),
+    records compared exactly (1e-13 of the field maximum) on planes of three different passes"""
     ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
     zs = [5, n // 2 + 3, n - 2]
     lo, ilo = _planes(zd, ps, n, zs)
@@ -174,7 +175,7 @@ def test_oversampled_planes_exact_at_full_size(zd, n):
         assert scale > 0
         err = np.abs(a["d"] - b["d"]).max() / scale
         print("  z", z, "max |d(2n, even sites) - d(n)| / max|d| =", err)
-        assert err < 1e-13
+        assert err < (1e-13 if n != 3456 else 1e-12)  # composite transforms: 27-term outer sums
 
 
 def test_ppd2048_plt_store_and_stream_invariance(zd, oracle):
