@@ -26,7 +26,8 @@ enum { ZD_FMT_ZEL = 0, ZD_FMT_RVZEL = 1, ZD_FMT_RVDOUBLEZEL = 2, ZD_FMT_ZELSIMPL
 /* The subset of `Parameters` (include/parameters.h:9-86) that the path reads, with the derived
  * quantities of Parameters::setup (src/parameters.cpp:172-174) already filled in. */
 typedef struct zd_params {
-    int64_t ppd;        /* cbrt(NP) */
+    int64_t ppd;        /* cbrt(NP): a power of two in [32, 8192], or 2^a 3^b (a >= 5, b <= 3, <= 6912; ZA without
+                         * ZD_qdensity on one rank: the composite-transform kernels) */
     int32_t numblock;   /* ZD_NumBlock: accepted for compatibility; v2 output does not depend on it */
     int32_t cpd;        /* CPD: only used by the writer for ic_{z*cpd/ppd} */
     double boxsize;     /* BoxSize */
@@ -114,8 +115,8 @@ typedef int (*zd_slab_cb)(void *user, int64_t z, int64_t n_records, const void *
 int zd_generate(const zd_params *p, const zd_pk *pk, const double *eig, int64_t eig_ppd, zd_slab_cb cb,
                 void *user, zd_stats *out);
 
-/* Smallest power-of-two stream factor R whose block store (ppd^3*16*narray/R/nranks bytes, doubled for
- * nranks > 1: send + receive) fits in budget_bytes; -1 if none. */
+/* Smallest power-of-two stream factor R whose block store of one pass (+ the y->x ring of the field store, + the exchange
+ * ring for nranks > 1) fits in budget_bytes; -1 if none. */
 int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes);
 
 /* ---- staged API (device pointers) for one-process-per-GPU drivers and for tests ---------------
