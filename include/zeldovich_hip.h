@@ -28,7 +28,7 @@ enum { ZD_FMT_ZEL = 0, ZD_FMT_RVZEL = 1, ZD_FMT_RVDOUBLEZEL = 2, ZD_FMT_ZELSIMPL
 typedef struct zd_params {
     int64_t ppd;        /* cbrt(NP): a power of two in [32, 8192], or 2^a 3^b (a >= 5, b <= 3, <= 6912; ZA without
                          * ZD_qdensity on one rank: the composite-transform kernels) */
-    int32_t numblock;   /* ZD_NumBlock: accepted for compatibility; v2 output does not depend on it */
+    int32_t numblock;   /* ZD_NumBlock: v2 output does not depend on it; version 1: PPD / numblock random streams */
     int32_t cpd;        /* CPD: only used by the writer for ic_{z*cpd/ppd} */
     double boxsize;     /* BoxSize */
     double fundamental; /* 2 pi / boxsize */
@@ -55,6 +55,12 @@ typedef struct zd_params {
     int32_t exchange_planes; /* store planes per exchange group between ranks (0 = ~4 GB ring slots) */
     /* --- local primordial non-Gaussianity (include/parameters.h:56-58); f_NL = 0 disables the path --- */
     double f_NL, n_s, Omega_M;
+    /* --- ZD_Version (include/parameters.h:67-72): 0 or 2 = the pcg64 counter streams; 1 = the legacy phases: one
+     * gsl_rng_mt19937 per yres (seed + yres) with rejection sampling (src/power_spectrum.cpp:18-25,310-332), which makes
+     * the field depend on `numblock` — pass the value AFTER the reader's adjustment numblock = numblock * k_cutoff + .5
+     * (src/parameters.cpp:129-141; zd_read_params does it) --- */
+    int32_t version;
+    int32_t reserved_;
 } zd_params;
 
 /* zd_params.store_mode */
@@ -223,6 +229,9 @@ int zd_test_modes(const zd_params *p, const zd_pk *pk, int64_t n, const int32_t 
 /* the same through the arithmetic the production generator k_genf uses (LDS-table ln / exp / sincos / spline segments,
  * integer zero rule, Newton reciprocal): out[3*i] = {Re D, Im D, fundamental / |k|^2}; ky >= 0 */
 int zd_test_modes_table(const zd_params *p, const zd_pk *pk, int64_t n, const int32_t *kxyz, double *out);
+/* ZD_Version = 1: the first 624 * nblocks words of gsl_rng_mt19937 seeded with `seed`, from the workgroup-parallel
+ * regeneration the stream kernel uses (src/power_spectrum.cpp:18-25) */
+int zd_test_v1_words(int64_t seed, int32_t nblocks, uint32_t *out);
 /* batch of `lines` independent length-n inverse FFTs, host in/out [lines][n] complex double;
  * axis_kind 0: the contiguous-line kernel path (x pass), 1: the strided-line path (y/z passes) */
 int zd_test_fft(int32_t n, int64_t lines, int32_t axis_kind, const double *in, double *out);

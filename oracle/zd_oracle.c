@@ -377,6 +377,55 @@ static void cgauss2(const zdo_pk *pk, double wavenumber, zdo_pcg *rng, double ou
     out[1] = R * sin(theta);
 }
 
+/* gsl_rng_mt19937 (see zd_oracle.h): mt_set / mt_get / mt_get_double of gsl rng/mt.c */
+void zdo_mt_seed(zdo_mt *g, unsigned long s) {
+    if (s == 0) s = 4357;
+    g->mt[0] = (uint32_t) (s & 0xffffffffUL);
+    for (int i = 1; i < 624; i++) g->mt[i] = 1812433253U * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t) i;
+    g->mti = 624;
+}
+uint32_t zdo_mt_next(zdo_mt *g) {
+    uint32_t *mt = g->mt;
+    if (g->mti >= 624) {
+        int kk;
+        for (kk = 0; kk < 624 - 397; kk++) {
+            uint32_t y = (mt[kk] & 0x80000000U) | (mt[kk + 1] & 0x7fffffffU);
+            mt[kk]     = mt[kk + 397] ^ (y >> 1) ^ ((y & 1) ? 0x9908b0dfU : 0);
+        }
+        for (; kk < 623; kk++) {
+            uint32_t y = (mt[kk] & 0x80000000U) | (mt[kk + 1] & 0x7fffffffU);
+            mt[kk]     = mt[kk + (397 - 624)] ^ (y >> 1) ^ ((y & 1) ? 0x9908b0dfU : 0);
+        }
+        uint32_t y = (mt[623] & 0x80000000U) | (mt[0] & 0x7fffffffU);
+        mt[623]    = mt[396] ^ (y >> 1) ^ ((y & 1) ? 0x9908b0dfU : 0);
+        g->mti     = 0;
+    }
+    uint32_t k = mt[g->mti++];
+    k ^= k >> 11;
+    k ^= (k << 7) & 0x9d2c5680U;
+    k ^= (k << 15) & 0xefc60000U;
+    k ^= k >> 18;
+    return k;
+}
+double zdo_mt_uniform(zdo_mt *g) { return zdo_mt_next(g) / 4294967296.0; }
+
+/* cgauss<1>: src/power_spectrum.cpp:310-332 (rejection Box-Muller, a variable number of draws per mode) */
+static void cgauss1(const zdo_pk *pk, double wavenumber, zdo_mt *rng, double out[2]) {
+    double Pk = zdo_power(pk, wavenumber);
+    double phase1, phase2, r2;
+    do {
+        phase1 = zdo_mt_uniform(rng) * 2.0 - 1.0;
+        phase2 = zdo_mt_uniform(rng) * 2.0 - 1.0;
+        r2     = phase1 * phase1 + phase2 * phase2;
+    } while (!(r2 < 1.0 && r2 > 0.0));
+    if (pk->fixed_power)
+        r2 = sqrt(Pk / r2);
+    else
+        r2 = sqrt(-Pk * log(r2) / r2);
+    out[0] = phase1 * r2;
+    out[1] = phase2 * r2;
+}
+
 /* ------------------------------------------------------------------------------------------- */
 /* PLT eigenmodes (src/zeldovich.cpp:149-276)                                                  */
 
@@ -612,6 +661,16 @@ static zdo_pcg *make_v2rng(const zdo_params *p) {
     return rng;
 }
 
+/* one mt19937 per yres, seeds seed + i: src/power_spectrum.cpp:18-25 */
+static zdo_mt *make_v1rng(const zdo_params *p) {
+    if (p->version != 1) return NULL;
+    int64_t block = p->ppd / p->numblock;
+    zdo_mt *rng   = (zdo_mt *) malloc(sizeof(zdo_mt) * (size_t) (block > 0 ? block : 1));
+    unsigned long longseed = (unsigned long) (long) p->seed;
+    for (int64_t i = 0; i < block; i++) zdo_mt_seed(&rng[i], longseed + (unsigned long) i);
+    return rng;
+}
+
 typedef struct {
     int64_t ppd, ppdhalf, narray;
     int numblock, block;
@@ -630,7 +689,7 @@ static inline void cset(double *d, double re, double im) {
 /* LoadPlane without the trailing z FFTs: src/zeldovich.cpp:278-503 */
 #define AYZX_PHI(_slab, _a, _y, _z, _x) ((_slab) + 2 * ((int64_t) (_x) + g->ppd * ((_z) + g->ppd * ((_a) + (int64_t) (_y)))))
 
-static void load_plane_modes(const geom *g, const zdo_params *param, const zdo_pk *Pk, zdo_pcg *v2rng,
+static void load_plane_modes(const geom *g, const zdo_params *param, const zdo_pk *Pk, zdo_pcg *v2rng, zdo_mt *v1rng,
                              const double *eig, int64_t eig_ppd, int yblock, int yres, double *slab,
                              double *slabHer, int gen_phi, const double *input_phi_slab) {
     int64_t ppd = g->ppd, ppdhalf = g->ppdhalf;
@@ -673,12 +732,14 @@ static void load_plane_modes(const geom *g, const zdo_params *param, const zdo_p
                     && !(kx == param->one_mode[0] && ky == param->one_mode[1] && kz == param->one_mode[2]))) {
                 D[0] = D[1] = 0.0;
                 nskip++;
-            } else {
+            } else if (!v1rng) {
                 if (nskip) {
                     zdo_pcg_advance(&v2rng[y], 0, (uint64_t) (2 * nskip));
                     nskip = 0;
                 }
                 cgauss2(Pk, kmag, &v2rng[y], D);
+            } else {
+                cgauss1(Pk, kmag, &v1rng[yres], D); /* only inside the k_cutoff region: :365-370 */
             }
             if (k2 == 0.0) k2 = 1.0;
             double ik2 = 1. / k2;
@@ -751,9 +812,11 @@ static void load_plane_modes(const geom *g, const zdo_params *param, const zdo_p
             }
         }
     }
-    zdo_pcg_advance(&v2rng[y], 0, (uint64_t) (2 * nskip));
-    /* the reference's RNG bookkeeping self-check: :478 */
-    assert(zdo_pcg_distance(&checkpoint, &v2rng[y]) == (uint64_t) (2 * ZDO_MAX_PPD * ZDO_MAX_PPD));
+    if (!v1rng) {
+        zdo_pcg_advance(&v2rng[y], 0, (uint64_t) (2 * nskip));
+        /* the reference's RNG bookkeeping self-check: :478 */
+        assert(zdo_pcg_distance(&checkpoint, &v2rng[y]) == (uint64_t) (2 * ZDO_MAX_PPD * ZDO_MAX_PPD));
+    }
 
     /* ky = 0: copy half of the reflected plane back, zero the origin   (:485-503) */
     if (yblock == 0 && yres == 0) {
@@ -938,7 +1001,7 @@ static void load_block_forward(const geom *g, double *arr, int yblock, int zbloc
 }
 
 /* ZeldovichZ: src/zeldovich.cpp:517-601 */
-static int zeldovich_z(const geom *g, const zdo_params *param, const zdo_pk *Pk, zdo_pcg *v2rng, const double *eig,
+static int zeldovich_z(const geom *g, const zdo_params *param, const zdo_pk *Pk, zdo_pcg *v2rng, zdo_mt *v1rng, const double *eig,
                        int64_t eig_ppd, const fft_plan *pl, double *arr, int gen_phi, const geom *gphi,
                        double *phi_arr, zdo_stats *stats) {
     int64_t ppd = g->ppd;
@@ -959,7 +1022,7 @@ static int zeldovich_z(const geom *g, const zdo_params *param, const zdo_pk *Pk,
         for (int yres = 0; yres < g->block; yres++) {
             if (input_phi_slab) /* ForwardFFT_Yonly of the phi plane: :324-326 */
                 forward_fft_first_index(pl, input_phi_slab + 2 * (int64_t) yres * ppd * ppd, n);
-            load_plane_modes(g, param, Pk, v2rng, eig, eig_ppd, yblock, yres, slab, slabHer, gen_phi, input_phi_slab);
+            load_plane_modes(g, param, Pk, v2rng, v1rng, eig, eig_ppd, yblock, yres, slab, slabHer, gen_phi, input_phi_slab);
             int yresHer = g->block - 1 - yres;
             for (int a = 0; a < g->narray; a++) { /* :508-511 */
                 inverse_fft_first_index(pl, AYZX(slab, a, yres, 0, 0), n);
@@ -1032,6 +1095,7 @@ int zdo_run(const zdo_params *param, const zdo_pk *Pk, const double *eig, int64_
     int n       = (int) ppd;
     fft_plan *pl = fft_plan_create(n);
     zdo_pcg *v2rng = make_v2rng(param);
+    zdo_mt *v1rng  = make_v1rng(param);
 
     /* ---- f_NL: phi field, local non-Gaussian transform (src/zeldovich.cpp:945-960) ---- */
     geom gphi = *g;
@@ -1043,7 +1107,7 @@ int zdo_run(const zdo_params *param, const zdo_pk *Pk, const double *eig, int64_
         if (!phi_arr) return 2;
         zdo_stats dummy;
         memset(&dummy, 0, sizeof(dummy));
-        if (zeldovich_z(&gphi, param, Pk, v2rng, eig, eig_ppd, pl, phi_arr, 1, NULL, NULL, &dummy)) return 2;
+        if (zeldovich_z(&gphi, param, Pk, v2rng, v1rng, eig, eig_ppd, pl, phi_arr, 1, NULL, NULL, &dummy)) return 2;
         if (zeldovich_xy_phi(&gphi, param, pl, phi_arr)) return 2;
     }
 
@@ -1057,7 +1121,7 @@ int zdo_run(const zdo_params *param, const zdo_pk *Pk, const double *eig, int64_
     double *slab = (double *) calloc((size_t) len, 2 * sizeof(double));
     if (!arr || !slab) return 2;
 
-    if (zeldovich_z(g, param, Pk, v2rng, eig, eig_ppd, pl, arr, 0, &gphi, phi_arr, stats)) return 2;
+    if (zeldovich_z(g, param, Pk, v2rng, v1rng, eig, eig_ppd, pl, arr, 0, &gphi, phi_arr, stats)) return 2;
     free(phi_arr);
 
     /* ---- ZeldovichXY: src/zeldovich.cpp:611-695 ---- */
@@ -1100,6 +1164,7 @@ int zdo_run(const zdo_params *param, const zdo_pk *Pk, const double *eig, int64_
     free(slab);
     free(arr);
     free(v2rng);
+    free(v1rng);
     fft_plan_destroy(pl);
     return 0;
 }
@@ -1112,13 +1177,14 @@ int zdo_mode_cube(const zdo_params *param, const zdo_pk *Pk, const double *eig, 
     if (check_geom(param, g)) return 1;
     int64_t ppd    = g->ppd;
     zdo_pcg *v2rng = make_v2rng(param);
+    zdo_mt *v1rng  = make_v1rng(param);
     int64_t len    = (int64_t) g->block * ppd * ppd * g->narray;
     double *slab    = (double *) calloc((size_t) len, 2 * sizeof(double));
     double *slabHer = (double *) calloc((size_t) len, 2 * sizeof(double));
     memset(cube, 0, sizeof(double) * 2 * (size_t) (ppd * ppd * ppd * g->narray));
     for (int yblock = 0; yblock < g->numblock / 2; yblock++) {
         for (int yres = 0; yres < g->block; yres++)
-            load_plane_modes(g, param, Pk, v2rng, eig, eig_ppd, yblock, yres, slab, slabHer, 0, NULL);
+            load_plane_modes(g, param, Pk, v2rng, v1rng, eig, eig_ppd, yblock, yres, slab, slabHer, 0, NULL);
         for (int yres = 0; yres < g->block; yres++) {
             for (int which = 0; which < 2; which++) {
                 /* global y index as stored, then the LoadBlock shift (src/block_array.cpp:487-491) */
@@ -1138,6 +1204,7 @@ int zdo_mode_cube(const zdo_params *param, const zdo_pk *Pk, const double *eig, 
     free(slab);
     free(slabHer);
     free(v2rng);
+    free(v1rng);
     return 0;
 }
 

@@ -56,6 +56,8 @@ typedef struct {
     int icformat; /* 0 Zeldovich, 1 RVZel, 2 RVdoubleZel, 3 ZelSimple  (include/output.h:44-49) */
     int nthreads; /* OpenMP threads for the oracle (0 = runtime default) */
     double f_NL, n_s, Omega_M; /* local primordial non-Gaussianity (include/parameters.h:56-58) */
+    int version; /* ZD_Version (include/parameters.h:67-72): 2 (0 = default) pcg64 counter streams; 1 = one mt19937 stream per
+                    yres with rejection sampling, numblock already adjusted as in src/parameters.cpp:129-141 */
 } zdo_params;
 
 typedef struct {
@@ -81,6 +83,18 @@ uint64_t zdo_pcg_next(zdo_pcg *g);
 void zdo_pcg_advance(zdo_pcg *g, uint64_t delta_hi, uint64_t delta_lo);
 uint64_t zdo_pcg_distance(const zdo_pcg *a, const zdo_pcg *b); /* b - a, low 64 bits */
 double zdo_u01(uint64_t r); /* src/power_spectrum.cpp:284-308 */
+
+/* ---- ZD_Version = 1 streams: gsl_rng_mt19937 (src/power_spectrum.cpp:18-25,276-280).  GSL is not under /root/reference
+ * (system package): MT19937 of Matsumoto & Nishimura with the 2002 initialisation, as in gsl rng/mt.c — gsl_rng_set maps
+ * seed 0 to 4357, gsl_rng_uniform = word / 2^32.  Pinned by the published known answer (seed 5489: 10000th word =
+ * 4123659995, the value the C++ standard requires of std::mt19937). ---- */
+typedef struct {
+    uint32_t mt[624];
+    int mti;
+} zdo_mt;
+void zdo_mt_seed(zdo_mt *g, unsigned long seed);
+uint32_t zdo_mt_next(zdo_mt *g);
+double zdo_mt_uniform(zdo_mt *g);
 
 /* ---- spline / power spectrum (include/spline_function.h, src/power_spectrum.cpp) ---- */
 void zdo_spline_build(int n, double *x, double *y, double *y2);

@@ -40,7 +40,7 @@ class Params(C.Structure):
         ("f_cluster", C.c_double), ("qonemode", C.c_int), ("one_mode", C.c_int * 3),
         ("qPLT", C.c_int), ("qPLTrescale", C.c_int), ("PLT_target_z", C.c_double),
         ("z_initial", C.c_double), ("CornerModes", C.c_int), ("icformat", C.c_int),
-        ("nthreads", C.c_int), ("f_NL", C.c_double), ("n_s", C.c_double), ("Omega_M", C.c_double),
+        ("nthreads", C.c_int), ("f_NL", C.c_double), ("n_s", C.c_double), ("Omega_M", C.c_double), ("version", C.c_int),
     ]
 
 
@@ -148,9 +148,12 @@ def blockarray_roundtrip(fn, ppd, numblock, narray, fill=-7.5):
 def make_params(ppd, numblock=2, boxsize=720.0, seed=12346, k_cutoff=1.0, qPLT=0, qPLTrescale=0,
                 PLT_target_z=0.0, z_initial=49.0, f_cluster=1.0, icformat="RVdoubleZel", qdensity=0,
                 qoneslab=-1, qonemode=0, one_mode=(0, 0, 0), CornerModes=0, cpd=None, nthreads=0,
-                f_NL=0.0, n_s=1.0, Omega_M=1.0):
+                f_NL=0.0, n_s=1.0, Omega_M=1.0, version=2):
     p = Params()
     p.ppd = ppd
+    if version == 1 and k_cutoff != 1.0:  # src/parameters.cpp:129-141
+        numblock = int(numblock * k_cutoff + .5)
+    p.version = version
     p.numblock = numblock
     p.cpd = cpd if cpd is not None else ppd
     p.boxsize = boxsize

@@ -7,9 +7,11 @@ ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 kc = float(sys.argv[2]) if len(sys.argv) > 2 else 2.0
 mode = sys.argv[3] if len(sys.argv) > 3 else "auto"
-p = zd.make_params(n, k_cutoff=kc, icformat="RVZel", profile=1, store_mode=mode)
+version = int(sys.argv[4]) if len(sys.argv) > 4 else 2      # 1: legacy mt19937 streams, PPD / NumBlock of them
+numblock = int(sys.argv[5]) if len(sys.argv) > 5 else 2
+p = zd.make_params(n, k_cutoff=kc, icformat="RVZel", profile=1, store_mode=mode, version=version, numblock=numblock)
 t0 = time.time()
 out = zd.generate(p, ps, collect=False)
-print("PPD=%d k_cutoff=%g store=%s: R=%d  %.2f s (library), wall %.1f s; kernel ms %s; dens var %.17g max_disp %s" % (
-    n, kc, mode, out["stream_factor"], out["seconds_total"], time.time() - t0, {k: round(v) for k, v in out["kernel_ms"].items()},
+print("PPD=%d k_cutoff=%g store=%s version=%d NumBlock=%d: R=%d  %.2f s (library), wall %.1f s; kernel ms %s; dens var %.17g max_disp %s" % (
+    n, kc, mode, version, numblock, out["stream_factor"], out["seconds_total"], time.time() - t0, {k: round(v) for k, v in out["kernel_ms"].items()},
     out["density_variance"], out["max_disp"]), flush=True)

@@ -73,3 +73,24 @@ def test_cli_writes_reference_files(tmp_path, oracle, fmt, R, qd, ngpu):
     if qd:
         dens = np.fromfile(out / ("density%d" % n), dtype=np.float32).reshape(n, n, n)
         assert np.abs(dens - ref["density"]).max() <= 1e-6 * np.abs(ref["density"]).max()
+
+
+def test_cli_version1(tmp_path, oracle):
+    """`ZD_Version = 1` parameter files (legacy phases; NumBlock scaled by ZD_k_cutoff as src/parameters.cpp:129-141)"""
+    n, cpd = 64, 5
+    out = tmp_path / "ic"
+    out.mkdir()
+    par = tmp_path / "v1.par"
+    text = PAR % dict(cpd=cpd, fmt="RVdoubleZel", out=out, np=n ** 3, pk=WMAP, qd=0, R=2)
+    par.write_text(text.replace("ZD_Version = 2", "ZD_Version = 1").replace("ZD_NumBlock = 2", "ZD_NumBlock = 4") + "ZD_k_cutoff = 2.0\n")
+    r = subprocess.run([EXE, str(par)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "ZD_Version = 1" in r.stderr and "NumBlock=8" in r.stderr
+    pk = oracle.pk_from_file(WMAP, 720.0)
+    ref = oracle.run(oracle.make_params(n, numblock=4, icformat="RVdoubleZel", cpd=cpd, k_cutoff=2.0, version=1), pk)
+    dt = oracle.RECORD_DTYPES["RVdoubleZel"]
+    for f in sorted(set(z * cpd // n for z in range(n))):
+        zs = [z for z in range(n) if z * cpd // n == f]
+        got = np.fromfile(out / ("ic_%d" % f), dtype=dt).reshape(len(zs), n, n)
+        want = ref["records"][zs]
+        assert np.abs(got["d"] - want["d"]).max() <= 1e-10 * np.abs(want["d"]).max()

@@ -104,7 +104,7 @@ def _compare(zd, oracle, ps, opk, n, fmt="RVdoubleZel", eig=None, tie_ok=False, 
     okw.pop("exchange_planes", None)
     if "corner_modes" in okw:
         okw["CornerModes"] = okw.pop("corner_modes")
-    op = oracle.make_params(n, numblock=2, icformat=fmt, **okw)
+    op = oracle.make_params(n, numblock=okw.pop("numblock", 2), icformat=fmt, **okw)
     got = zd.generate(p, ps, eig=eig)
     ref = oracle.run(op, opk, eig=eig, eig_ppd=0 if eig is None else eig.shape[0],
                      want_density=bool(kw.get("qdensity", 0)))
@@ -593,3 +593,66 @@ def test_non_power_of_two_oversampling_invariance(zd, ps):
     b = zd.generate(zd.make_params(1152, icformat="RVZel", stream_factor=8), ps, collect=False)
     assert abs(a["density_variance"] - b["density_variance"]) <= 1e-11 * a["density_variance"]
     assert np.abs(a["max_disp"] - b["max_disp"]).max() <= 1e-11 * np.abs(a["max_disp"]).max()
+
+
+# ---- ZD_Version = 1: legacy mt19937 streams with rejection sampling ----
+@pytest.mark.parametrize("seed", [12346, 5489, 0, 2 ** 32 + 7])
+def test_v1_stream_words(zd, seed):
+    """the workgroup-parallel MT19937 regeneration == the serial generator: numpy's RandomState(int) uses the same
+    init_genrand seeding as gsl_rng_set (gsl maps seed 0 to 4357 and keeps the low 32 bits); seed 5489 carries the published
+    known answer (10000th word = 4123659995)"""
+    w = zd.test_v1_words(seed, 17)
+    eff = 4357 if seed == 0 else seed & 0xffffffff
+    ref = np.random.RandomState(eff).randint(0, 2 ** 32, size=w.size, dtype=np.uint64).astype(np.uint32)
+    assert np.array_equal(w, ref)
+    if seed == 5489:
+        assert int(w[9999]) == 4123659995
+
+
+@pytest.mark.parametrize("n,kw", [
+    (64, dict(numblock=4)),                                              # 16 streams, field store
+    (128, dict(numblock=2, stream_factor=4)),                            # 64 streams replayed for every pass
+    (64, dict(numblock=8, store_mode="reference", stream_factor=2)),     # 8 streams: slab rows share streams
+    (128, dict(numblock=64, store_mode="packed")),                       # 2 streams serving 32 rows each
+    (128, dict(numblock=4, k_cutoff=2.0, stream_factor=2)),              # NumBlock -> 8; only the modes inside the cutoff draw
+    (64, dict(numblock=4, qdensity=1, fmt="RVZel")),
+    (64, dict(numblock=4, corner_modes=1)),
+    (64, dict(numblock=4, plt=True)),
+    (128, dict(numblock=4, ngpu=2, stream_factor=2)),                    # streams split over the ranks (ky mod G)
+    (128, dict(numblock=16, ngpu=4, store_mode="reference")),
+])
+def test_version1_vs_oracle(zd, oracle, ps, opk, n, kw):
+    """ZD_Version = 1 end to end against the oracle's restatement of cgauss<1> / gsl_rng_mt19937 (src/power_spectrum.cpp:18-25,
+    310-332; zeldovich.cpp:365-370): the n-th live mode of stream yres takes the n-th accepted pair"""
+    kw = dict(kw)
+    fmt = kw.pop("fmt", "RVdoubleZel")
+    eig = None
+    if kw.pop("plt", False):
+        eig = oracle.synthetic_eigenmodes(32)
+        kw.update(qPLT=1, qPLTrescale=1, PLT_target_z=5.0, f_cluster=0.97)
+    got, _ = _compare(zd, oracle, ps, opk, n, fmt=fmt, eig=eig, version=1, **kw)
+    assert sorted(got["planes_seen"]) == list(range(n))
+
+
+def test_version1_fixed_power_and_one_mode(zd, oracle, wmap_path):
+    ps2 = zd.PowerSpectrum.from_file(wmap_path, 720.0, fix_to_mean=1)
+    opk2 = oracle.pk_from_file(wmap_path, 720.0, fix_to_mean=1)
+    _compare(zd, oracle, ps2, opk2, 64, version=1, numblock=4)
+    _compare(zd, oracle, ps2, opk2, 32, version=1, numblock=2, qonemode=1, one_mode=(1, 2, -3), tie_ok=True)
+
+
+def test_version1_properties(zd, ps):
+    """what the reference documents about version 1 (include/zeldovich.h:27-28, parameters.cpp:129-141): the phases depend on
+    ZD_NumBlock, and with NumBlock scaled by k_cutoff an oversampled grid reproduces the coarse one at the shared sites"""
+    a = zd.generate(zd.make_params(128, numblock=4, version=1), ps)["records"]["d"]
+    b = zd.generate(zd.make_params(256, numblock=4, version=1, k_cutoff=2.0, stream_factor=2), ps)["records"]["d"][::2, ::2, ::2]
+    assert np.abs(a - b).max() <= 1e-12 * np.abs(a).max()
+    c = zd.generate(zd.make_params(128, numblock=2, version=1), ps)["records"]["d"]
+    assert np.abs(a - c).max() > 0.1 * np.abs(a).max()
+    d = zd.generate(zd.make_params(128, numblock=4), ps)["records"]["d"]      # version 2: other phases
+    assert np.abs(a - d).max() > 0.1 * np.abs(a).max()
+
+
+def test_version1_with_fnl_rejected(zd, ps):
+    with pytest.raises(RuntimeError):
+        zd.generate(zd.make_params(64, numblock=4, version=1, f_NL=10.0, n_s=0.96, Omega_M=0.3), ps)

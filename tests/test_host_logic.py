@@ -62,7 +62,8 @@ def test_params_from_file(zd, tmp_path):
 
 @pytest.mark.parametrize("mutation,ok", [
     (("ZD_Version = 2", ""), False),                    # ZD_Version must be given
-    (("ZD_Version = 2", "ZD_Version = 1"), False),      # v1 (GSL streams) is out of scope
+    (("ZD_Version = 2", "ZD_Version = 3"), False),      # parameters.cpp:111
+    (("ZD_Version = 2", "ZD_Version = 1\nZD_k_cutoff = 2.0"), True),  # legacy streams: NumBlock scaled by k_cutoff (:129-141)
     (("NP = 2097152", "NP = 2097153"), False),          # ppd^3 != NP
     (("BoxSize = 720", ""), False),                     # MUST_DEFINE
     (("ZD_Pk_sigma = 0.0210839935761", "ZD_Pk_sigma = 0.02\nZD_Pk_sigma_ratio = 1.0"), False),
@@ -80,6 +81,10 @@ def test_params_validation(zd, tmp_path, mutation, ok):
         p, s = zd.params_from_file(par)
         if "Seed" in mutation[1]:
             assert p.seed == -7
+        if "ZD_Version = 1" in mutation[1]:
+            assert p.version == 1 and p.numblock == 8
+        else:
+            assert p.version == 2 and p.numblock == 4
     else:
         with pytest.raises(ValueError):
             zd.params_from_file(par)

@@ -435,3 +435,84 @@ def test_fnl_path_vs_independent_numpy(oracle):
     # and the non-Gaussian term really changes the field
     lin = oracle.run(oracle.make_params(n, numblock=2, qdensity=2), pk, want_planes=True)["planes"][:, 0].real
     assert np.abs(got - lin).max() > 1e-4 * np.abs(lin).max()
+
+
+# ---- ZD_Version = 1 (legacy streams): gsl_rng_mt19937 + rejection Box-Muller ------------------------------------------
+class _Mt(C.Structure):
+    _fields_ = [("mt", C.c_uint32 * 624), ("mti", C.c_int)]
+
+
+def test_mt19937_known_answers(oracle):
+    """GSL is not under /root/reference; gsl_rng_mt19937 is MT19937 with the 2002 initialisation (gsl rng/mt.c).  Published
+    known answer: seed 5489 -> 10000th word 4123659995 (the value ISO C++ requires of std::mt19937); numpy's legacy
+    RandomState(int) seeds with the same init_genrand; gsl_rng_set maps seed 0 to 4357."""
+    L = oracle.lib()
+    L.zdo_mt_seed.argtypes = [C.POINTER(_Mt), C.c_ulong]
+    L.zdo_mt_next.restype = C.c_uint32
+    L.zdo_mt_next.argtypes = [C.POINTER(_Mt)]
+    L.zdo_mt_uniform.restype = C.c_double
+    L.zdo_mt_uniform.argtypes = [C.POINTER(_Mt)]
+    g = _Mt()
+    L.zdo_mt_seed(C.byref(g), 5489)
+    w = [L.zdo_mt_next(C.byref(g)) for _ in range(10000)]
+    assert w[0] == 3499211612 and w[9999] == 4123659995
+    for seed, eff in ((12346, 12346), (0, 4357), (2 ** 32 + 7, 7)):
+        L.zdo_mt_seed(C.byref(g), seed)
+        ref = np.random.RandomState(eff).randint(0, 2 ** 32, size=2000, dtype=np.uint64)
+        assert [L.zdo_mt_next(C.byref(g)) for _ in range(2000)] == [int(v) for v in ref]
+    L.zdo_mt_seed(C.byref(g), 12346)
+    assert L.zdo_mt_uniform(C.byref(g)) == 3990012703 / 4294967296.0  # gsl_rng_uniform: word / 2^32 in [0, 1)
+
+
+def test_version1_vs_independent_numpy(oracle):
+    """the `ver == 1` branch (src/zeldovich.cpp:365-370, power_spectrum.cpp:18-25,310-332) written independently: stream yres
+    = RandomState(seed + yres) serves rows yres + yblock*block in yblock order; inside a row z-major / x-minor, only modes
+    that survive the zero rule draw; pairs of uniforms 2u - 1 until 0 < r2 < 1; D = (p1, p2) sqrt(-P ln r2 / r2)"""
+    n, nb, box, seed = 16, 4, 720.0, 12346
+    pk = oracle.pk_from_file(WMAP, box)
+    p = oracle.make_params(n, numblock=nb, boxsize=box, seed=seed, version=1)
+    cube = oracle.mode_cube(p, pk)  # [a][ky][kz][kx], a = 0: D + i F_x ... use the density row below
+    block, half = n // nb, n // 2
+    fund = 2 * np.pi / box
+    k2cut = (np.pi / (box / n)) ** 2
+    streams = [np.random.RandomState(seed + i) for i in range(block)]
+    L = oracle.lib()
+    D = np.zeros((n, n, n), dtype=np.complex128)  # [ky][kz][kx], half-space rows
+    for yblock in range(nb // 2):
+        for yres in range(block):
+            y = yres + yblock * block
+            rs = streams[yres]
+            for z in range(n):
+                kz = z - n if z > half else z
+                for x in range(n):
+                    kx = x - n if x > half else x
+                    k2 = (kx * kx + y * y + kz * kz) * fund * fund
+                    if max(abs(kx), abs(y), abs(kz)) == half or k2 >= k2cut:
+                        continue
+                    while True:
+                        u = rs.randint(0, 2 ** 32, size=2, dtype=np.uint64) / 4294967296.0
+                        p1, p2 = u[0] * 2.0 - 1.0, u[1] * 2.0 - 1.0
+                        r2 = p1 * p1 + p2 * p2
+                        if 0.0 < r2 < 1.0:
+                            break
+                    q = np.sqrt(-L.zdo_power(C.byref(pk), float(np.sqrt(k2))) * np.log(r2) / r2)
+                    D[y, z, x] = complex(p1 * q, p2 * q)
+    # density-only run: the packed cube holds D itself for the half-space rows
+    pd = oracle.make_params(n, numblock=nb, boxsize=box, seed=seed, version=1, qdensity=2)
+    cd = oracle.mode_cube(pd, pk)[0]
+    for y in range(1, half):
+        assert np.abs(cd[y] - D[y]).max() <= 1e-15 * np.abs(D).max(), y
+    assert cube.shape[0] == 2
+
+
+def test_version1_properties(oracle):
+    """include/zeldovich.h:27-28: version-1 phases depend on ZD_NumBlock; parameters.cpp:129-141: NumBlock scaled by k_cutoff
+    keeps an oversampled grid on the coarse grid's phases"""
+    pk = oracle.pk_from_file(WMAP, 720.0)
+    a = oracle.run(oracle.make_params(32, numblock=4, version=1), pk)["records"]["d"]
+    b = oracle.run(oracle.make_params(64, numblock=4, version=1, k_cutoff=2.0), pk)["records"]["d"][::2, ::2, ::2]
+    assert np.abs(a - b).max() < 1e-14
+    c = oracle.run(oracle.make_params(32, numblock=2, version=1), pk)["records"]["d"]
+    assert np.abs(a - c).max() > 0.1 * np.abs(a).max()
+    d = oracle.run(oracle.make_params(32, numblock=4, version=1, nthreads=1), pk)["records"]["d"]
+    assert np.array_equal(a, d)  # one stream per yres: no dependence on the thread count

@@ -35,6 +35,7 @@ class ZdParams(C.Structure):
         ("stream_factor", C.c_int32), ("profile", C.c_int32),
         ("store_mode", C.c_int32), ("serial_z", C.c_int32), ("ngpu", C.c_int32), ("exchange_planes", C.c_int32),
         ("f_NL", C.c_double), ("n_s", C.c_double), ("Omega_M", C.c_double),
+        ("version", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -77,7 +78,7 @@ EXPORTED_SYMBOLS = [
     "zd_plan_plane_z", "zd_plan_stage_z", "zd_plan_stage_y", "zd_plan_stage_x", "zd_plan_stats", "zd_comm_unique_id", "zd_comm_create", "zd_comm_destroy", "zd_plan_ring_bytes", "zd_plan_run_pass",
     "zd_params_from_file", "zd_pk_create_from_file", "zd_pk_create_powerlaw", "zd_pk_power",
     "zd_pk_sigmaR", "zd_pk_destroy", "zd_load_eigmodes", "zd_free", "zd_test_draws", "zd_test_modes",
-    "zd_test_modes_table", "zd_test_fft",
+    "zd_test_modes_table", "zd_test_v1_words", "zd_test_fft",
 ]
 STORE_MODES = {"auto": 0, "reference": 1, "packed": 2, "fields": 3}  # zd_params.store_mode (ZD_STORE_*)
 
@@ -140,6 +141,7 @@ def load_library():
     L.zd_test_draws.argtypes = [i64, i64, vp, vp]
     L.zd_test_modes.argtypes = [C.POINTER(ZdParams), C.POINTER(ZdPk), i64, vp, vp]
     L.zd_test_modes_table.argtypes = [C.POINTER(ZdParams), C.POINTER(ZdPk), i64, vp, vp]
+    L.zd_test_v1_words.argtypes = [i64, C.c_int32, vp]
     L.zd_test_fft.argtypes = [i32, i64, i32, vp, vp]
     _lib = L
     return L
@@ -148,10 +150,15 @@ def load_library():
 def make_params(ppd, numblock=2, boxsize=720.0, seed=12346, k_cutoff=1.0, qPLT=0, qPLTrescale=0,
                 PLT_target_z=0.0, z_initial=49.0, f_cluster=1.0, icformat="RVdoubleZel", qdensity=0,
                 qoneslab=-1, qonemode=0, one_mode=(0, 0, 0), corner_modes=0, cpd=None, stream_factor=0,
-                profile=0, f_NL=0.0, n_s=1.0, Omega_M=1.0, store_mode="auto", serial_z=0, ngpu=0, exchange_planes=0):
-    """Parameters with the derived quantities of Parameters::setup (src/parameters.cpp:172-174)."""
+                profile=0, f_NL=0.0, n_s=1.0, Omega_M=1.0, store_mode="auto", serial_z=0, ngpu=0, exchange_planes=0,
+                version=2):
+    """Parameters with the derived quantities of Parameters::setup (src/parameters.cpp:172-174); version = 1 (legacy
+    mt19937 streams) adjusts NumBlock by k_cutoff as the reader does (src/parameters.cpp:129-141)."""
     p = ZdParams()
     p.ppd = ppd
+    if version == 1 and k_cutoff != 1.0:
+        numblock = int(numblock * k_cutoff + .5)
+    p.version = version
     p.numblock = numblock
     p.cpd = cpd if cpd is not None else ppd
     p.boxsize = boxsize
@@ -431,6 +438,15 @@ def test_modes_table(params, ps, kxyz):
     if L.zd_test_modes_table(C.byref(params), C.byref(ps.pk), k.shape[0], k.ctypes.data, out.ctypes.data):
         raise RuntimeError("zd_test_modes_table failed")
     return out[:, 0] + 1j * out[:, 1], out[:, 2]
+
+
+def test_v1_words(seed, nblocks):
+    """first 624 * nblocks words of the ZD_Version = 1 stream generator (gsl_rng_mt19937) for `seed`"""
+    L = load_library()
+    out = np.zeros(624 * nblocks, dtype=np.uint32)
+    if L.zd_test_v1_words(int(seed), int(nblocks), out.ctypes.data):
+        raise RuntimeError("zd_test_v1_words failed")
+    return out
 
 
 def test_fft(x, axis_kind):

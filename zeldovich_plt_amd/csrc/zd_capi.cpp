@@ -352,6 +352,16 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
                 (long long) N, R, nranks);
         return 1;
     }
+    const bool v1 = p->version == 1;  // legacy mt19937 streams, one per yres (power_spectrum.cpp:18-25)
+    if (p->version != 0 && p->version != 1 && p->version != 2) {
+        fprintf(stderr, "zeldovich_hip: ZD_Version = %d (1 or 2 expected)\n", p->version);
+        return 1;
+    }
+    if (v1 && (p->numblock <= 0 || N % p->numblock || (N / p->numblock) % nranks || phi_mode != 0 || phik != nullptr)) {
+        fprintf(stderr, "zeldovich_hip: ZD_Version = 1 needs ZD_NumBlock dividing PPD, PPD/NumBlock streams divisible by the number of "
+                        "ranks (%d), and ZD_f_NL = 0\n", nranks);
+        return 1;
+    }
     zd_plan *pl = new zd_plan;
     pl->p       = *p;
     pl->rank    = rank;
@@ -709,9 +719,22 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
             rows = std::max(zd::FIELD_RB, rows / zd::FIELD_RB * zd::FIELD_RB);
             while (pl->Hq % rows) rows -= zd::FIELD_RB;
         }
+        if (v1) {  // the accepted pairs of a slab: N^2 x 16 B per row, <= ~4 GB
+            const int minr = zd::pack_is_fields(pl->pack) ? zd::FIELD_RB : 1;
+            rows = std::max<int64_t>(minr, std::min<int64_t>(rows, ((int64_t) 4 << 30) / (N * N * 16)));
+            if (zd::pack_is_fields(pl->pack)) rows = rows / zd::FIELD_RB * zd::FIELD_RB;
+        }
         while (pl->Hq % rows) rows--;
         pl->slab_rows = rows;
-        pl->overlap   = p->serial_z == 0;
+        pl->overlap   = p->serial_z == 0 && !v1;  // version 1: the streams are sequential in ky
+        if (v1) {
+            pl->v1_block = (int) (N / p->numblock);
+            PLCHECK(hipMalloc((void **) &pl->d_v1streams, sizeof(zd::V1Stream) * (size_t) pl->v1_block));
+            PLCHECK(hipMalloc((void **) &pl->d_v1dev, (size_t) rows * N * N * sizeof(double2)));
+            PLCHECK(hipMalloc((void **) &pl->d_v1err, sizeof(int)));
+            PLCHECK(hipMemset(pl->d_v1err, 0, sizeof(int)));
+            g.v1dev = pl->d_v1dev;
+        }
         // k_genf is a persistent kernel: a few workgroups per CU pull tiles from a counter (one per launch).  With
         // the second stream active the grid is kept small enough that a k_zfft workgroup (64 KB LDS, 2 waves/SIMD)
         // always fits beside the generator's waves on every CU.
@@ -779,6 +802,9 @@ void zd_plan_destroy(zd_plan *pl) {
     hipFree(pl->d_red);
     hipFree(pl->d_fieldrows);
     hipFree(pl->d_ring);
+    hipFree(pl->d_v1streams);
+    hipFree(pl->d_v1dev);
+    hipFree(pl->d_v1err);
     for (cplx *y : pl->d_Y) hipFree(y);
     if (pl->s_gen) hipStreamDestroy(pl->s_gen);
     if (pl->s_fft) hipStreamDestroy(pl->s_fft);
@@ -824,10 +850,20 @@ int zd_plan_stage_z(zd_plan *pl, int residue, void *d_send, void *hip_stream) {
     const int zspan = span_begin(pl, ZD_K_ZSTAGE, st);
     if (!pl->overlap) {
         HIPCHECK(hipMemsetAsync(pl->d_tilectr, 0, sizeof(unsigned) * pl->n_tilectr, st));
+        // ZD_Version = 1: every pass replays the streams from their seeds; rows that share a stream (block/G apart in
+        // this rank's row order) are drawn by successive launches
+        if (pl->v1_block && zd::launch_v1_seed((unsigned long long) pl->p.seed, pl->v1_block, pl->d_v1streams, st)) return 1;
         int slab = 0;
         for (int r0 = 0; r0 < pl->Hq; r0 += pl->slab_rows, slab++) {
             const int nky = std::min(pl->slab_rows, pl->Hq - r0);
             tick(pl, ZD_K_GEN, st, true);
+            if (pl->v1_block) {
+                const int group = pl->v1_block / G;
+                for (int i0 = 0; i0 < nky; i0 += group)
+                    if (zd::launch_v1_draw(pl->g, pl->v1_block, ky_first + G * (r0 + i0), G, std::min(group, nky - i0), pl->d_v1streams,
+                                           pl->d_v1dev + (size_t) i0 * pl->N * pl->N, pl->d_v1err, st))
+                        return 1;
+            }
             if (zd::launch_gen(pl->g, pl->J, pl->jobs, pl->S, ky_first + G * r0, nky, pl->L, residue, residue2, pl->d_twN, pl->d_Y[0],
                                pl->d_tilectr + slab, pl->gen_max_wgs, st))
                 return 1;
@@ -1004,6 +1040,14 @@ int zd_plan_stats(zd_plan *pl, zd_stats *out) {
     out->bytes_intermediate = zd_plan_exchange_bytes(pl);
     out->stream_factor      = pl->R;
     out->modes_cached       = 0;  // modes are regenerated per residue pass (counter-addressed RNG)
+    if (pl->d_v1err) {  // ZD_Version = 1: a stream that stopped accepting pairs (k_v1_draw's guard)
+        int e = 0;
+        HIPCHECK(hipMemcpy(&e, pl->d_v1err, sizeof(int), hipMemcpyDeviceToHost));
+        if (e) {
+            fprintf(stderr, "zeldovich_hip: ZD_Version = 1 stream generator failed\n");
+            return 1;
+        }
+    }
     return 0;
 }
 
@@ -1331,6 +1375,24 @@ int zd_test_modes_table(const zd_params *p, const zd_pk *pk, int64_t n, const in
     hipFree(d_k);
     hipFree(d_o);
     zd_plan_destroy(pl);
+    return rc;
+}
+
+int zd_test_v1_words(int64_t seed, int32_t nblocks, uint32_t *out) {
+    zd::V1Stream *d_s = nullptr;
+    uint32_t *d_o = nullptr;
+    int rc = 1;
+    do {
+        if (nblocks <= 0) break;
+        if (hipMalloc((void **) &d_s, sizeof(zd::V1Stream)) != hipSuccess) break;
+        if (hipMalloc((void **) &d_o, sizeof(uint32_t) * 624 * (size_t) nblocks) != hipSuccess) break;
+        if (zd::launch_v1_seed((unsigned long long) seed, 1, d_s, 0)) break;
+        if (zd::launch_test_v1_words(d_s, nblocks, d_o, 0)) break;
+        if (hipMemcpy(out, d_o, sizeof(uint32_t) * 624 * (size_t) nblocks, hipMemcpyDeviceToHost) != hipSuccess) break;
+        rc = 0;
+    } while (0);
+    hipFree(d_s);
+    hipFree(d_o);
     return rc;
 }
 

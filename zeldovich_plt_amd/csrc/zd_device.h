@@ -55,6 +55,18 @@ struct GenConst {
     int accum_var;
     // RNG: state at the start of each ky plane (== reference v2rng[ky], power_spectrum.cpp:30-36)
     const zdpcg::u128 *row_state;
+    // ZD_Version = 1 (zd_kernels_v1.hip): the accepted (phase1, phase2) pairs of cgauss<1> for the rows of the slab being
+    // generated, [row of the slab][z][x]; NULL for the version-2 counter streams
+    const double2 *v1dev;
+};
+
+// ZD_Version = 1: one mt19937 stream per yres (src/power_spectrum.cpp:18-25) between two launches of k_v1_draw: the state
+// words at a regeneration boundary and the accepted pairs already drawn past the last mode served
+constexpr int V1_QCAP = 1024;
+struct V1Stream {
+    uint32_t mt[624];
+    uint32_t nq, pad[3];
+    double2 q[V1_QCAP];
 };
 
 // Affine maps used by the generator's z-walk (set per launch geometry)
@@ -232,5 +244,16 @@ struct Reduce {
     unsigned long long maxpos[3][NSLOT];  // bit pattern of max(+v)
     unsigned long long maxneg[3][NSLOT];  // bit pattern of max(-v)
 };
+
+#if defined(__HIPCC__)
+// zero rule of LoadPlane (src/zeldovich.cpp:350-356)
+__device__ __forceinline__ bool mode_is_zero(const GenConst &g, int kx, int ky, int kz, double k2) {
+    const int ax = kx < 0 ? -kx : kx, ay = ky < 0 ? -ky : ky, az = kz < 0 ? -kz : kz;
+    if (ax == g.kmax || az == g.kmax || ay == g.kmax) return true;
+    if (!g.corner_modes && k2 >= g.k2_cutoff) return true;
+    if (g.qonemode && !(kx == g.one_mode[0] && ky == g.one_mode[1] && kz == g.one_mode[2])) return true;
+    return false;
+}
+#endif
 
 }  // namespace zd

@@ -613,10 +613,15 @@ int zd_params_from_file(const char *path, zd_params *p, zd_param_strings *s) {
                 "    these in the parameter file.\n");
         return 1;
     }
-    if (s->version != 2) {
-        fprintf(stderr, "zeldovich (MI355X): only ZD_Version = 2 is supported (ZD_Version = 1 needs GSL mt19937 streams).\n");
+    if (s->version != 1 && s->version != 2) {  // parameters.cpp:111
+        fprintf(stderr, "Invalid Parameters given: assertion `version == 1 || version == 2' failed\n");
         return 1;
     }
+    if (s->version == 1)  // parameters.cpp:113-120
+        fprintf(stderr,
+                "\n*** WARNING: ZD_Version = 1 selected: the phases of this legacy mode depend on ZD_NumBlock.\n"
+                "    Use it only to reproduce old initial conditions; new ones should set ZD_Version = 2.\n\n");
+    p->version = s->version;
     p->ppd = (int64_t) llround(cbrt((double) s->np));
     fprintf(stderr, "Generating ICs for ppd = %lld\n", (long long) p->ppd);
 #define ZD_REQUIRE(cond)                                                             \
@@ -626,6 +631,12 @@ int zd_params_from_file(const char *path, zd_params *p, zd_param_strings *s) {
     }
     ZD_REQUIRE(p->ppd * p->ppd * p->ppd == s->np);
     ZD_REQUIRE(p->ppd <= ZD_MAX_PPD);
+    if (s->version == 1 && p->k_cutoff != 1.) {  // keeps the streams aligned between different PPD (parameters.cpp:129-141)
+        const int numblock_old = p->numblock;
+        p->numblock = (int) (p->numblock * p->k_cutoff + .5);
+        fprintf(stderr, "Note: using k_cutoff=%f means that we are using NumBlock=%d instead of the supplied value of NumBlock=%d\n",
+                p->k_cutoff, p->numblock, numblock_old);
+    }
     ZD_REQUIRE(!(p->boxsize <= 0.0));
     ZD_REQUIRE(!(p->ppd <= 0));
     ZD_REQUIRE(!(p->numblock <= 0));

@@ -94,15 +94,6 @@ __device__ __forceinline__ double pk_power(const GenConst &g, double k2) {  // k
     }
 }
 
-// zero rule of LoadPlane (src/zeldovich.cpp:350-356)
-__device__ __forceinline__ bool mode_is_zero(const GenConst &g, int kx, int ky, int kz, double k2) {
-    const int ax = kx < 0 ? -kx : kx, ay = ky < 0 ? -ky : ky, az = kz < 0 ? -kz : kz;
-    if (ax == g.kmax || az == g.kmax || ay == g.kmax) return true;
-    if (!g.corner_modes && k2 >= g.k2_cutoff) return true;
-    if (g.qonemode && !(kx == g.one_mode[0] && ky == g.one_mode[1] && kz == g.one_mode[2])) return true;
-    return false;
-}
-
 // sin and cos of 2*pi*theta for theta in (0,1]: exact octant reduction (theta*8 is exact), then the
 // fdlibm kernel polynomials on [0, pi/4].  cgauss<2> (power_spectrum.cpp:353-356) evaluates
 // cos/sin(fl(2*M_PI*theta)); the two differ by the rounding of that product, ~4e-16 absolute.
@@ -347,6 +338,22 @@ __global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, JobList 
                     di  = ph.y * M;
                     ik2 = 1.0 / k2v;
                 }
+            } else if (!zero && !mode_is_zero(g, kxm, ky, kzm, k2v) && g.v1dev) {
+                // ZD_Version = 1, cgauss<1> (power_spectrum.cpp:310-332): the accepted pair of this mode, drawn by k_v1_draw
+                const double2 ph = g.v1dev[((long long) kyl * N + zs) * N + xs];
+                const double r2  = __dadd_rn(__dmul_rn(ph.x, ph.x), __dmul_rn(ph.y, ph.y));
+                double Pk;
+                if (g.pk_tab) {
+                    const double2 pv = g.pk_tab[k2i];
+                    Pk  = pv.x;
+                    ik2 = pv.y;
+                } else {
+                    Pk  = pk_power<PLAW>(g, k2v);
+                    ik2 = 1.0 / (k2v == 0.0 ? 1.0 : k2v);
+                }
+                const double q = g.fixed_power ? sqrt(Pk / r2) : sqrt(-Pk * log(r2) / r2);
+                dr = ph.x * q;
+                di = ph.y * q;
             } else if (!zero && !mode_is_zero(g, kxm, ky, kzm, k2v)) {
                 if (g.pk_tab) {  // {P(k), 1/k^2} by integer k^2
                     const double2 pv = g.pk_tab[k2i];
@@ -1921,15 +1928,6 @@ __global__ void k_copy16(const uint4 *__restrict__ in, uint4 *__restrict__ out, 
 // ================================================================================================
 // launchers (C++ linkage inside the library; the C ABI lives in zd_capi.cpp)
 
-#define ZD_LAUNCH_CHECK()                                                                       \
-    do {                                                                                        \
-        hipError_t e__ = hipGetLastError();                                                     \
-        if (e__ != hipSuccess) {                                                                \
-            fprintf(stderr, "zeldovich_hip: launch failed at %s:%d: %s\n", __FILE__, __LINE__,  \
-                    hipGetErrorString(e__));                                                    \
-            return 1;                                                                           \
-        }                                                                                       \
-    } while (0)
 
 namespace zd {
 
@@ -2020,7 +2018,7 @@ int launch_gen(const GenConst &g, const GenJumps &J, const JobList &jobs, const 
 #endif
     // rows ky >= 1 of a production run go through k_genf; everything else through the general kernel
     const int kind = genf_kind(jobs, g.qPLT != 0);
-    const bool fast = g.genf_tab && tile_ctr && !g.phik && !g.gen_phi && !g.qonemode && !ZD_TUNE(g.ablate & 15) && !force_general
+    const bool fast = g.genf_tab && tile_ctr && !g.phik && !g.gen_phi && !g.qonemode && !g.v1dev && !ZD_TUNE(g.ablate & 15) && !force_general
                       && kind >= 0;
     int general_rows = nky;
     if (fast) {

@@ -13,15 +13,6 @@
 using namespace zd;
 using zdfft::cplx;
 
-#define ZD_LAUNCH_CHECK()                                                                       \
-    do {                                                                                        \
-        hipError_t e__ = hipGetLastError();                                                     \
-        if (e__ != hipSuccess) {                                                                \
-            fprintf(stderr, "zeldovich_hip: launch failed at %s:%d: %s\n", __FILE__, __LINE__,  \
-                    hipGetErrorString(e__));                                                    \
-            return 1;                                                                           \
-        }                                                                                       \
-    } while (0)
 
 // ------------------------------------------------------------------------------------------------
 // test kernels: batches of independent lines of length P*Q through the two LDS layouts
@@ -191,6 +182,72 @@ __global__ __launch_bounds__(W *Q *P / E) void k_yfft_fq(FieldLayout F, StoreLay
     }
 }
 
+// x stage + epilogue, three lines per workgroup (PPD <= 5461: 3 N / 16 threads): the arrays of one row side by side; the
+// threads of lines 0 / 1 hold qx, qy of their plane, only qz_r0 + i qz_r1 (line 2) goes through LDS, records leave straight
+// from the registers (the form of k_xfft's field-store path).
+//   grid: (N, planes)   block: 3*Q*P/E
+template <int P, int E, int Q>
+__global__ __launch_bounds__(3 * Q *P / E) void k_xfft_q3(EpiConst ec, const cplx *__restrict__ twP, const cplx *__restrict__ twN,
+                                                        const cplx *__restrict__ twQ, const cplx *__restrict__ ring,
+                                                        int ring_pitch, int z_first, int z_step, char *__restrict__ records,
+                                                        Reduce *__restrict__ red) {
+    constexpr int N = P * Q;
+    using LQ = zdfft::LineQ<P, E, Q, 3, true>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int T = LQ::T, NT = 3 * T * Q;
+    const int t = threadIdx.x % T, c = threadIdx.x / T;
+    const int a = c % 3, n2 = c / 3;
+    const int y = blockIdx.x, pl = blockIdx.y;
+    const cplx *src = ring + ((long long) (pl * 3 + a) * N + y) * ring_pitch;
+    double re[E], im[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const cplx v = src[Q * (t + T * e) + n2];
+        re[e] = v.x;
+        im[e] = v.y;
+    }
+    LQ::run(re, im, t, a, n2, lds, twP, twN, twQ);
+    const int z = z_first + z_step * (int) blockIdx.y;
+    double mp[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
+    const long long plane_rec0 = 2 * (long long) blockIdx.y * N * N;
+    double2 *cz = reinterpret_cast<double2 *>(lds);  // [x] = {qz_r0, qz_r1}
+    if (a == 2) {
+#pragma unroll
+        for (int e = 0; e < E; e++) cz[(t + T * e) + P * n2] = double2{re[e], im[e]};
+    }
+    __syncthreads();
+    if (a < 2) {
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int xx = (t + T * e) + P * n2;
+            const double2 cv = cz[xx];
+            const double pos[3] = {re[e], im[e], a ? cv.y : cv.x};
+            const double vel[3] = {pos[0] * ec.vnorm, pos[1] * ec.vnorm, pos[2] * ec.vnorm};
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                mp[j] = fmax(mp[j], pos[j]);
+                mn[j] = fmax(mn[j], -pos[j]);
+            }
+            if (records) emit_record(records, plane_rec0 + (long long) a * N * N + (long long) y * N + xx, ec, z + a * ec.z_pair, y, xx, pos, vel);
+        }
+    }
+    __syncthreads();
+    for (int j = 0; j < 3; j++) {
+        lds[threadIdx.x * 6 + j]     = mp[j];
+        lds[threadIdx.x * 6 + 3 + j] = mn[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {  // thread j reduces one of the six quantities
+        double m = 0;
+        for (int i = 0; i < NT; i++) m = fmax(m, lds[i * 6 + threadIdx.x]);
+        const int slot = (blockIdx.x + blockIdx.y * 7) % NSLOT;
+        if (threadIdx.x < 3)
+            atomicMax(&red->maxpos[threadIdx.x][slot], dbits(fabs(m)));
+        else
+            atomicMax(&red->maxneg[threadIdx.x - 3][slot], dbits(fabs(m)));
+    }
+}
+
 // x stage + epilogue: one row per workgroup, its three arrays in sequence; the third (qz_r0 + i qz_r1) first and kept in
 // registers, then each (qx + i qy)_r with the records of its plane straight from registers.
 //   grid: (N, planes)   block: Q*P/E
@@ -314,6 +371,18 @@ template <int P, int E, int Q>
 static int launch_xfft_q_t(const EpiConst &ec, const cplx *tw, const void *ring, int ring_pitch, int nplanes, int z_first, int z_step,
                            void *records, Reduce *red, hipStream_t st) {
     constexpr int N = P * Q, threads = Q * P / E;
+    if constexpr (3 * threads <= 1024) {  // three lines per workgroup
+        using LQ3 = zdfft::LineQ<P, E, Q, 3, true>;
+        constexpr size_t dbl = LQ3::LDS_DOUBLES > 2 * N ? LQ3::LDS_DOUBLES : 2 * N;  // FFT scratch, then cz[N] / the reduction
+        const size_t shmem3 = sizeof(double) * (dbl > (size_t) 18 * threads ? dbl : (size_t) 18 * threads);
+        if (shmem3 <= 160 * 1024) {
+            hipFuncSetAttribute((const void *) k_xfft_q3<P, E, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem3);
+            hipLaunchKernelGGL((k_xfft_q3<P, E, Q>), dim3(N, nplanes), dim3(3 * threads), shmem3, st, ec, tw, tw + P, tw + P + N,
+                               (const cplx *) ring, ring_pitch, z_first, z_step, (char *) records, red);
+            ZD_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     const size_t shmem = sizeof(double) * zdfft::LineQ<P, E, Q, 1, true>::LDS_DOUBLES;
     hipFuncSetAttribute((const void *) k_xfft_seq_q<P, E, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
     dim3 grid(N, nplanes), block(threads);

@@ -1,7 +1,18 @@
 // zd_launch.h — host-callable launchers implemented in zd_kernels.hip
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include "zd_device.h"
+
+#define ZD_LAUNCH_CHECK()                                                                       \
+    do {                                                                                        \
+        hipError_t e__ = hipGetLastError();                                                     \
+        if (e__ != hipSuccess) {                                                                \
+            fprintf(stderr, "zeldovich_hip: launch failed at %s:%d: %s\n", __FILE__, __LINE__,  \
+                    hipGetErrorString(e__));                                                    \
+            return 1;                                                                           \
+        }                                                                                       \
+    } while (0)
 
 namespace zd {
 constexpr int GEN_BX = 256;  // threads (consecutive x) per generator workgroup
@@ -45,6 +56,11 @@ int launch_xfft_np2(int N, const EpiConst &ec, const void *tw, const void *ring,
                     void *records, Reduce *red, hipStream_t st);
 int launch_test_fftq(int n, int kind, const void *twP, const void *twN, const void *twQ, const void *in, void *out, long long lines,
                      hipStream_t st);
+// ---- ZD_Version = 1 streams (zd_kernels_v1.hip) ----
+int launch_v1_seed(unsigned long long seed, int block, V1Stream *streams, hipStream_t st);
+int launch_v1_draw(const GenConst &g, int block, int ky0, int ky_stride, int nrows, V1Stream *streams, void *dev, int *err,
+                   hipStream_t st);
+int launch_test_v1_words(V1Stream *streams, int nblocks, uint32_t *out, hipStream_t st);
 int launch_copy16(const void *in, void *out, long long n16, hipStream_t st);
 }  // namespace zd
 

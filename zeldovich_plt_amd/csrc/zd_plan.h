@@ -60,6 +60,11 @@ struct zd_plan {
     hipStream_t s_gen = nullptr, s_fft = nullptr;
     hipEvent_t ev_fork = nullptr;
     bool overlap = true;
+    // ZD_Version = 1 (zd_kernels_v1.hip): mt19937 streams, one per yres; accepted pairs of the slab being generated
+    int v1_block = 0;               // PPD / NumBlock streams (0: version 2)
+    zd::V1Stream *d_v1streams = nullptr;
+    double2 *d_v1dev = nullptr;     // [slab row][z][x]
+    int *d_v1err = nullptr;
     // timing
     std::vector<EventPair> events;
     std::vector<hipEvent_t> pool;
