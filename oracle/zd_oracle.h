@@ -10,6 +10,8 @@
  *   pinned against reference object code (oracle/_ref, built from the reference's own headers):
  *     - pcg64 seeding / stepping / advance / distance  (include/pcg-rng/pcg_random.hpp)
  *     - natural cubic spline build + evaluation         (include/spline_function.h)
+ *     - BlockArray layout, StoreBlock, LoadBlock y shift (src/block_array.cpp + src/STimer.cc, RAM mode) —
+ *       tests/golden/blockarray_kat.json
  *   pinned against the known-answer vectors recorded from a reference run in SURVEY.md §8(c)
  *     (per-mode RNG counters and draws for six modes, seed 12346) — tests/golden/pcg_kat.json
  *   NOT pinned end-to-end ("parity unpinned" for these rows): Box-Muller/P(k) amplitude, PLT
@@ -17,8 +19,11 @@
  *     remaining sources need FFTW3, GSL and flex/bison-generated ParseHeader code, none of which
  *     exist in this image, so the reference cannot be built here and it ships no golden outputs.
  *     Those rows are restated line-by-line from the cited sources and cross-checked by (i) an
- *     independent numpy formulation (tests/test_oracle_independent.py) and (ii) the invariants the
+ *     independent numpy formulation (tests/test_oracle_golden.py) and (ii) the invariants the
  *     reference documents (NumBlock independence, oversampling invariance, fix-to-mean phases).
+ *   ZD_Version = 1 streams: gsl_rng_mt19937 comes from GSL (system package, not under /root/reference): restated from the
+ *     published MT19937 algorithm as gsl rng/mt.c seeds and scales it, pinned by the published known answer
+ *     (seed 5489 -> 10000th word 4123659995) and numpy's RandomState; cgauss<1> is "parity unpinned" like cgauss<2>.
  */
 #ifndef ZD_ORACLE_H
 #define ZD_ORACLE_H
