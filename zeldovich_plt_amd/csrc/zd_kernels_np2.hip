@@ -248,12 +248,15 @@ __global__ __launch_bounds__(3 * Q *P / E) void k_xfft_q3(EpiConst ec, const cpl
     }
 }
 
-// x stage + epilogue: one row per workgroup, its three arrays in sequence; the third (qz_r0 + i qz_r1) first and kept in
-// registers, then each (qx + i qy)_r with the records of its plane straight from registers.
-//   grid: (N, planes)   block: Q*P/E
+// x stage + epilogue where the three lines of a row do not fit one workgroup (PPD > 5461): one line per workgroup, two
+// launches.  Launch 0 (grid (N, planes, 1)) transforms qz_r0 + i qz_r1 (array 2) over its own ring row; launch 1 (grid
+// (N, planes, 2)) transforms (qx + i qy)_r, r = blockIdx.z, and writes the records of its plane straight from the
+// registers, reading qz from the row launch 0 left (one extra ring-row round trip instead of holding a second line's
+// results in registers: that cost 240-450 spilled dwords in every single-launch form tried).
+//   block: Q*P/E
 template <int P, int E, int Q>
 __global__ __launch_bounds__(Q *P / E) void k_xfft_seq_q(EpiConst ec, const cplx *__restrict__ twP, const cplx *__restrict__ twN,
-                                                       const cplx *__restrict__ twQ, const cplx *__restrict__ ring,
+                                                       const cplx *__restrict__ twQ, cplx *ring, int emit,
                                                        int ring_pitch, int z_first, int z_step, char *__restrict__ records,
                                                        Reduce *__restrict__ red) {
     constexpr int N = P * Q;
@@ -262,37 +265,37 @@ __global__ __launch_bounds__(Q *P / E) void k_xfft_seq_q(EpiConst ec, const cplx
     constexpr int T = LQ::T, NT = T * Q;
     const int t = threadIdx.x % T, n2 = threadIdx.x / T;
     const int y = blockIdx.x, pl = blockIdx.y;
-    auto load_fft = [&](int a, double (&re)[E], double (&im)[E]) {
-        const cplx *src = ring + ((long long) (pl * 3 + a) * N + y) * ring_pitch;
+    cplx *czrow = ring + ((long long) (pl * 3 + 2) * N + y) * ring_pitch;
+    const int a = emit ? (int) blockIdx.z : 2;
+    const cplx *src = ring + ((long long) (pl * 3 + a) * N + y) * ring_pitch;
+    double re[E], im[E];
 #pragma unroll
-        for (int e = 0; e < E; e++) {
-            const cplx v = src[Q * (t + T * e) + n2];
-            re[e] = v.x;
-            im[e] = v.y;
-        }
-        LQ::run(re, im, t, 0, n2, lds, twP, twN, twQ);
-    };
-    double cr[E], ci[E];
-    load_fft(2, cr, ci);
+    for (int e = 0; e < E; e++) {
+        const cplx v = src[Q * (t + T * e) + n2];
+        re[e] = v.x;
+        im[e] = v.y;
+    }
+    LQ::run(re, im, t, 0, n2, lds, twP, twN, twQ);
+    if (!emit) {
+#pragma unroll
+        for (int e = 0; e < E; e++) czrow[(t + T * e) + P * n2] = cplx{re[e], im[e]};
+        return;
+    }
     const int z = z_first + z_step * (int) blockIdx.y;
     double mp[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
     const long long plane_rec0 = 2 * (long long) blockIdx.y * N * N;
-#pragma unroll 1
-    for (int w2 = 0; w2 < 2; w2++) {
-        double ar[E], ai[E];
-        load_fft(w2, ar, ai);
 #pragma unroll
-        for (int e = 0; e < E; e++) {
-            const int xx = (t + T * e) + P * n2;
-            const double pos[3] = {ar[e], ai[e], w2 ? ci[e] : cr[e]};
-            const double vel[3] = {pos[0] * ec.vnorm, pos[1] * ec.vnorm, pos[2] * ec.vnorm};
+    for (int e = 0; e < E; e++) {
+        const int xx = (t + T * e) + P * n2;
+        const cplx cv = czrow[xx];
+        const double pos[3] = {re[e], im[e], a ? cv.y : cv.x};
+        const double vel[3] = {pos[0] * ec.vnorm, pos[1] * ec.vnorm, pos[2] * ec.vnorm};
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
-                mp[j] = fmax(mp[j], pos[j]);
-                mn[j] = fmax(mn[j], -pos[j]);
-            }
-            if (records) emit_record(records, plane_rec0 + (long long) w2 * N * N + (long long) y * N + xx, ec, z + w2 * ec.z_pair, y, xx, pos, vel);
+        for (int j = 0; j < 3; j++) {
+            mp[j] = fmax(mp[j], pos[j]);
+            mn[j] = fmax(mn[j], -pos[j]);
         }
+        if (records) emit_record(records, plane_rec0 + (long long) a * N * N + (long long) y * N + xx, ec, z + a * ec.z_pair, y, xx, pos, vel);
     }
     // workgroup reduction through LDS (the workgroup is N/16 threads: not a whole number of waves, so no wave shuffles)
     __syncthreads();
@@ -301,18 +304,14 @@ __global__ __launch_bounds__(Q *P / E) void k_xfft_seq_q(EpiConst ec, const cplx
         lds[threadIdx.x * 6 + 3 + j] = mn[j];
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double a3[3] = {0, 0, 0}, b3[3] = {0, 0, 0};
-        for (int i = 0; i < NT; i++)
-            for (int j = 0; j < 3; j++) {
-                a3[j] = fmax(a3[j], lds[i * 6 + j]);
-                b3[j] = fmax(b3[j], lds[i * 6 + 3 + j]);
-            }
+    if (threadIdx.x < 6) {  // thread j reduces one of the six quantities
+        double m = 0;
+        for (int i = 0; i < NT; i++) m = fmax(m, lds[i * 6 + threadIdx.x]);
         const int slot = (blockIdx.x + blockIdx.y * 7) % NSLOT;
-        for (int j = 0; j < 3; j++) {
-            atomicMax(&red->maxpos[j][slot], dbits(fabs(a3[j])));
-            atomicMax(&red->maxneg[j][slot], dbits(fabs(b3[j])));
-        }
+        if (threadIdx.x < 3)
+            atomicMax(&red->maxpos[threadIdx.x][slot], dbits(fabs(m)));
+        else
+            atomicMax(&red->maxneg[threadIdx.x - 3][slot], dbits(fabs(m)));
     }
 }
 
@@ -385,10 +384,12 @@ static int launch_xfft_q_t(const EpiConst &ec, const cplx *tw, const void *ring,
     }
     const size_t shmem = sizeof(double) * zdfft::LineQ<P, E, Q, 1, true>::LDS_DOUBLES;
     hipFuncSetAttribute((const void *) k_xfft_seq_q<P, E, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
-    dim3 grid(N, nplanes), block(threads);
-    hipLaunchKernelGGL((k_xfft_seq_q<P, E, Q>), grid, block, shmem, st, ec, tw, tw + P, tw + P + N, (const cplx *) ring, ring_pitch,
-                       z_first, z_step, (char *) records, red);
-    ZD_LAUNCH_CHECK();
+    for (int emit = 0; emit < 2; emit++) {
+        dim3 grid(N, nplanes, emit ? 2 : 1), block(threads);
+        hipLaunchKernelGGL((k_xfft_seq_q<P, E, Q>), grid, block, shmem, st, ec, tw, tw + P, tw + P + N, (cplx *) ring, emit, ring_pitch,
+                           z_first, z_step, (char *) records, red);
+        ZD_LAUNCH_CHECK();
+    }
     return 0;
 }
 // the PPDs with a y / x transform: N = P*Q
