@@ -445,6 +445,9 @@ def test_fnl_with_plt(zd, oracle, ps, wmap_path):
     (2, 64, dict(store_mode="reference")),                             # the reference's arrays with Hermitian twins
     (4, 128, dict(stream_factor=2, store_mode="packed")),
     (2, 128, dict(stream_factor=2, plt=True)),
+    (2, 192, dict(stream_factor=2)),                                   # PPD = 2^6 3: 48 planes per rank (composite transforms)
+    (4, 384, dict(stream_factor=4, k_cutoff=2.0, exchange_planes=5)),  # 24 planes per rank in groups of 5
+    (2, 288, dict(stream_factor=2, exchange_planes=7)),                # 2^5 3^2
 ])
 def test_native_multi_gpu_driver(zd, oracle, ps, opk, ngpu, n, kw):
     """ZD_NumGPU > 1 through zd_generate: one host thread per rank, exchange in plane groups + pipelined XY stages inside

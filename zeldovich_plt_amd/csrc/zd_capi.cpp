@@ -293,7 +293,7 @@ int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes
     int R0 = 1;
     if (!p->qPLT && pack_mode(p, 2) != zd::PACK_NONE && N / 2 >= 32 && (N / 2) % nranks == 0) R0 = 2;
     const bool np2 = !is_pow2(N);
-    if (np2 && (nranks != 1 || R0 != 2 || !zd::np2_supported_ppd((int) N))) return -1;
+    if (np2 && (R0 != 2 || !zd::np2_supported_ppd((int) N) || (N / 2) % (nranks * zd::FIELD_RB))) return -1;
     for (int R = R0; N / R >= 32 && N % R == 0; R *= 2) {
         if ((N / R) % nranks) break;
         if (N / R > 4096) continue;  // z-FFT kernels exist up to length 4096
@@ -342,9 +342,9 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         fprintf(stderr, "zeldovich_hip: stream factor %d invalid for PPD %lld\n", R, (long long) N);
         return 1;
     }
-    if (np2 && (nranks != 1 || phi_mode != 0 || phik != nullptr || pack_mode(p, R) != zd::PACK_ZAFIELD)) {
-        fprintf(stderr, "zeldovich_hip: PPD = %lld (not a power of two) runs on the ZA field store only: one rank, ZD_StreamFactor >= 2, no "
-                        "ZD_qdensity / ZD_qPLT / ZD_f_NL / ZD_qoneslab, store_mode auto\n", (long long) N);
+    if (np2 && (phi_mode != 0 || phik != nullptr || pack_mode(p, R) != zd::PACK_ZAFIELD || (N / 2) % (nranks * zd::FIELD_RB))) {
+        fprintf(stderr, "zeldovich_hip: PPD = %lld (not a power of two) runs on the ZA field store only: ZD_StreamFactor >= 2, no "
+                        "ZD_qdensity / ZD_qPLT / ZD_f_NL / ZD_qoneslab, store_mode auto, PPD/2 a multiple of 8 x ranks\n", (long long) N);
         return 1;
     }
     if (nranks < 1 || !is_pow2(nranks) || rank < 0 || rank >= nranks || (N / 2) % nranks || (N / R) % nranks) {
@@ -679,6 +679,7 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         pl->F.lG          = S.lG;
         pl->F.lZq         = 0;
         while ((1 << pl->F.lZq) < pl->Zq) pl->F.lZq++;
+        pl->F.Zq          = pl->Zq;
         pl->F.field_elems = fe;
         pl->F.nfield      = pl->pack == zd::PACK_PLTFIELD ? 6 : 4;
         pl->F.chunk_elems = (int64_t) pl->Zq * pl->F.nfield * fe;

@@ -100,8 +100,9 @@ __global__ __launch_bounds__(NC *FIELD_RB *Q *P / E) void k_zfft_fq(FieldLayout 
     const unsigned pos = ((unsigned) (x < row.split ? x : x - row.gap)) * FIELD_RB + r;
 #pragma unroll
     for (int e = 0; e < E; e++) {
-        const int zl = (t + T * e) + P * n2;  // one rank: every plane is local
-        out[(long long) (zl * F.nfield + (int) blockIdx.z) * F.field_elems + (unsigned) row.base + pos] = cplx{re[e], im[e]};
+        const int z2 = (t + T * e) + P * n2, dst = z2 / F.Zq, zl = z2 - dst * F.Zq;  // destination rank, its local plane
+        out[(long long) dst * F.chunk_elems + (long long) (zl * F.nfield + (int) blockIdx.z) * F.field_elems + (unsigned) row.base + pos]
+            = cplx{re[e], im[e]};
     }
 }
 
@@ -134,8 +135,9 @@ __global__ __launch_bounds__(W *Q *P / E) void k_yfft_fq(FieldLayout F, StoreLay
         const int y = Q * (t + T * e) + n2;
         int kyp = y > N / 2 ? N - y : y;
         kyp = kyp < N / 2 ? kyp : N / 2 - 1;
-        rows[e] = F.rows[kyp / FIELD_RB];
+        rows[e] = F.rows[(kyp >> F.lG) / FIELD_RB];  // row slot kyp / G of the chunk of rank kyp % G
     }
+    const int gmask = (1 << F.lG) - 1;
     constexpr int BATCH = E >= 4 ? 4 : E;
 #pragma unroll
     for (int b = 0; b < E; b += BATCH) {
@@ -150,8 +152,8 @@ __global__ __launch_bounds__(W *Q *P / E) void k_yfft_fq(FieldLayout F, StoreLay
             skip[j] = (2 * y == N) || ((S.prune & 4) && column_is_zero(S, kx, kyp));
             const int split = rows[e].split, gap = rows[e].gap;
             const unsigned off = skip[j] ? 0u : (unsigned) rows[e].base + (unsigned) (xs < split ? xs : xs - gap) * FIELD_RB
-                                                    + (unsigned) (kyp & (FIELD_RB - 1));
-            const cplx *q = p0 + off;
+                                                    + (unsigned) ((kyp >> F.lG) & (FIELD_RB - 1));
+            const cplx *q = p0 + ((long long) (kyp & gmask) * F.chunk_elems + off);
             u[j] = q[0];
             if (two) v[j] = q[d01];
         }
