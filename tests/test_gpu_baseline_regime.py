@@ -120,8 +120,9 @@ def test_table_generator_arithmetic_vs_oracle(zd, oracle, n, box, fix):
 
 
 # ---- (b) full-size exact checks through the oversampling invariant ------------------------------------------------
-def _planes(zd, ps, n, zs, **kw):
-    """records of the z planes `zs` of a PPD = n run: only the passes that hold them are executed"""
+def _planes(zd, ps, n, zs, stride=1, **kw):
+    """records of the z planes `zs` of a PPD = n run: only the passes that hold them are executed; stride > 1: only every
+    stride-th lattice site of a plane leaves the GPU (a PPD = 16384 plane of records is 8.6 GB)"""
     import torch
     p = zd.make_params(n, icformat="Zeldovich", **kw)
     if p.stream_factor <= 0:
@@ -147,8 +148,8 @@ def _planes(zd, ps, n, zs, **kw):
         first = lp // step * step
         plan.stage_x(pass_, store.data_ptr(), first, step, out.data_ptr())
         torch.cuda.synchronize()
-        host = out.cpu().numpy().view(dt).reshape(step, n, n)
-        res[z] = host[lp - first].copy()
+        sel = out.view(step, n, n, dt.itemsize)[lp - first, ::stride, ::stride].contiguous()
+        res[z] = sel.cpu().numpy().view(dt).reshape(n // stride, n // stride).copy()
     info = dict(R=plan.R, passes=plan.passes, narray=plan.narray)
     plan.close()
     del store, out
@@ -176,6 +177,22 @@ def test_oversampled_planes_exact_at_full_size(zd, n):
         err = np.abs(a["d"] - b["d"]).max() / scale
         print("  z", z, "max |d(2n, even sites) - d(n)| / max|d| =", err)
         assert err < (1e-13 if n != 3456 else 1e-12)  # composite transforms: 27-term outer sums
+
+
+def test_ppd16384_k_cutoff4_planes_equal_ppd4096(zd):
+    """PPD = 16384 (beyond the 8192 of BASELINE C5; MAX_PPD = 65536, include/zeldovich.h:34) with ZD_k_cutoff = 4 at every
+    fourth lattice site == PPD = 4096: one plane, records compared exactly"""
+    ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
+    n, z = 4096, 4096 // 2 + 3
+    lo, ilo = _planes(zd, ps, n, [z])
+    hi, ihi = _planes(zd, ps, 4 * n, [4 * z], stride=4, k_cutoff=4.0)
+    print("PPD", n, ilo, "PPD", 4 * n, ihi)
+    a, b = lo[z], hi[4 * z]
+    assert np.array_equal(b["ijk"][..., 0], np.full((n, n), 4 * z))
+    assert np.array_equal(4 * a["ijk"][..., 1:].astype(np.int64), b["ijk"][..., 1:].astype(np.int64))
+    err = np.abs(a["d"] - b["d"]).max() / np.abs(a["d"]).max()
+    print("  max |d(16384, every 4th site) - d(4096)| / max|d| =", err)
+    assert err < 1e-13
 
 
 def test_ppd2048_plt_store_and_stream_invariance(zd, oracle):

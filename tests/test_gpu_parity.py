@@ -82,7 +82,7 @@ def test_mode_amplitudes(zd, oracle, ps, opk):
     assert err < 1e-13
 
 
-@pytest.mark.parametrize("n", [32, 64, 128, 256, 512, 1024, 2048, 4096, 8192])
+@pytest.mark.parametrize("n", [32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384])
 @pytest.mark.parametrize("kind", [0, 1])
 def test_fft_lines(zd, n, kind):
     """the register/LDS FFT engine vs numpy (unnormalised inverse DFT), both LDS layouts"""

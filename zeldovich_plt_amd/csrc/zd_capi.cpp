@@ -297,6 +297,7 @@ int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes
     for (int R = R0; N / R >= 32 && N % R == 0; R *= 2) {
         if ((N / R) % nranks) break;
         if (N / R > 4096) continue;  // z-FFT kernels exist up to length 4096
+        if (N > 4096 && N / R > 2048) continue;  // the field store's z FFT stops at 2048 and PPD > 4096 has no other store worth using
         if (np2 && !zd::np2_supported_zlen((int) (N / R))) {
             if (N / R < 48) break;
             continue;
@@ -327,8 +328,8 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
                           int phi_mode, const cplx *phik, zd_plan **out) {
     const int64_t N = p->ppd;
     const bool np2 = !is_pow2(N);  // PPD = 2^a 3^b: the composite-transform kernels (zd_kernels_np2.hip), field store only
-    if (np2 ? !zd::np2_supported_ppd((int) N) : (N < 32 || N > 8192)) {
-        fprintf(stderr, "zeldovich_hip: PPD = %lld unsupported (a power of two in [32, 8192], or 2^a 3^b with a >= 5, b <= 3 up to 6912)\n",
+    if (np2 ? !zd::np2_supported_ppd((int) N) : (N < 32 || N > 16384)) {
+        fprintf(stderr, "zeldovich_hip: PPD = %lld unsupported (a power of two in [32, 16384], or 2^a 3^b with a >= 5, b <= 3 up to 6912)\n",
                 (long long) N);
         return 1;
     }
@@ -372,6 +373,12 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
     if (phi_mode == 0 && phik == nullptr && pl->narray >= 2) pl->pack = pack_mode(p, R);
     if (zd::pack_is_fields(pl->pack) && ((pl->half / nranks) % zd::FIELD_RB || N / R > 2048))  // row blocks of 8, z FFT <= 2048
         pl->pack = N > 4096 ? zd::PACK_NONE : (pl->pack == zd::PACK_PLTFIELD ? zd::PACK_PLT3 : zd::PACK_ZAPAIR);
+    if (N > 8192 && pl->pack != zd::PACK_ZAFIELD) {  // a 16384-point line fills a workgroup: only the field store's kernels exist
+        fprintf(stderr, "zeldovich_hip: PPD = %lld runs on the ZA field store only (ZD_StreamFactor >= 16, no ZD_qdensity / ZD_qPLT / ZD_f_NL)\n",
+                (long long) N);
+        delete pl;
+        return 1;
+    }
     if (pl->pack != zd::PACK_NONE) pl->narray = 3;
     pl->pstep   = (pl->pack == zd::PACK_ZAPAIR || pl->pack == zd::PACK_ZAFIELD) ? 2 : 1;
     pl->npass   = R / pl->pstep;

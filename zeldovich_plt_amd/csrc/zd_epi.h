@@ -82,6 +82,7 @@ __device__ __forceinline__ void xfft_reduce(double *lds, Reduce *__restrict__ re
     if (threadIdx.x == 0) {
         constexpr int NW = (NT + 63) / 64;
         double tot = 0, a3[3] = {0, 0, 0}, b3[3] = {0, 0, 0};
+#pragma unroll 1  // (unrolled, the 7 NW values of a 1024-thread workgroup were all loaded first: 136 spilled dwords)
         for (int i = 0; i < NW; i++) {
             tot += scr[i * 7];
             for (int j = 0; j < 3; j++) {

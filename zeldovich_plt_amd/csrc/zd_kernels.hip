@@ -1535,7 +1535,10 @@ __global__ __launch_bounds__(W *N / E) void k_yfft_f(FieldLayout F, StoreLayout 
     for (int e = 0; e < E; e++) {
         const int y = t2 + T * e;
         const unsigned slot = y < N / 2 ? y : (y == N / 2 ? N / 2 : N / 2 + (N - y));
-        *reinterpret_cast<cplx *>(base + (slot * pb + xb)) = cplx{re[e], im[e]};
+        if constexpr (N > 8192)  // one array plane of the ring exceeds 4 GB
+            *reinterpret_cast<cplx *>(base + ((size_t) slot * pb + xb)) = cplx{re[e], im[e]};
+        else
+            *reinterpret_cast<cplx *>(base + (slot * pb + xb)) = cplx{re[e], im[e]};
     }
 }
 
@@ -1769,6 +1772,60 @@ __global__ __launch_bounds__(N / E) void k_xfft_seq(StoreLayout S, EpiConst ec, 
             }
         }
     }
+    xfft_reduce<NT, 3>(lds, red, 0.0, mp, mn);
+}
+
+// k_xfft_two: the same x pass as two launches of one line per workgroup (PPD = 16384: a line alone takes the 1024 threads
+// of a workgroup at 128 VGPRs, and holding a second line's results beside the transform spilled 400 dwords).  Launch 0
+// (grid (N, planes, 1)) transforms qz_r0 + i qz_r1 over its own ring row; launch 1 (grid (N, planes, 2)) transforms
+// (qx + i qy)_r, r = blockIdx.z, and writes the records of its plane straight from the registers, qz from the row
+// launch 0 left.
+//   block: N/E
+template <int N, int E>
+__global__ __launch_bounds__(N / E) void k_xfft_two(StoreLayout S, EpiConst ec, const cplx *__restrict__ tw, cplx *data, int emit,
+                                                   int plane0, int z_first, int z_step, char *__restrict__ records,
+                                                   Reduce *__restrict__ red) {
+    using PL  = zdfft::Plan<N, E>;
+    using LDS = zdfft::LineInner<N, 1>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int T = PL::T, NT = T;
+    const int t = threadIdx.x;
+    const int y = blockIdx.x, pl = plane0 + blockIdx.y;
+    const int a = emit ? (int) blockIdx.z : 2;
+    cplx *czrow     = data + row_offset(S, pl, 2, y);
+    const cplx *src = data + row_offset(S, pl, a, y);
+    double re[E], im[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const cplx v = src[t + T * e];
+        re[e] = v.x;
+        im[e] = v.y;
+    }
+    zdfft::fft_line<PL, LDS>(re, im, t, 0, lds, tw);
+    int t2 = t;
+    asm volatile("" : "+v"(t2));  // keep the address arithmetic of the epilogue after the FFT (register pressure)
+    if (!emit) {
+#pragma unroll
+        for (int e = 0; e < E; e++) czrow[t2 + T * e] = cplx{re[e], im[e]};
+        return;
+    }
+    const int z = z_first + z_step * (int) blockIdx.y;
+    double mp[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
+    const long long plane_rec0 = 2 * (long long) blockIdx.y * N * N;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int xx = t2 + T * e;
+        const cplx cv = czrow[xx];
+        const double pos[3] = {re[e], im[e], a ? cv.y : cv.x};
+        const double vel[3] = {pos[0] * ec.vnorm, pos[1] * ec.vnorm, pos[2] * ec.vnorm};
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            mp[j] = fmax(mp[j], pos[j]);
+            mn[j] = fmax(mn[j], -pos[j]);
+        }
+        if (records) emit_record(records, plane_rec0 + (long long) a * N * N + (long long) y * N + xx, ec, z + a * ec.z_pair, y, xx, pos, vel);
+    }
+    __syncthreads();
     xfft_reduce<NT, 3>(lds, red, 0.0, mp, mn);
 }
 
@@ -2127,6 +2184,7 @@ int zfft_tile_width(int L) {
         case 1024: case 2048: return 8;
         case 4096: return 4;
         case 8192: return 2;
+        case 16384: return 1;
     }
     return 0;
 }
@@ -2224,6 +2282,7 @@ int launch_yfft_fields(const FieldLayout &F, const StoreLayout &S, const void *t
         YCASE(2048, 16, 8)
         YCASE(4096, 16, 4)
         YCASE(8192, 16, 2)
+        YCASE(16384, 16, 1)
     }
 #undef YCASE
     fprintf(stderr, "zeldovich_hip: field store unsupported for PPD %d\n", S.N);
@@ -2290,12 +2349,28 @@ static int launch_xfft_seq_t(const StoreLayout &S, const EpiConst &ec, const voi
     return 0;
 }
 
+template <int N, int E>
+static int launch_xfft_two_t(const StoreLayout &S, const EpiConst &ec, const void *tw, const void *data, int plane0,
+                             int nplanes, int z_first, int z_step, void *records, Reduce *red, hipStream_t st) {
+    const size_t shmem = sizeof(double) * zdfft::LineInner<N, 1>::SIZE;
+    hipFuncSetAttribute((const void *) k_xfft_two<N, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+    for (int emit = 0; emit < 2; emit++) {
+        dim3 grid(N, nplanes, emit ? 2 : 1), block(N / E);
+        hipLaunchKernelGGL((k_xfft_two<N, E>), grid, block, shmem, st, S, ec, (const cplx *) tw, (cplx *) data, emit, plane0, z_first,
+                           z_step, (char *) records, red);
+        ZD_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 int launch_xfft(const StoreLayout &S, const EpiConst &ec, const void *tw, const void *data, int plane0, int nplanes,
                 int z_first, int z_step, void *records, float *density, Reduce *red, hipStream_t st) {
     // PPD = 8192 with the field store's ring: three lines of a row are 1536 threads / 209 KB of LDS -> one row per
     // workgroup, its arrays in sequence
     if (S.N == 8192 && S.narray == 3 && ec.pack == PACK_ZAFIELD)
         return launch_xfft_seq_t<8192, 16>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, red, st);
+    if (S.N == 16384 && S.narray == 3 && ec.pack == PACK_ZAFIELD)
+        return launch_xfft_two_t<16384, 16>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, red, st);
 #define XCASE(n, e, rows1, rows2, rows4, rows3z, rows3p)                                                              \
     case n:                                                                                                           \
         if (S.narray == 1) return launch_xfft_t<n, e, 1, rows1>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, density, red, st); \
@@ -2352,6 +2427,7 @@ int launch_test_fft(int n, int kind, const void *tw, const void *in, void *out, 
         TCASE(2048, 16, 8)
         TCASE(4096, 16, 4)
         TCASE(8192, 16, 2)
+        TCASE(16384, 16, 1)
     }
 #undef TCASE
     return 2;
