@@ -120,18 +120,18 @@ def test_table_generator_arithmetic_vs_oracle(zd, oracle, n, box, fix):
 
 
 # ---- (b) full-size exact checks through the oversampling invariant ------------------------------------------------
-def _planes(zd, ps, n, zs, stride=1, **kw):
+def _planes(zd, ps, n, zs, stride=1, eig=None, fmt="Zeldovich", **kw):
     """records of the z planes `zs` of a PPD = n run: only the passes that hold them are executed; stride > 1: only every
     stride-th lattice site of a plane leaves the GPU (a PPD = 16384 plane of records is 8.6 GB)"""
     import torch
-    p = zd.make_params(n, icformat="Zeldovich", **kw)
+    p = zd.make_params(n, icformat=fmt, **kw)
     if p.stream_factor <= 0:
         free_b, _ = torch.cuda.mem_get_info()
         p.stream_factor = zd.load_library().zd_choose_stream_factor(C.byref(p), 1, int(free_b) - (24 << 30))
         assert p.stream_factor > 0
-    plan = zd.Plan(p, ps)
+    plan = zd.Plan(p, ps, eig=eig)
     store = torch.empty(plan.exchange_bytes, dtype=torch.uint8, device="cuda")
-    dt = zd.RECORD_DTYPES["Zeldovich"]
+    dt = zd.RECORD_DTYPES[fmt]
     step = plan.plane_step
     out = torch.empty(step * n * n * dt.itemsize, dtype=torch.uint8, device="cuda")
     where = {}
@@ -193,6 +193,50 @@ def test_ppd16384_k_cutoff4_planes_equal_ppd4096(zd):
     err = np.abs(a["d"] - b["d"]).max() / np.abs(a["d"]).max()
     print("  max |d(16384, every 4th site) - d(4096)| / max|d| =", err)
     assert err < 1e-13
+
+
+def test_ppd8192_plt_plane_waves_and_stream_invariance(zd, oracle):
+    """PLT + rescale at PPD = 8192 (ZD_k_cutoff = 2): the PLT field store with the y pass at 8192 and the x pass in two
+    launches (`k_xfft_two`).  (There is no oversampling invariant with PLT: the eigenmode of a physical k depends on the
+    particle lattice, src/zeldovich.cpp:154-227.)
+    (i) one-mode runs against the closed form built from the ORACLE's per-mode pieces (its draw D(k) and get_eigenmode at
+        ppd = 8192): q_j(x) = -2 s_j (Re D sin t + Im D cos t), t = 2 pi k.x / N, s = rescale e fund / k^2, v = f q
+        (src/zeldovich.cpp:403-452), for three modes — every component of displacement and velocity of a plane;
+    (ii) a full random plane is independent of the stream factor (R = 64 vs 128)."""
+    ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
+    opk = oracle.pk_from_file(WMAP, 720.0)
+    eig = oracle.synthetic_eigenmodes(128)
+    n, z = 8192, 4099
+    fc, ztar, zini = 0.97, 5.0, 49.0
+    kw = dict(qPLT=1, qPLTrescale=1, PLT_target_z=ztar, z_initial=zini, f_cluster=fc, fmt="RVdoubleZel", eig=eig, k_cutoff=2.0)
+    op = oracle.make_params(n, k_cutoff=2.0, qPLT=1, qPLTrescale=1, PLT_target_z=ztar, z_initial=zini, f_cluster=fc)
+    L = oracle.lib()
+    fund = 2 * np.pi / 720.0
+    yy, xx = np.meshgrid(np.arange(0, n, 16), np.arange(0, n, 16), indexing="ij")
+    for mode in [(3, 5, -7), (-1001, 777, 1200), (0, 2, 0)]:
+        got, _ = _planes(zd, ps, n, [z], stride=16, stream_factor=64, qonemode=1, one_mode=mode, **kw)
+        r, D, e = (C.c_uint64 * 2)(), (C.c_double * 2)(), (C.c_double * 4)()
+        L.zdo_mode_draw(C.byref(op), C.byref(opk), mode[0], mode[1], mode[2], r, D)
+        L.zdo_get_eigenmode(eig.ctypes.data, eig.shape[0], mode[0], mode[1], mode[2], n, 1, e)
+        f = (np.sqrt(1 + 24 * e[3] * fc) - 1) / 4
+        target_f = (np.sqrt(1 + 24 * fc) - 1) / 4
+        rescale = ((1 / (1 + ztar)) / (1 / (1 + zini))) ** (target_f - f)
+        k2 = sum(m * m for m in mode) * fund * fund
+        t = 2 * np.pi * ((mode[0] * xx + mode[1] * yy + mode[2] * z) % n) / n
+        wave = -2.0 * (D[0] * np.sin(t) + D[1] * np.cos(t))
+        rec = got[z]
+        scale = max(abs(rescale * e[j] * fund / k2) for j in range(3)) * np.abs(wave).max()  # of the displacement vector
+        assert scale > 0
+        for j in range(3):  # records hold (qz, qy, qx): component j of this code's x, y, z order is column 2 - j
+            want = rescale * e[j] * fund / k2 * wave
+            assert np.abs(rec["d"][..., 2 - j] - want).max() <= 1e-12 * scale, (mode, j)
+            assert np.abs(rec["v"][..., 2 - j] - f * want).max() <= 1e-12 * f * scale, (mode, j)
+    a, ia = _planes(zd, ps, n, [z], stride=8, stream_factor=64, **kw)
+    b, ib = _planes(zd, ps, n, [z], stride=8, stream_factor=128, **kw)
+    print(ia, ib)
+    for f_ in ("d", "v"):
+        assert np.abs(a[z][f_]).max() > 0
+        assert np.abs(a[z][f_] - b[z][f_]).max() <= 1e-12 * np.abs(a[z][f_]).max()
 
 
 def test_ppd2048_plt_store_and_stream_invariance(zd, oracle):

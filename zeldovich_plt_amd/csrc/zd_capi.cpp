@@ -206,7 +206,9 @@ static int pack_mode(const zd_params *p, int R) {
     // PLT: the three packed arrays by default; its field store (six half-space sums) only on request — measured slower
     // (PPD=2048 PLT+rescale 0.553 -> 0.609 s: every array of the y stage needs two potentials, each fetched twice, and the
     // 148-VGPR PLT generator leaves no room for the z FFT beside it anyway)
-    if (p->qPLT) return p->ppd > 4096 ? zd::PACK_NONE : (p->store_mode == ZD_STORE_FIELDS ? zd::PACK_PLTFIELD : zd::PACK_PLT3);
+    // (PPD = 8192: the x pass of the packed arrays does not exist — three lines of a row are 1536 threads — so PLT runs on
+    // its field store there, whose ring goes through k_xfft_two)
+    if (p->qPLT) return p->ppd > 4096 ? zd::PACK_PLTFIELD : (p->store_mode == ZD_STORE_FIELDS ? zd::PACK_PLTFIELD : zd::PACK_PLT3);
     if (R < 2) return zd::PACK_NONE;  // the ZA packings carry two z-residues per pass
     if (p->store_mode == ZD_STORE_PACKED) return p->ppd > 4096 ? zd::PACK_NONE : zd::PACK_ZAPAIR;
     return zd::PACK_ZAFIELD;

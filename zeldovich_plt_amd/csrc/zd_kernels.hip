@@ -1776,12 +1776,16 @@ __global__ __launch_bounds__(N / E) void k_xfft_seq(StoreLayout S, EpiConst ec, 
 }
 
 // k_xfft_two: the same x pass as two launches of one line per workgroup (PPD = 16384: a line alone takes the 1024 threads
-// of a workgroup at 128 VGPRs, and holding a second line's results beside the transform spilled 400 dwords).  Launch 0
-// (grid (N, planes, 1)) transforms qz_r0 + i qz_r1 over its own ring row; launch 1 (grid (N, planes, 2)) transforms
-// (qx + i qy)_r, r = blockIdx.z, and writes the records of its plane straight from the registers, qz from the row
-// launch 0 left.
-//   block: N/E
-template <int N, int E>
+// of a workgroup at 128 VGPRs, and holding a second line's results beside the transform spilled; PPD = 8192 with PLT: a
+// record needs all three arrays).  Launch 0 transforms the arrays the records only READ, each over its own ring row;
+// launch 1 transforms the remaining ones and writes the records straight from the registers, the rest from the rows
+// launch 0 left (L2-resident: written a moment ago by the same XCD's neighbours).
+//   ZA field ring  (qx + i qy)_r0 | (qx + i qy)_r1 | qz_r0 + i qz_r1:   launch 0: array 2 (grid z = 1); launch 1: arrays 0, 1
+//                  = the two planes of the pair (grid z = 2)
+//   PLT ring       qx + i vx | qy + i qz | vy + i vz (PACK_PLT3):        launch 0: arrays 0 and 2 (grid z = 2); launch 1:
+//                  array 1 (grid z = 1), one plane
+//   grid: (N, planes, z)   block: N/E
+template <int N, int E, bool PLT>
 __global__ __launch_bounds__(N / E) void k_xfft_two(StoreLayout S, EpiConst ec, const cplx *__restrict__ tw, cplx *data, int emit,
                                                    int plane0, int z_first, int z_step, char *__restrict__ records,
                                                    Reduce *__restrict__ red) {
@@ -1791,13 +1795,15 @@ __global__ __launch_bounds__(N / E) void k_xfft_two(StoreLayout S, EpiConst ec, 
     constexpr int T = PL::T, NT = T;
     const int t = threadIdx.x;
     const int y = blockIdx.x, pl = plane0 + blockIdx.y;
-    const int a = emit ? (int) blockIdx.z : 2;
-    cplx *czrow     = data + row_offset(S, pl, 2, y);
-    const cplx *src = data + row_offset(S, pl, a, y);
+    constexpr bool plt = PLT;
+    const int a = plt ? (emit ? 1 : 2 * (int) blockIdx.z) : (emit ? (int) blockIdx.z : 2);
+    cplx *row2 = data + row_offset(S, pl, 2, y);
+    cplx *row0 = data + row_offset(S, pl, 0, y);
+    cplx *self = data + row_offset(S, pl, a, y);
     double re[E], im[E];
 #pragma unroll
     for (int e = 0; e < E; e++) {
-        const cplx v = src[t + T * e];
+        const cplx v = self[t + T * e];
         re[e] = v.x;
         im[e] = v.y;
     }
@@ -1806,24 +1812,32 @@ __global__ __launch_bounds__(N / E) void k_xfft_two(StoreLayout S, EpiConst ec, 
     asm volatile("" : "+v"(t2));  // keep the address arithmetic of the epilogue after the FFT (register pressure)
     if (!emit) {
 #pragma unroll
-        for (int e = 0; e < E; e++) czrow[t2 + T * e] = cplx{re[e], im[e]};
+        for (int e = 0; e < E; e++) self[t2 + T * e] = cplx{re[e], im[e]};
         return;
     }
-    const int z = z_first + z_step * (int) blockIdx.y;
+    const int z = z_first + z_step * (int) blockIdx.y + (plt ? 0 : a * ec.z_pair);
     double mp[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
-    const long long plane_rec0 = 2 * (long long) blockIdx.y * N * N;
+    const long long rec0 = plt ? (long long) blockIdx.y * N * N + (long long) y * N
+                               : 2 * (long long) blockIdx.y * N * N + (long long) a * N * N + (long long) y * N;
 #pragma unroll
     for (int e = 0; e < E; e++) {
         const int xx = t2 + T * e;
-        const cplx cv = czrow[xx];
-        const double pos[3] = {re[e], im[e], a ? cv.y : cv.x};
-        const double vel[3] = {pos[0] * ec.vnorm, pos[1] * ec.vnorm, pos[2] * ec.vnorm};
+        const cplx c2 = row2[xx];
+        double pos[3], vel[3];
+        if constexpr (plt) {
+            const cplx c0 = row0[xx];
+            pos[0] = c0.x; pos[1] = re[e]; pos[2] = im[e];
+            vel[0] = c0.y * ec.vnorm; vel[1] = c2.x * ec.vnorm; vel[2] = c2.y * ec.vnorm;
+        } else {
+            pos[0] = re[e]; pos[1] = im[e]; pos[2] = a ? c2.y : c2.x;
+            vel[0] = pos[0] * ec.vnorm; vel[1] = pos[1] * ec.vnorm; vel[2] = pos[2] * ec.vnorm;
+        }
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             mp[j] = fmax(mp[j], pos[j]);
             mn[j] = fmax(mn[j], -pos[j]);
         }
-        if (records) emit_record(records, plane_rec0 + (long long) a * N * N + (long long) y * N + xx, ec, z + a * ec.z_pair, y, xx, pos, vel);
+        if (records) emit_record(records, rec0 + xx, ec, z, y, xx, pos, vel);
     }
     __syncthreads();
     xfft_reduce<NT, 3>(lds, red, 0.0, mp, mn);
@@ -2349,14 +2363,14 @@ static int launch_xfft_seq_t(const StoreLayout &S, const EpiConst &ec, const voi
     return 0;
 }
 
-template <int N, int E>
+template <int N, int E, bool PLT>
 static int launch_xfft_two_t(const StoreLayout &S, const EpiConst &ec, const void *tw, const void *data, int plane0,
                              int nplanes, int z_first, int z_step, void *records, Reduce *red, hipStream_t st) {
     const size_t shmem = sizeof(double) * zdfft::LineInner<N, 1>::SIZE;
-    hipFuncSetAttribute((const void *) k_xfft_two<N, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+    hipFuncSetAttribute((const void *) k_xfft_two<N, E, PLT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
     for (int emit = 0; emit < 2; emit++) {
-        dim3 grid(N, nplanes, emit ? 2 : 1), block(N / E);
-        hipLaunchKernelGGL((k_xfft_two<N, E>), grid, block, shmem, st, S, ec, (const cplx *) tw, (cplx *) data, emit, plane0, z_first,
+        dim3 grid(N, nplanes, (emit != 0) == PLT ? 1 : 2), block(N / E);
+        hipLaunchKernelGGL((k_xfft_two<N, E, PLT>), grid, block, shmem, st, S, ec, (const cplx *) tw, (cplx *) data, emit, plane0, z_first,
                            z_step, (char *) records, red);
         ZD_LAUNCH_CHECK();
     }
@@ -2370,7 +2384,9 @@ int launch_xfft(const StoreLayout &S, const EpiConst &ec, const void *tw, const 
     if (S.N == 8192 && S.narray == 3 && ec.pack == PACK_ZAFIELD)
         return launch_xfft_seq_t<8192, 16>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, red, st);
     if (S.N == 16384 && S.narray == 3 && ec.pack == PACK_ZAFIELD)
-        return launch_xfft_two_t<16384, 16>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, red, st);
+        return launch_xfft_two_t<16384, 16, false>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, red, st);
+    if (S.N == 8192 && S.narray == 3 && ec.pack == PACK_PLT3)  // the ring of the PLT field store
+        return launch_xfft_two_t<8192, 16, true>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, red, st);
 #define XCASE(n, e, rows1, rows2, rows4, rows3z, rows3p)                                                              \
     case n:                                                                                                           \
         if (S.narray == 1) return launch_xfft_t<n, e, 1, rows1>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, density, red, st); \
