@@ -90,6 +90,23 @@ def test_params_validation(zd, tmp_path, mutation, ok):
             zd.params_from_file(par)
 
 
+def test_power_spectrum_table_order_quirk_matches_oracle(zd, oracle, tmp_path):
+    """a P(k) file whose rows are NOT ascending: the reference's table sort compares one slot to the right of the element it
+    moves (include/spline_function.h:77-104), so such a table comes out in the reference's own order — host library and
+    oracle must agree bit for bit there too (ascending files pass through unchanged)"""
+    t = np.loadtxt(WMAP)
+    idx = np.random.default_rng(3).permutation(len(t))[:10]
+    t[idx] = t[idx[::-1]]
+    path = tmp_path / "shuffled.pow"
+    np.savetxt(path, t)
+    ps = zd.PowerSpectrum.from_file(str(path), 720.0)
+    opk = oracle.pk_from_file(str(path), 720.0)
+    x, y, y2 = ps.tables()
+    ox, oy, oy2 = oracle.pk_tables(opk)
+    assert np.array_equal(x, ox) and np.array_equal(y, oy) and np.array_equal(y2, oy2, equal_nan=True)
+    assert ps.pk.normalization == opk.normalization
+
+
 def test_power_spectrum_matches_oracle(zd, oracle):
     ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
     opk = oracle.pk_from_file(WMAP, 720.0)

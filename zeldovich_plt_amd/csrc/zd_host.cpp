@@ -27,65 +27,69 @@
 namespace {
 
 // ---------------------------------------------------------------------------------------------
-// spline (include/spline_function.h)
+// P(k) table: natural cubic spline through (ln k, ln P)  (what SplineFunction does for the reference,
+// include/spline_function.h:77-163).  Every amplitude the GPU produces carries these numbers, so each floating-point
+// operation below happens in the reference's order; the code around them is this library's own.
 
 struct Spline {
     std::vector<double> x, y, y2;
 
-    void sort_arrays() {  // shell sort, spline_function.h:77-104 (same comparison as the source)
-        const int n = (int) x.size();
-        double *a = x.data() - 1, *b = y.data() - 1;
-        int inc = 1;
-        do {
-            inc *= 3;
-            inc++;
-        } while (inc <= n);
-        do {
-            inc /= 3;
-            for (int i = inc + 1; i <= n; i++) {
-                const double v = a[i], w = b[i];
-                int j = i;
-                while (x[j - inc] > v) {
-                    a[j] = a[j - inc];
-                    b[j] = b[j - inc];
-                    j -= inc;
-                    if (j <= inc) break;
+    // The reference orders its table with a diminishing-increment sort whose comparison looks ONE SLOT TO THE RIGHT of
+    // the element it then moves (spline_function.h:92: the key array is addressed 0-based there, the moved arrays
+    // 1-based).  An ascending table — every P(k) file in practice — passes through unchanged; anything else comes out
+    // in the reference's order, not necessarily sorted.  Same increments (1, 4, 13, ... largest first), same
+    // comparisons, written 0-based.
+    void order_like_reference() {
+        const long n = (long) x.size();
+        std::vector<long> gaps;
+        for (long g = 1; g <= n; g = 3 * g + 1) gaps.push_back(g);
+        if (gaps.empty()) return;
+        // the reference starts from the first increment ABOVE n divided by 3, i.e. the largest one <= n ... 1
+        for (auto it = gaps.rbegin(); it != gaps.rend(); ++it) {
+            const long gap = *it;
+            for (long p = gap; p < n; p++) {
+                const double kx = x[p], ky = y[p];
+                long q = p;
+                while (x[q + 1 - gap] > kx) {  // (the neighbour to the right of slot q - gap)
+                    x[q] = x[q - gap];
+                    y[q] = y[q - gap];
+                    q -= gap;
+                    if (q < gap) break;
                 }
-                a[j] = v;
-                b[j] = w;
+                x[q] = kx;
+                y[q] = ky;
             }
-        } while (inc > 1);
-    }
-    void build() {  // natural cubic spline, spline_function.h:106-139
-        const int n = (int) x.size();
-        y2.assign(n, 0.0);
-        std::vector<double> u(n, 0.0);
-        sort_arrays();
-        for (int i = 1; i <= n - 2; i++) {
-            const double sig = (x[i] - x[i - 1]) / (x[i + 1] - x[i - 1]);
-            const double p   = sig * y2[i - 1] + 2.0;
-            y2[i]            = (sig - 1.0) / p;
-            u[i] = (y[i + 1] - y[i]) / (x[i + 1] - x[i]) - (y[i] - y[i - 1]) / (x[i] - x[i - 1]);
-            u[i] = (6.0 * u[i] / (x[i + 1] - x[i - 1]) - sig * u[i - 1]) / p;
         }
-        const double qn = 0.0, un = 0.0;
-        y2[n - 1] = (un - qn * u[n - 2]) / (qn * y2[n - 2] + 1.0);
-        for (int k = n - 2; k >= 0; k--) y2[k] = y2[k] * y2[k + 1] + u[k];
+    }
+
+    // second derivatives of the natural spline: forward elimination of the tridiagonal system, then back substitution
+    void build() {
+        const long n = (long) x.size();
+        order_like_reference();
+        y2.assign(n, 0.0);
+        std::vector<double> rhs(n, 0.0), slope(n, 0.0);
+        for (long i = 0; i + 1 < n; i++) slope[i] = (y[i + 1] - y[i]) / (x[i + 1] - x[i]);
+        for (long i = 1; i + 1 < n; i++) {
+            const double span  = x[i + 1] - x[i - 1];
+            const double ratio = (x[i] - x[i - 1]) / span;
+            const double pivot = ratio * y2[i - 1] + 2.0;
+            y2[i]  = (ratio - 1.0) / pivot;
+            rhs[i] = (6.0 * (slope[i] - slope[i - 1]) / span - ratio * rhs[i - 1]) / pivot;
+        }
+        y2[n - 1] = 0.0;  // natural end (the reference's (un - qn u)/(qn y2 + 1) with un = qn = 0)
+        for (long i = n - 2; i >= 0; i--) y2[i] = y2[i] * y2[i + 1] + rhs[i];
     }
 };
 
+// value of the spline at v; outside the table the first / last cubic piece continues (the bisection of
+// spline_function.h:141-163 ends on the last node <= v, kept inside [0, n-2])
 double spline_val(int n, const double *x, const double *y, const double *y2, double v) {
-    int klo = 0, khi = n - 1;
-    while (khi - klo > 1) {
-        const int k = (khi + klo) >> 1;
-        if (x[k] > v)
-            khi = k;
-        else
-            klo = k;
-    }
-    const double h = x[khi] - x[klo];
-    const double a = (x[khi] - v) / h, b = (v - x[klo]) / h;
-    return a * y[klo] + b * y[khi] + ((a * a * a - a) * y2[klo] + (b * b * b - b) * y2[khi]) * (h * h) / 6.0;
+    long lo = (std::upper_bound(x, x + n, v) - x) - 1;
+    lo      = std::min<long>(std::max<long>(lo, 0), n - 2);
+    const long hi      = lo + 1;
+    const double width = x[hi] - x[lo];
+    const double wl = (x[hi] - v) / width, wh = (v - x[lo]) / width;
+    return wl * y[lo] + wh * y[hi] + ((wl * wl * wl - wl) * y2[lo] + (wh * wh * wh - wh) * y2[hi]) * (width * width) / 6.0;
 }
 
 double pk_power(const zd_pk *pk, double k) {  // power_spectrum.cpp:225-261
@@ -106,57 +110,66 @@ double pk_power(const zd_pk *pk, double k) {  // power_spectrum.cpp:225-261
     return std::exp(spline_val(pk->n, pk->x, pk->y, pk->y2, std::log(k)) - k * k * pk->Pk_smooth2) * pk->normalization;
 }
 
-double sigmaR_integrand(const zd_pk *pk, double Rnorm, double k) {  // power_spectrum.cpp:50-58
-    const double x = k * Rnorm;
-    double w;
-    if (x <= 1e-3)
-        w = 1 - x * x / 10.0;
-    else
-        w = 3.0 * (std::sin(x) - x * std::cos(x)) / x / x / x;
-    return 0.5 / M_PI / M_PI * k * k * w * w * pk_power(pk, k);
-}
+// sigma_R^2 = int dk k^2 P(k) W^2(kR) / (2 pi^2), W = the top-hat window (series below kR = 1e-3); integrand of
+// power_spectrum.cpp:50-58
+struct TopHatVariance {
+    const zd_pk *pk;
+    double R;
+    double operator()(double k) const {
+        const double kr = k * R;
+        const double window = kr <= 1e-3 ? 1 - kr * kr / 10.0 : 3.0 * (std::sin(kr) - kr * std::cos(kr)) / kr / kr / kr;
+        return 0.5 / M_PI / M_PI * k * k * window * window * pk_power(pk, k);
+    }
+};
 
-// Romberg with up to 32 bisections (power_spectrum.cpp:93-128); midpoint sums in k order
-double romberg(const zd_pk *pk, double Rnorm, double a, double b, double prec, double *obtprec) {
-    constexpr int MAXITER = 32;
-    static thread_local double TT[MAXITER + 1][MAXITER + 1];
-    double h = 0.5 * (b - a);
-    TT[0][1] = h * (sigmaR_integrand(pk, Rnorm, a) + sigmaR_integrand(pk, Rnorm, b));
-    int jj   = 0;
-    do {
-        jj++;
-        double s = 0;
-        for (uint64_t k = 1; k <= (1ULL << (jj - 1)); k++) s += sigmaR_integrand(pk, Rnorm, a + (2 * k - 1) * h);
-        TT[jj][1] = 0.5 * TT[jj - 1][1] + h * s;
-        double fourtokm1 = 1;
-        for (int k = 2; k <= jj; k++) {
-            fourtokm1 *= 4;
-            TT[jj][k] = TT[jj][k - 1] + (TT[jj][k - 1] - TT[jj - 1][k - 1]) / (fourtokm1 - 1);
+// Romberg integration as the reference runs it (power_spectrum.cpp:93-128): trapezoid refined by midpoints taken in
+// ascending order, Richardson columns with factors 4, 16, ...; stops when the diagonal moves by less than `tol`
+// relatively (at least two refinements, at most 32).  Only the previous row of the tableau is needed.
+template <class F>
+double romberg(const F &f, double lo, double hi, double tol, double *achieved) {
+    constexpr int kMaxLevels = 32;
+    std::vector<double> prev(1, 0.0), cur;
+    double half = 0.5 * (hi - lo);
+    prev[0]     = half * (f(lo) + f(hi));
+    double diag_before = prev[0], diag = prev[0];
+    for (int level = 1; level <= kMaxLevels; level++) {
+        double mid = 0;
+        for (uint64_t m = 1; m <= (1ULL << (level - 1)); m++) mid += f(lo + (2 * m - 1) * half);
+        cur.assign(level + 1, 0.0);
+        cur[0]       = 0.5 * prev[0] + half * mid;
+        double power = 1;
+        for (int c = 1; c < level; c++) {
+            power *= 4;
+            cur[c] = cur[c - 1] + (cur[c - 1] - prev[c - 1]) / (power - 1);
         }
-        h *= 0.5;
-        if (jj > 1 && std::fabs(TT[jj][jj] - TT[jj - 1][jj - 1]) < prec * std::fabs(TT[jj][jj])) break;
-    } while (jj < MAXITER);
-    *obtprec = (TT[jj][jj] - TT[jj - 1][jj - 1]) / TT[jj][jj];
-    return TT[jj][jj];
+        half *= 0.5;
+        diag_before = prev[level - 1 > 0 ? level - 2 : 0];
+        diag        = cur[level - 1];
+        prev.swap(cur);
+        if (level > 1 && std::fabs(diag - diag_before) < tol * std::fabs(diag)) break;
+    }
+    *achieved = (diag - diag_before) / diag;
+    return diag;
 }
 
 double pk_sigmaR(const zd_pk *pk, double R) {  // power_spectrum.cpp:60-89
     if (!pk->is_powerlaw) {
-        const double target_prec = 1e-6;
-        double precision         = 1.0;
-        const double retval      = std::sqrt(romberg(pk, R, 0, 10.0, target_prec, &precision));
-        if (precision > target_prec) {
+        const double want = 1e-6;
+        double got        = 1.0;
+        const double sig  = std::sqrt(romberg(TopHatVariance{pk, R}, 0, 10.0, want, &got));
+        if (got > want) {
             fprintf(stderr,
                     "Error: actual Romberg integration precision (%g) is greater than the target precision (%g); halting.\n",
-                    precision, target_prec);
+                    got, want);
             exit(1);
         }
-        return retval;
+        return sig;
     }
-    const double n = pk->powerlaw_index;
-    double retval  = 9 * std::pow(R, -n - 3) / (2 * M_PI * std::sqrt(M_PI)) * std::tgamma((3 + n) / 2.)
-                    / (std::tgamma((2 - n) / 2.) * (n - 3) * (n - 1));
-    return std::sqrt(retval * pk->normalization);
+    // power law: closed form of the same integral
+    const double idx = pk->powerlaw_index;
+    const double var = 9 * std::pow(R, -idx - 3) / (2 * M_PI * std::sqrt(M_PI)) * std::tgamma((3 + idx) / 2.)
+                       / (std::tgamma((2 - idx) / 2.) * (idx - 3) * (idx - 1));
+    return std::sqrt(var * pk->normalization);
 }
 
 }  // namespace
