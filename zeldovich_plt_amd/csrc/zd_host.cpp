@@ -84,9 +84,11 @@ struct Spline {
 // value of the spline at v; outside the table the first / last cubic piece continues (the bisection of
 // spline_function.h:141-163 ends on the last node <= v, kept inside [0, n-2])
 double spline_val(int n, const double *x, const double *y, const double *y2, double v) {
-    long lo = (std::upper_bound(x, x + n, v) - x) - 1;
-    lo      = std::min<long>(std::max<long>(lo, 0), n - 2);
-    const long hi      = lo + 1;
+    long lo = 0, hi = n - 1;  // halving by hand, not std::upper_bound: on a table the sort above left unordered the two differ
+    while (hi - lo > 1) {
+        const long mid = lo + (hi - lo) / 2;
+        (x[mid] > v ? hi : lo) = mid;
+    }
     const double width = x[hi] - x[lo];
     const double wl = (x[hi] - v) / width, wh = (v - x[lo]) / width;
     return wl * y[lo] + wh * y[hi] + ((wl * wl * wl - wl) * y2[lo] + (wh * wh * wh - wh) * y2[hi]) * (width * width) / 6.0;
