@@ -195,26 +195,32 @@ def test_ppd16384_k_cutoff4_planes_equal_ppd4096(zd):
     assert err < 1e-13
 
 
-def test_ppd8192_plt_plane_waves_and_stream_invariance(zd, oracle):
-    """PLT + rescale at PPD = 8192 (ZD_k_cutoff = 2): the PLT field store with the y pass at 8192 and the x pass in two
-    launches (`k_xfft_two`).  (There is no oversampling invariant with PLT: the eigenmode of a physical k depends on the
-    particle lattice, src/zeldovich.cpp:154-227.)
+@pytest.mark.parametrize("n,kc,Ra,Rb,modes", [
+    (8192, 2.0, 64, 128, [(3, 5, -7), (-1001, 777, 1200), (0, 2, 0)]),   # k_xfft_two<8192, PLT>
+    (6912, 4.0, 8, 16, [(3, 5, -7), (-401, 377, 500)]),                  # composite kernels, x pass in two launches
+    (3456, 2.0, 4, 8, [(-3, 5, 7), (401, 377, -500)]),                   # composite kernels, three lines per workgroup
+])
+def test_large_plt_plane_waves_and_stream_invariance(zd, oracle, n, kc, Ra, Rb, modes):
+    """PLT + rescale at the sizes that only the PLT FIELD store serves — PPD = 8192 (the y pass at 8192 and the x pass in two
+    launches, `k_xfft_two`) and PPD = 2^a 3^b (6912 = the production Abacus grid, 3456) — checked at full size.  (There is no
+    oversampling invariant with PLT: the eigenmode of a physical k depends on the particle lattice,
+    src/zeldovich.cpp:154-227.)
     (i) one-mode runs against the closed form built from the ORACLE's per-mode pieces (its draw D(k) and get_eigenmode at
-        ppd = 8192): q_j(x) = -2 s_j (Re D sin t + Im D cos t), t = 2 pi k.x / N, s = rescale e fund / k^2, v = f q
-        (src/zeldovich.cpp:403-452), for three modes — every component of displacement and velocity of a plane;
-    (ii) a full random plane is independent of the stream factor (R = 64 vs 128)."""
+        this ppd): q_j(x) = -2 s_j (Re D sin t + Im D cos t), t = 2 pi k.x / N, s = rescale e fund / k^2, v = f q
+        (src/zeldovich.cpp:403-452) — every component of displacement and velocity of a plane;
+    (ii) a full random plane is independent of the stream factor."""
     ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
     opk = oracle.pk_from_file(WMAP, 720.0)
     eig = oracle.synthetic_eigenmodes(128)
-    n, z = 8192, 4099
+    z = n // 2 + 3
     fc, ztar, zini = 0.97, 5.0, 49.0
-    kw = dict(qPLT=1, qPLTrescale=1, PLT_target_z=ztar, z_initial=zini, f_cluster=fc, fmt="RVdoubleZel", eig=eig, k_cutoff=2.0)
-    op = oracle.make_params(n, k_cutoff=2.0, qPLT=1, qPLTrescale=1, PLT_target_z=ztar, z_initial=zini, f_cluster=fc)
+    kw = dict(qPLT=1, qPLTrescale=1, PLT_target_z=ztar, z_initial=zini, f_cluster=fc, fmt="RVdoubleZel", eig=eig, k_cutoff=kc)
+    op = oracle.make_params(n, k_cutoff=kc, qPLT=1, qPLTrescale=1, PLT_target_z=ztar, z_initial=zini, f_cluster=fc)
     L = oracle.lib()
     fund = 2 * np.pi / 720.0
     yy, xx = np.meshgrid(np.arange(0, n, 16), np.arange(0, n, 16), indexing="ij")
-    for mode in [(3, 5, -7), (-1001, 777, 1200), (0, 2, 0)]:
-        got, _ = _planes(zd, ps, n, [z], stride=16, stream_factor=64, qonemode=1, one_mode=mode, **kw)
+    for mode in modes:
+        got, _ = _planes(zd, ps, n, [z], stride=16, stream_factor=Ra, qonemode=1, one_mode=mode, **kw)
         r, D, e = (C.c_uint64 * 2)(), (C.c_double * 2)(), (C.c_double * 4)()
         L.zdo_mode_draw(C.byref(op), C.byref(opk), mode[0], mode[1], mode[2], r, D)
         L.zdo_get_eigenmode(eig.ctypes.data, eig.shape[0], mode[0], mode[1], mode[2], n, 1, e)
@@ -231,8 +237,8 @@ def test_ppd8192_plt_plane_waves_and_stream_invariance(zd, oracle):
             want = rescale * e[j] * fund / k2 * wave
             assert np.abs(rec["d"][..., 2 - j] - want).max() <= 1e-12 * scale, (mode, j)
             assert np.abs(rec["v"][..., 2 - j] - f * want).max() <= 1e-12 * f * scale, (mode, j)
-    a, ia = _planes(zd, ps, n, [z], stride=8, stream_factor=64, **kw)
-    b, ib = _planes(zd, ps, n, [z], stride=8, stream_factor=128, **kw)
+    a, ia = _planes(zd, ps, n, [z], stride=8, stream_factor=Ra, **kw)
+    b, ib = _planes(zd, ps, n, [z], stride=8, stream_factor=Rb, **kw)
     print(ia, ib)
     for f_ in ("d", "v"):
         assert np.abs(a[z][f_]).max() > 0

@@ -578,6 +578,24 @@ def test_non_power_of_two_ppd_vs_oracle(zd, oracle, ps, opk, n, kw):
     assert sorted(got["planes_seen"]) == list(range(n))
 
 
+@pytest.mark.parametrize("n,kw", [
+    (96, dict(stream_factor=2, ppd_e=32)),                       # exact-stride eigenmode lookup is impossible (32 does not divide 96): trilinear
+    (192, dict(stream_factor=4, ppd_e=64, resc=0)),
+    (288, dict(stream_factor=2, ppd_e=24, fmt="RVZel")),
+    (192, dict(stream_factor=2, ppd_e=32, ngpu=2)),              # two ranks
+    (192, dict(stream_factor=2, ppd_e=32, version=1, numblock=4)),  # legacy streams on a composite grid
+])
+def test_non_power_of_two_ppd_plt_vs_oracle(zd, oracle, ps, opk, n, kw):
+    """PLT (+ rescale) on PPD = 2^a 3^b — the production Abacus configuration (PPD = 6912 with ZD_qPLT): the PLT field store
+    (six half-space sums) through the composite-transform kernels, against the oracle"""
+    kw = dict(kw)
+    fmt = kw.pop("fmt", "RVdoubleZel")
+    eig = oracle.synthetic_eigenmodes(kw.pop("ppd_e"))
+    resc = kw.pop("resc", 1)
+    got, _ = _compare(zd, oracle, ps, opk, n, fmt=fmt, eig=eig, qPLT=1, qPLTrescale=resc, PLT_target_z=5.0, f_cluster=0.97, **kw)
+    assert sorted(got["planes_seen"]) == list(range(n))
+
+
 def test_non_power_of_two_oversampling_invariance(zd, ps):
     """PPD = 2N with k_cutoff = 2 at even sites == PPD = N (README), across the composite sizes: 192 <-> 96, 576 <-> 288,
     1728 <-> 864 (27 * 64 / 27 * 32), on sample planes (a full PPD = 1728 record array would be 290 GB of host memory);

@@ -208,7 +208,8 @@ static int pack_mode(const zd_params *p, int R) {
     // 148-VGPR PLT generator leaves no room for the z FFT beside it anyway)
     // (PPD = 8192: the x pass of the packed arrays does not exist — three lines of a row are 1536 threads — so PLT runs on
     // its field store there, whose ring goes through k_xfft_two)
-    if (p->qPLT) return p->ppd > 4096 ? zd::PACK_PLTFIELD : (p->store_mode == ZD_STORE_FIELDS ? zd::PACK_PLTFIELD : zd::PACK_PLT3);
+    // PPD = 2^a 3^b: the composite-transform kernels exist for the field stores only
+    if (p->qPLT) return (p->ppd > 4096 || !is_pow2(p->ppd) || p->store_mode == ZD_STORE_FIELDS) ? zd::PACK_PLTFIELD : zd::PACK_PLT3;
     if (R < 2) return zd::PACK_NONE;  // the ZA packings carry two z-residues per pass
     if (p->store_mode == ZD_STORE_PACKED) return p->ppd > 4096 ? zd::PACK_NONE : zd::PACK_ZAPAIR;
     return zd::PACK_ZAFIELD;
@@ -295,7 +296,7 @@ int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes
     int R0 = 1;
     if (!p->qPLT && pack_mode(p, 2) != zd::PACK_NONE && N / 2 >= 32 && (N / 2) % nranks == 0) R0 = 2;
     const bool np2 = !is_pow2(N);
-    if (np2 && (R0 != 2 || !zd::np2_supported_ppd((int) N) || (N / 2) % (nranks * zd::FIELD_RB))) return -1;
+    if (np2 && (!zd::pack_is_fields(pack_mode(p, 2)) || !zd::np2_supported_ppd((int) N) || (N / 2) % (nranks * zd::FIELD_RB))) return -1;
     for (int R = R0; N / R >= 32 && N % R == 0; R *= 2) {
         if ((N / R) % nranks) break;
         if (N / R > 4096) continue;  // z-FFT kernels exist up to length 4096
@@ -345,9 +346,9 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         fprintf(stderr, "zeldovich_hip: stream factor %d invalid for PPD %lld\n", R, (long long) N);
         return 1;
     }
-    if (np2 && (phi_mode != 0 || phik != nullptr || pack_mode(p, R) != zd::PACK_ZAFIELD || (N / 2) % (nranks * zd::FIELD_RB))) {
-        fprintf(stderr, "zeldovich_hip: PPD = %lld (not a power of two) runs on the ZA field store only: ZD_StreamFactor >= 2, no "
-                        "ZD_qdensity / ZD_qPLT / ZD_f_NL / ZD_qoneslab, store_mode auto, PPD/2 a multiple of 8 x ranks\n", (long long) N);
+    if (np2 && (phi_mode != 0 || phik != nullptr || !zd::pack_is_fields(pack_mode(p, R)) || (N / 2) % (nranks * zd::FIELD_RB))) {
+        fprintf(stderr, "zeldovich_hip: PPD = %lld (not a power of two) runs on the field stores only: ZD_StreamFactor >= 2, no "
+                        "ZD_qdensity / ZD_f_NL / ZD_qoneslab, store_mode auto, PPD/2 a multiple of 8 x ranks\n", (long long) N);
         return 1;
     }
     if (nranks < 1 || !is_pow2(nranks) || rank < 0 || rank >= nranks || (N / 2) % nranks || (N / R) % nranks) {

@@ -124,10 +124,12 @@ __global__ __launch_bounds__(W *Q *P / E) void k_yfft_fq(FieldLayout F, StoreLay
     const int x = tile * W + w, xm = x ? N - x : 0;
     const int zl = plane0 + blockIdx.z;
     const int kx = x > N / 2 ? x - N : x;
-    const bool two = a == 2;  // (Z_0, Z_1); a < 2: E_a alone
-    const int f0 = a == 2 ? 1 : 2 * a;
+    // ZA: E_a alone (a < 2) or (Z_0, Z_1); PLT: the pairs (X, fX), (Y, Z), (fY, fZ) of the six sums — see k_yfft_f
+    const bool plt = F.nfield == 6, two = plt || a == 2;
+    const int f0 = plt ? (a == 0 ? 0 : (a == 1 ? 1 : 4)) : (a == 2 ? 1 : 2 * a);
+    const int f1 = plt ? (a == 0 ? 3 : (a == 1 ? 2 : 5)) : 3;
     const cplx *p0 = store + (long long) (zl * F.nfield + f0) * F.field_elems;
-    const long long d01 = two ? 2 * F.field_elems : 0;
+    const long long d01 = two ? (long long) (f1 - f0) * F.field_elems : 0;
     double re[E], im[E];
     FieldRow rows[E];
 #pragma unroll
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(W *Q *P / E) void k_yfft_fq(FieldLayout F, StoreLay
 // threads of lines 0 / 1 hold qx, qy of their plane, only qz_r0 + i qz_r1 (line 2) goes through LDS, records leave straight
 // from the registers (the form of k_xfft's field-store path).
 //   grid: (N, planes)   block: 3*Q*P/E
-template <int P, int E, int Q>
+template <int P, int E, int Q, bool PLT>
 __global__ __launch_bounds__(3 * Q *P / E) void k_xfft_q3(EpiConst ec, const cplx *__restrict__ twP, const cplx *__restrict__ twN,
                                                         const cplx *__restrict__ twQ, const cplx *__restrict__ ring,
                                                         int ring_pitch, int z_first, int z_step, char *__restrict__ records,
@@ -213,6 +215,30 @@ __global__ __launch_bounds__(3 * Q *P / E) void k_xfft_q3(EpiConst ec, const cpl
     double mp[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
     const long long plane_rec0 = 2 * (long long) blockIdx.y * N * N;
     double2 *cz = reinterpret_cast<double2 *>(lds);  // [x] = {qz_r0, qz_r1}
+    if constexpr (PLT) {
+        // PLT ring qx + i vx | qy + i qz | vy + i vz: ONE plane per store plane; lines 0 and 2 go through LDS ([x] and
+        // [N + x]), line 1 writes the records
+        if (a != 1) {
+#pragma unroll
+            for (int e = 0; e < E; e++) cz[(a ? N : 0) + (t + T * e) + P * n2] = double2{re[e], im[e]};
+        }
+        __syncthreads();
+        if (a == 1) {
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const int xx = (t + T * e) + P * n2;
+                const double2 c0 = cz[xx], c2 = cz[N + xx];
+                const double pos[3] = {c0.x, re[e], im[e]};
+                const double vel[3] = {c0.y * ec.vnorm, c2.x * ec.vnorm, c2.y * ec.vnorm};
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    mp[j] = fmax(mp[j], pos[j]);
+                    mn[j] = fmax(mn[j], -pos[j]);
+                }
+                if (records) emit_record(records, (long long) blockIdx.y * N * N + (long long) y * N + xx, ec, z, y, xx, pos, vel);
+            }
+        }
+    } else {
     if (a == 2) {
 #pragma unroll
         for (int e = 0; e < E; e++) cz[(t + T * e) + P * n2] = double2{re[e], im[e]};
@@ -232,6 +258,7 @@ __global__ __launch_bounds__(3 * Q *P / E) void k_xfft_q3(EpiConst ec, const cpl
             }
             if (records) emit_record(records, plane_rec0 + (long long) a * N * N + (long long) y * N + xx, ec, z + a * ec.z_pair, y, xx, pos, vel);
         }
+    }
     }
     __syncthreads();
     for (int j = 0; j < 3; j++) {
@@ -256,7 +283,7 @@ __global__ __launch_bounds__(3 * Q *P / E) void k_xfft_q3(EpiConst ec, const cpl
 // registers, reading qz from the row launch 0 left (one extra ring-row round trip instead of holding a second line's
 // results in registers: that cost 240-450 spilled dwords in every single-launch form tried).
 //   block: Q*P/E
-template <int P, int E, int Q>
+template <int P, int E, int Q, bool PLT>
 __global__ __launch_bounds__(Q *P / E) void k_xfft_seq_q(EpiConst ec, const cplx *__restrict__ twP, const cplx *__restrict__ twN,
                                                        const cplx *__restrict__ twQ, cplx *ring, int emit,
                                                        int ring_pitch, int z_first, int z_step, char *__restrict__ records,
@@ -267,9 +294,12 @@ __global__ __launch_bounds__(Q *P / E) void k_xfft_seq_q(EpiConst ec, const cplx
     constexpr int T = LQ::T, NT = T * Q;
     const int t = threadIdx.x % T, n2 = threadIdx.x / T;
     const int y = blockIdx.x, pl = blockIdx.y;
+    // ZA ring: launch 0 = array 2, launch 1 = arrays 0, 1 (the two planes).  PLT ring qx + i vx | qy + i qz | vy + i vz:
+    // launch 0 = arrays 0 and 2 (grid z = 2), launch 1 = array 1 with the records of the one plane.
     cplx *czrow = ring + ((long long) (pl * 3 + 2) * N + y) * ring_pitch;
-    const int a = emit ? (int) blockIdx.z : 2;
-    const cplx *src = ring + ((long long) (pl * 3 + a) * N + y) * ring_pitch;
+    cplx *row0  = ring + ((long long) (pl * 3 + 0) * N + y) * ring_pitch;
+    const int a = PLT ? (emit ? 1 : 2 * (int) blockIdx.z) : (emit ? (int) blockIdx.z : 2);
+    cplx *src = ring + ((long long) (pl * 3 + a) * N + y) * ring_pitch;
     double re[E], im[E];
 #pragma unroll
     for (int e = 0; e < E; e++) {
@@ -280,24 +310,32 @@ __global__ __launch_bounds__(Q *P / E) void k_xfft_seq_q(EpiConst ec, const cplx
     LQ::run(re, im, t, 0, n2, lds, twP, twN, twQ);
     if (!emit) {
 #pragma unroll
-        for (int e = 0; e < E; e++) czrow[(t + T * e) + P * n2] = cplx{re[e], im[e]};
+        for (int e = 0; e < E; e++) src[(t + T * e) + P * n2] = cplx{re[e], im[e]};
         return;
     }
-    const int z = z_first + z_step * (int) blockIdx.y;
+    const int z = z_first + z_step * (int) blockIdx.y + (PLT ? 0 : a * ec.z_pair);
     double mp[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
-    const long long plane_rec0 = 2 * (long long) blockIdx.y * N * N;
+    const long long rec0 = PLT ? (long long) blockIdx.y * N * N + (long long) y * N
+                               : 2 * (long long) blockIdx.y * N * N + (long long) a * N * N + (long long) y * N;
 #pragma unroll
     for (int e = 0; e < E; e++) {
         const int xx = (t + T * e) + P * n2;
-        const cplx cv = czrow[xx];
-        const double pos[3] = {re[e], im[e], a ? cv.y : cv.x};
-        const double vel[3] = {pos[0] * ec.vnorm, pos[1] * ec.vnorm, pos[2] * ec.vnorm};
+        const cplx c2 = czrow[xx];
+        double pos[3], vel[3];
+        if constexpr (PLT) {
+            const cplx c0 = row0[xx];
+            pos[0] = c0.x; pos[1] = re[e]; pos[2] = im[e];
+            vel[0] = c0.y * ec.vnorm; vel[1] = c2.x * ec.vnorm; vel[2] = c2.y * ec.vnorm;
+        } else {
+            pos[0] = re[e]; pos[1] = im[e]; pos[2] = a ? c2.y : c2.x;
+            vel[0] = pos[0] * ec.vnorm; vel[1] = pos[1] * ec.vnorm; vel[2] = pos[2] * ec.vnorm;
+        }
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             mp[j] = fmax(mp[j], pos[j]);
             mn[j] = fmax(mn[j], -pos[j]);
         }
-        if (records) emit_record(records, plane_rec0 + (long long) a * N * N + (long long) y * N + xx, ec, z + a * ec.z_pair, y, xx, pos, vel);
+        if (records) emit_record(records, rec0 + xx, ec, z, y, xx, pos, vel);
     }
     // workgroup reduction through LDS (the workgroup is N/16 threads: not a whole number of waves, so no wave shuffles)
     __syncthreads();
@@ -368,27 +406,31 @@ static int launch_yfft_fq_t(const FieldLayout &F, const StoreLayout &S, const cp
     ZD_LAUNCH_CHECK();
     return 0;
 }
-template <int P, int E, int Q>
+template <int P, int E, int Q, bool PLT>
 static int launch_xfft_q_t(const EpiConst &ec, const cplx *tw, const void *ring, int ring_pitch, int nplanes, int z_first, int z_step,
                            void *records, Reduce *red, hipStream_t st) {
     constexpr int N = P * Q, threads = Q * P / E;
     if constexpr (3 * threads <= 1024) {  // three lines per workgroup
         using LQ3 = zdfft::LineQ<P, E, Q, 3, true>;
-        constexpr size_t dbl = LQ3::LDS_DOUBLES > 2 * N ? LQ3::LDS_DOUBLES : 2 * N;  // FFT scratch, then cz[N] / the reduction
+        constexpr size_t stash = PLT ? 4 * N : 2 * N;  // doubles: the one (ZA) or two (PLT) lines the records read from LDS
+        constexpr size_t dbl = LQ3::LDS_DOUBLES > stash ? LQ3::LDS_DOUBLES : stash;
         const size_t shmem3 = sizeof(double) * (dbl > (size_t) 18 * threads ? dbl : (size_t) 18 * threads);
         if (shmem3 <= 160 * 1024) {
-            hipFuncSetAttribute((const void *) k_xfft_q3<P, E, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem3);
-            hipLaunchKernelGGL((k_xfft_q3<P, E, Q>), dim3(N, nplanes), dim3(3 * threads), shmem3, st, ec, tw, tw + P, tw + P + N,
+            hipFuncSetAttribute((const void *) k_xfft_q3<P, E, Q, PLT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem3);
+            hipLaunchKernelGGL((k_xfft_q3<P, E, Q, PLT>), dim3(N, nplanes), dim3(3 * threads), shmem3, st, ec, tw, tw + P, tw + P + N,
                                (const cplx *) ring, ring_pitch, z_first, z_step, (char *) records, red);
             ZD_LAUNCH_CHECK();
             return 0;
         }
     }
-    const size_t shmem = sizeof(double) * zdfft::LineQ<P, E, Q, 1, true>::LDS_DOUBLES;
-    hipFuncSetAttribute((const void *) k_xfft_seq_q<P, E, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+    using LQ = zdfft::LineQ<P, E, Q, 1, true>;
+    const size_t need = sizeof(double) * (size_t) LQ::LDS_DOUBLES, red_b = sizeof(double) * 6 * threads;
+    const size_t shmem = need > red_b ? need : red_b;
+    if (shmem > 160 * 1024) return 2;
+    hipFuncSetAttribute((const void *) k_xfft_seq_q<P, E, Q, PLT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
     for (int emit = 0; emit < 2; emit++) {
-        dim3 grid(N, nplanes, emit ? 2 : 1), block(threads);
-        hipLaunchKernelGGL((k_xfft_seq_q<P, E, Q>), grid, block, shmem, st, ec, tw, tw + P, tw + P + N, (cplx *) ring, emit, ring_pitch,
+        dim3 grid(N, nplanes, (emit != 0) == PLT ? 1 : 2), block(threads);
+        hipLaunchKernelGGL((k_xfft_seq_q<P, E, Q, PLT>), grid, block, shmem, st, ec, tw, tw + P, tw + P + N, (cplx *) ring, emit, ring_pitch,
                            z_first, z_step, (char *) records, red);
         ZD_LAUNCH_CHECK();
     }
@@ -409,8 +451,11 @@ int launch_yfft_fields_np2(const FieldLayout &F, const StoreLayout &S, const voi
 }
 int launch_xfft_np2(int N, const EpiConst &ec, const void *tw, const void *ring, int ring_pitch, int nplanes, int z_first, int z_step,
                     void *records, Reduce *red, hipStream_t st) {
-#define XC(p, q, w) \
-    if (N == (p) * (q)) return launch_xfft_q_t<p, 16, q>(ec, (const cplx *) tw, ring, ring_pitch, nplanes, z_first, z_step, records, red, st);
+#define XC(p, q, w)                                                                                                          \
+    if (N == (p) * (q))                                                                                                      \
+        return ec.pack == PACK_PLT3                                                                                          \
+                   ? launch_xfft_q_t<p, 16, q, true>(ec, (const cplx *) tw, ring, ring_pitch, nplanes, z_first, z_step, records, red, st) \
+                   : launch_xfft_q_t<p, 16, q, false>(ec, (const cplx *) tw, ring, ring_pitch, nplanes, z_first, z_step, records, red, st);
     NP2_SIZES(XC)
 #undef XC
     fprintf(stderr, "zeldovich_hip: PPD %d is not among the supported 2^a 3^b sizes\n", N);
