@@ -132,7 +132,9 @@ int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes
  * pass (Zq = ppd/R/nranks) during the XY stage.  Between the two, the caller exchanges equal
  * chunks (all-to-all): chunk d of the send buffer goes to rank d and is received as chunk `rank`…
  * of the receive buffer (exactly torch.distributed.all_to_all_single / ncclAllToAll semantics).
- * With nranks == 1 the send buffer IS the receive buffer. */
+ * With nranks == 1 the send buffer IS the receive buffer.
+ * ZD_f_NL != 0 (one rank): zd_plan_create runs the phi round of the reference (src/zeldovich.cpp:945-960) once and the plan
+ * keeps PhiK; its Z stages then read D = PhiK * M. */
 typedef struct zd_plan zd_plan;
 
 int zd_plan_create(const zd_params *p, const zd_pk *pk, const double *eig, int64_t eig_ppd, int rank,

@@ -425,6 +425,38 @@ def test_fnl_end_to_end(zd, oracle, ps, wmap_path, n, kw):
     assert abs(got["density_variance"] - ref["density_variance"]) <= TOL * ref["density_variance"]
 
 
+def test_fnl_through_the_staged_api(zd, oracle, ps, wmap_path):
+    """ZD_f_NL through zd_plan_create + the staged pipeline (what bench.py drives): the phi round runs at plan creation, the
+    plan owns PhiK; every plane against the oracle"""
+    import ctypes as C
+    import torch
+    from zeldovich_plt_amd.parallel import HipEngine, SlabPipeline
+    n, fmt = 64, "RVdoubleZel"
+    fnl, ns, om = 2.0e4, 0.96, 0.31
+    opk = oracle.pk_from_file(wmap_path, 720.0)
+    oracle.lib().zdo_pk_set_primordial(C.byref(opk), ns)
+    plan = zd.Plan(zd.make_params(n, icformat=fmt, stream_factor=2, f_NL=fnl, n_s=ns, Omega_M=om), ps)
+    pipe = SlabPipeline(HipEngine(plan, n), n, device="cuda", chunk_bytes=7 * n * n * 56)
+    dt = zd.RECORD_DTYPES[fmt]
+    rec = np.zeros((n, n * n), dtype=dt)
+    seen = []
+
+    def consume(zs, ring):
+        torch.cuda.synchronize()
+        host = ring.cpu().numpy()[:len(zs) * n * n * dt.itemsize].view(dt).reshape(len(zs), n * n)
+        for i, z in enumerate(zs):
+            rec[z] = host[i]
+            seen.append(z)
+
+    pipe.run(consume)
+    assert sorted(seen) == list(range(n))
+    ref = oracle.run(oracle.make_params(n, numblock=2, icformat=fmt, f_NL=fnl, n_s=ns, Omega_M=om), opk)["records"].reshape(n, n * n)
+    assert _rel(rec["d"], ref["d"]) < TOL and _rel(rec["v"], ref["v"]) < TOL
+    plan.close()
+    with pytest.raises(RuntimeError):  # the phi round needs every plane on one rank
+        zd.Plan(zd.make_params(n, icformat=fmt, f_NL=fnl, n_s=ns, Omega_M=om), ps, rank=0, nranks=2)
+
+
 def test_fnl_with_plt(zd, oracle, ps, wmap_path):
     import ctypes as C
     eig = oracle.synthetic_eigenmodes(32)

@@ -318,13 +318,59 @@ int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes
 static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig, int64_t eig_ppd, int rank, int nranks,
                           int phi_mode, const cplx *phik, zd_plan **out);
 
+// f_NL: phi field -> local transform phi + f_NL phi^2 -> Fourier space again (zeldovich.cpp:945-960, 699-790): the first
+// ZeldovichZ / ZeldovichXY_Phi round of the reference, run once; *d_phik = PhiK[ky][kz][x] for the half-space rows (owned
+// by the caller).  One rank: the forward z transform needs every plane resident.
+static int make_phik(const zd_params *p, const zd_pk *pk, cplx **d_phik) {
+    const int64_t N  = p->ppd;
+    zd_params pp     = *p;
+    pp.stream_factor = 1;
+    pp.qPLT          = 0;  // the phi pass never reaches the displacement algebra
+    zd_plan *ph      = nullptr;
+    if (plan_create_ex(&pp, pk, nullptr, 0, 0, 1, 1, nullptr, &ph)) return 1;
+    void *d_phi = nullptr;
+    int frc     = 1;
+    *d_phik     = nullptr;
+    do {
+        if (hipMalloc(&d_phi, (size_t) zd_plan_exchange_bytes(ph)) != hipSuccess
+            || hipMalloc((void **) d_phik, (size_t) (N / 2) * N * N * 16) != hipSuccess) {
+            fprintf(stderr, "zeldovich_hip: f_NL needs %.1f GB of HBM for the phi field at PPD %lld\n",
+                    (zd_plan_exchange_bytes(ph) + (N / 2) * N * N * 16) / 1e9, (long long) N);
+            break;
+        }
+        fprintf(stderr, "Generating phi field\n");
+        if (zd_plan_stage_z(ph, 0, d_phi, 0) || zd_plan_stage_y(ph, d_phi, 0)) break;
+        if (zd::launch_fnl_stage(0, ph->S, p->f_NL, ph->d_twN, d_phi, nullptr, 0)) break;
+        if (zd::launch_fnl_stage(1, ph->S, p->f_NL, ph->d_twN, d_phi, nullptr, 0)) break;
+        if (zd::launch_fnl_stage(2, ph->S, p->f_NL, ph->d_twN, d_phi, *d_phik, 0)) break;
+        if (hipDeviceSynchronize() != hipSuccess) break;
+        frc = 0;
+    } while (0);
+    hipFree(d_phi);
+    zd_plan_destroy(ph);
+    if (frc) {
+        hipFree(*d_phik);
+        *d_phik = nullptr;
+    }
+    return frc;
+}
+
 int zd_plan_create(const zd_params *p, const zd_pk *pk, const double *eig, int64_t eig_ppd, int rank, int nranks,
                    zd_plan **out) {
-    if (p->f_NL != 0.) {
-        fprintf(stderr, "zeldovich_hip: ZD_f_NL != 0 is only available through zd_generate (single GPU)\n");
+    if (p->f_NL == 0.) return plan_create_ex(p, pk, eig, eig_ppd, rank, nranks, 0, nullptr, out);
+    // ZD_f_NL: the phi round runs here, once; the plan owns PhiK and its Z stages read D = PhiK * M
+    if (nranks != 1) {
+        fprintf(stderr, "zeldovich_hip: ZD_f_NL != 0 runs on one rank (the forward z transform of the phi field needs every plane)\n");
         return 1;
     }
-    return plan_create_ex(p, pk, eig, eig_ppd, rank, nranks, 0, nullptr, out);
+    cplx *d_phik = nullptr;
+    if (make_phik(p, pk, &d_phik)) return 1;
+    if (plan_create_ex(p, pk, eig, eig_ppd, 0, 1, 0, d_phik, out)) {
+        hipFree(d_phik);
+        return 1;
+    }
+    (*out)->d_phik_owned = d_phik;
+    return 0;
 }
 
 static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig, int64_t eig_ppd, int rank, int nranks,
@@ -816,6 +862,7 @@ void zd_plan_destroy(zd_plan *pl) {
     hipFree(pl->d_v1streams);
     hipFree(pl->d_v1dev);
     hipFree(pl->d_v1err);
+    hipFree(pl->d_phik_owned);
     for (cplx *y : pl->d_Y) hipFree(y);
     if (pl->s_gen) hipStreamDestroy(pl->s_gen);
     if (pl->s_fft) hipStreamDestroy(pl->s_fft);
@@ -1090,34 +1137,7 @@ int zd_generate(const zd_params *p_in, const zd_pk *pk, const double *eig, int64
     // ---- f_NL: phi field -> local transform -> Fourier space again (zeldovich.cpp:945-960) ----
     cplx *d_phik = nullptr;
     if (p.f_NL != 0.) {
-        zd_params pp     = p;
-        pp.stream_factor = 1;  // the forward z transform needs every plane resident
-        pp.qPLT          = 0;  // the phi pass never reaches the displacement algebra
-        zd_plan *ph      = nullptr;
-        if (plan_create_ex(&pp, pk, nullptr, 0, 0, 1, 1, nullptr, &ph)) return 1;
-        void *d_phi = nullptr;
-        int frc     = 1;
-        do {
-            if (hipMalloc(&d_phi, (size_t) zd_plan_exchange_bytes(ph)) != hipSuccess
-                || hipMalloc((void **) &d_phik, (size_t) (N / 2) * N * N * 16) != hipSuccess) {
-                fprintf(stderr, "zeldovich_hip: f_NL needs %.1f GB of HBM for the phi field at PPD %lld\n",
-                        (zd_plan_exchange_bytes(ph) + (N / 2) * N * N * 16) / 1e9, (long long) N);
-                break;
-            }
-            fprintf(stderr, "Generating phi field\n");
-            if (zd_plan_stage_z(ph, 0, d_phi, 0) || zd_plan_stage_y(ph, d_phi, 0)) break;
-            if (zd::launch_fnl_stage(0, ph->S, p.f_NL, ph->d_twN, d_phi, nullptr, 0)) break;
-            if (zd::launch_fnl_stage(1, ph->S, p.f_NL, ph->d_twN, d_phi, nullptr, 0)) break;
-            if (zd::launch_fnl_stage(2, ph->S, p.f_NL, ph->d_twN, d_phi, d_phik, 0)) break;
-            if (hipDeviceSynchronize() != hipSuccess) break;
-            frc = 0;
-        } while (0);
-        hipFree(d_phi);
-        zd_plan_destroy(ph);
-        if (frc) {
-            hipFree(d_phik);
-            return 1;
-        }
+        if (make_phik(&p, pk, &d_phik)) return 1;
         HIPCHECK(hipMemGetInfo(&free_b, &total_b));
         if (p_in->stream_factor <= 0) {
             const int R2 = zd_choose_stream_factor(&p, 1, (int64_t) free_b - ((int64_t) 16 << 30));

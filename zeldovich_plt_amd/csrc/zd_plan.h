@@ -65,6 +65,7 @@ struct zd_plan {
     zd::V1Stream *d_v1streams = nullptr;
     double2 *d_v1dev = nullptr;     // [slab row][z][x]
     int *d_v1err = nullptr;
+    zdfft::cplx *d_phik_owned = nullptr;  // ZD_f_NL through zd_plan_create: PhiK of the phi round (zd_generate keeps its own)
     // timing
     std::vector<EventPair> events;
     std::vector<hipEvent_t> pool;
