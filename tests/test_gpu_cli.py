@@ -94,3 +94,32 @@ def test_cli_version1(tmp_path, oracle):
         got = np.fromfile(out / ("ic_%d" % f), dtype=dt).reshape(len(zs), n, n)
         want = ref["records"][zs]
         assert np.abs(got["d"] - want["d"]).max() <= 1e-10 * np.abs(want["d"]).max()
+
+
+def test_cli_plt_on_a_composite_grid(tmp_path, oracle):
+    """the production Abacus shape in small: NP = 96^3 (2^5 3) with ZD_qPLT + rescale from an eigenmode FILE in the
+    reference's layout (int32 ppd + ppd^2 (ppd/2+1) 4 doubles, src/zeldovich.cpp:794-830), through `zeldovich <param_file>`"""
+    n, cpd = 96, 7
+    out = tmp_path / "ic"
+    out.mkdir()
+    eig = oracle.synthetic_eigenmodes(32)
+    eigfile = tmp_path / "eigmodes32"
+    with open(eigfile, "wb") as f:
+        f.write(np.int32(32).tobytes())
+        f.write(np.ascontiguousarray(eig, dtype=np.float64).tobytes())
+    par = tmp_path / "plt.par"
+    par.write_text(PAR % dict(cpd=cpd, fmt="RVZel", out=out, np=n ** 3, pk=WMAP, qd=0, R=2)
+                   + 'ZD_qPLT = 1\nZD_qPLT_rescale = 1\nZD_PLT_target_z = 5.0\nZD_PLT_filename = "%s"\nZD_f_cluster = 0.97\n' % eigfile)
+    r = subprocess.run([EXE, str(par)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    pk = oracle.pk_from_file(WMAP, 720.0)
+    ref = oracle.run(oracle.make_params(n, numblock=2, icformat="RVZel", cpd=cpd, qPLT=1, qPLTrescale=1, PLT_target_z=5.0,
+                                        f_cluster=0.97), pk, eig=eig, eig_ppd=32)
+    dt = oracle.RECORD_DTYPES["RVZel"]
+    for f in sorted(set(z * cpd // n for z in range(n))):
+        zs = [z for z in range(n) if z * cpd // n == f]
+        got = np.fromfile(out / ("ic_%d" % f), dtype=dt).reshape(len(zs), n, n)
+        want = ref["records"][zs]
+        assert np.array_equal(got["ijk"], want["ijk"])
+        assert np.abs(got["d"] - want["d"]).max() <= 1e-6 * np.abs(want["d"]).max()
+        assert np.abs(got["v"] - want["v"]).max() <= 1e-6 * np.abs(want["v"]).max()
