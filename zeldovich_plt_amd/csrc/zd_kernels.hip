@@ -1042,19 +1042,16 @@ __device__ __forceinline__ double genf_tile_mirror(const GenConst &g, const GenJ
             const double k2v = (double) k2i * g.fundamental2;
             const double P   = genf_power<PLAW>(g, T, k2v);
             const double q   = g.fundamental * frcp(k2v);
-            // W_R^{k1 r} (and the second residue's)
-            double wr = 1.0, wi = 0.0, w2r = 1.0, w2i = 0.0;
+            // W_R^{k1 r}.  The second residue of a pass is r + R/2 (zd_plan_stage_z; checked by the launcher), so its
+            // twiddle is W_R^{k1 r} (-1)^{k1}: the same products with a sign.
+            double wr = 1.0, wi = 0.0;
             if (R > 1) {
                 const cplx w = twN[modn(N, k1 * residue * L)];
                 wr = w.x;
                 wi = w.y;
-                if constexpr (ZA2) {
-                    const cplx w2 = twN[modn(N, k1 * residue2 * L)];
-                    w2r = w2.x;
-                    w2i = w2.y;
-                }
             }
             const double dkz = (double) kz;
+            const double sg2 = (k1 & 1) ? -1.0 : 1.0, dkz2 = (k1 & 1) ? -dkz : dkz;
             auto one = [&](uint64_t r1, uint64_t r2, double (&ar)[NACC], double (&ai)[NACC]) {
                 // cgauss<2> (power_spectrum.cpp:338-359); zeroed lanes of a live wave ride along with amplitude 0
                 const uint64_t m1 = r1 + 1ULL;
@@ -1065,7 +1062,7 @@ __device__ __forceinline__ double genf_tile_mirror(const GenConst &g, const GenJ
                 double sn, cs;
                 sincos_u01(u64_to_double(r2 + 1ULL), T, sn, cs);
                 const double d0r = amp * cs, d0i = amp * sn;
-                vsum = fma(d0r, d0r, fma(d0i, d0i, vsum));
+                vsum += v;  // |D|^2 = amp^2 (cos^2 + sin^2)
                 const double dr = d0r * wr - d0i * wi, di = d0r * wi + d0i * wr;
                 if constexpr (KIND == GENF_DENS) {
                     ar[0] += dr;
@@ -1082,11 +1079,8 @@ __device__ __forceinline__ double genf_tile_mirror(const GenConst &g, const GenJ
                     ar[0] += er;
                     ai[0] += ei;
                     cmac(ar[1], ai[1], dkz, er, ei);
-                    const double d2r = d0r * w2r - d0i * w2i, d2i = d0r * w2i + d0i * w2r;
-                    const double e2r = q * d2r, e2i = q * d2i;
-                    ar[2] += e2r;
-                    ai[2] += e2i;
-                    cmac(ar[3], ai[3], dkz, e2r, e2i);
+                    cmac(ar[2], ai[2], sg2, er, ei);
+                    cmac(ar[3], ai[3], dkz2, er, ei);
                 }
             };
             one(r1A, r2A, aAr, aAi);
@@ -2028,6 +2022,8 @@ static int launch_genf_t(const GenConst &g, const GenJumps &J, const StoreLayout
     constexpr bool mirror_off = false;
 #endif
     const bool mirror = za && (!mirror_off || KIND == GENF_ZAF);  // the field store's blocked layout exists in the mirror form only
+    // the mirror form folds the second residue of a pass as (-1)^k1 times the first: it must be residue + R/2
+    if (mirror && (KIND == GENF_ZAP || KIND == GENF_ZAF) && residue2 != residue + (N / L) / 2) return 2;
     const bool blk = (mirror && KIND == GENF_ZAF) || KIND == GENF_PLTF;
     const int xw = blk ? GEN_BX / FIELD_RB : GEN_BX;
     const int gx = ((mirror ? N / 2 + 1 : N) + xw - 1) / xw;
