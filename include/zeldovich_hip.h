@@ -114,7 +114,8 @@ typedef struct zd_stats {
 typedef int (*zd_slab_cb)(void *user, int64_t z, int64_t n_records, const void *records,
                           const float *density);
 
-/* One call = ZeldovichZ + ZeldovichXY (src/zeldovich.cpp:517-695) on one GPU.
+/* One call = ZeldovichZ + ZeldovichXY (src/zeldovich.cpp:517-695) on one GPU, or on p->ngpu GPUs of this node (one host thread
+ * per GPU inside the library, the block exchange over RCCL / xGMI; the callback still comes from one thread at a time).
  *   eig / eig_ppd: PLT eigenmode table as loaded by load_eigmodes (src/zeldovich.cpp:794-830),
  *                  [eig_ppd][eig_ppd][eig_ppd/2+1][4] doubles; NULL/0 unless qPLT.
  *   cb may be NULL: planes are then produced in HBM and dropped (benchmark sink). */

@@ -1,8 +1,8 @@
 // zd_host.cpp — host-side setup that stays on the CPU, behind the C ABI of include/zeldovich_hip.h:
 //   * the parameter file reader + Parameters::setup      (src/parameters.cpp:11-197; the reference
-//     parses with the flex/bison ParseHeader library — this is a plain `key = value` reader that
-//     covers every construct used by the shipped .par files: comments, quoted strings, ints, floats
-//     with Fortran D exponents, integer vectors)
+//     parses with the flex/bison ParseHeader library — this is a hand-written reader of the same grammar:
+//     comments and ## blocks, `include`, continuation lines, quoted strings, ints, floats with Fortran D
+//     exponents, logical keywords, vectors, `vcounter` / `vector` blocks, `mapvar` aliases)
 //   * PowerSpectrum tables and normalisation             (src/power_spectrum.cpp:50-223,
 //     include/spline_function.h:77-163)
 //   * the PLT eigenmode file loader                      (src/zeldovich.cpp:794-830)
