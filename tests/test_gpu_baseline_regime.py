@@ -199,6 +199,7 @@ def test_ppd16384_k_cutoff4_planes_equal_ppd4096(zd):
     (8192, 2.0, 64, 128, [(3, 5, -7), (-1001, 777, 1200), (0, 2, 0)]),   # k_xfft_two<8192, PLT>
     (6912, 4.0, 8, 16, [(3, 5, -7), (-401, 377, 500)]),                  # composite kernels, x pass in two launches
     (3456, 2.0, 4, 8, [(-3, 5, 7), (401, 377, -500)]),                   # composite kernels, three lines per workgroup
+    (6912, 1.0, 64, None, [(-2001, 1777, 1200)]),                        # production Abacus on ONE GPU: z lines of 108 = 4 * 27
 ])
 def test_large_plt_plane_waves_and_stream_invariance(zd, oracle, n, kc, Ra, Rb, modes):
     """PLT + rescale at the sizes that only the PLT FIELD store serves — PPD = 8192 (the y pass at 8192 and the x pass in two
@@ -237,12 +238,43 @@ def test_large_plt_plane_waves_and_stream_invariance(zd, oracle, n, kc, Ra, Rb, 
             want = rescale * e[j] * fund / k2 * wave
             assert np.abs(rec["d"][..., 2 - j] - want).max() <= 1e-12 * scale, (mode, j)
             assert np.abs(rec["v"][..., 2 - j] - f * want).max() <= 1e-12 * f * scale, (mode, j)
+    if Rb is None:  # only one stream factor fits the GPU
+        return
     a, ia = _planes(zd, ps, n, [z], stride=8, stream_factor=Ra, **kw)
     b, ib = _planes(zd, ps, n, [z], stride=8, stream_factor=Rb, **kw)
     print(ia, ib)
     for f_ in ("d", "v"):
         assert np.abs(a[z][f_]).max() > 0
         assert np.abs(a[z][f_] - b[z][f_]).max() <= 1e-12 * np.abs(a[z][f_]).max()
+
+
+def test_ppd6912_on_one_gpu_plane_waves(zd, oracle):
+    """PPD = 6912 = 2^8 3^3 at ZD_k_cutoff = 1 — the production Abacus grid — on ONE GPU: R = 64, z lines of 108 = 4 * 27.
+    One-mode runs against the closed form q_j(x) = -2 (k_j fund / k^2) (Re D sin t + Im D cos t), v = vnorm q, with D(k) from
+    the oracle's per-mode draw; the random-field path of these kernels is covered at PPD = 864 / 1728
+    (test_non_power_of_two_short_z_lines) and by 6912 (k_cutoff = 2) <-> 3456."""
+    ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
+    opk = oracle.pk_from_file(WMAP, 720.0)
+    n, z, fc = 6912, 3461, 0.9
+    op = oracle.make_params(n, f_cluster=fc)
+    L = oracle.lib()
+    fund = 2 * np.pi / 720.0
+    vnorm = (np.sqrt(1 + 24 * fc) - 1) / 4
+    yy, xx = np.meshgrid(np.arange(0, n, 16), np.arange(0, n, 16), indexing="ij")
+    for mode in [(-2001, 1777, 1200), (5, 3, -7)]:
+        got, info = _planes(zd, ps, n, [z], stride=16, fmt="RVdoubleZel", f_cluster=fc, qonemode=1, one_mode=mode)
+        assert info["R"] == 64
+        r, D = (C.c_uint64 * 2)(), (C.c_double * 2)()
+        L.zdo_mode_draw(C.byref(op), C.byref(opk), mode[0], mode[1], mode[2], r, D)
+        k2 = sum(m * m for m in mode) * fund * fund
+        t = 2 * np.pi * ((mode[0] * xx + mode[1] * yy + mode[2] * z) % n) / n
+        wave = -2.0 * (D[0] * np.sin(t) + D[1] * np.cos(t))
+        scale = max(abs(m) for m in mode) * fund / k2 * np.abs(wave).max()
+        rec = got[z]
+        for j in range(3):
+            want = mode[j] * fund / k2 * wave
+            assert np.abs(rec["d"][..., 2 - j] - want).max() <= 1e-12 * scale, (mode, j)
+            assert np.abs(rec["v"][..., 2 - j] - vnorm * want).max() <= 1e-12 * vnorm * scale, (mode, j)
 
 
 def test_ppd2048_plt_store_and_stream_invariance(zd, oracle):

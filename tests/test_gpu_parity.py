@@ -648,6 +648,33 @@ def test_non_power_of_two_oversampling_invariance(zd, ps):
     assert np.abs(a["max_disp"] - b["max_disp"]).max() <= 1e-11 * np.abs(a["max_disp"]).max()
 
 
+def test_non_power_of_two_short_z_lines(zd, oracle, ps):
+    """z lines of 108 = 4 * 27 (generator threads walk 4 z rows instead of 16; one thread per 4-point sub-line in the z
+    transform) — what lets PPD = 6912 run on ONE GPU at ZD_k_cutoff = 1 (R = 64).  PPD = 864 at R = 8 against R = 2 (z lines
+    of 432), ZA and PLT, on sample planes; 1728 (k_cutoff = 2, R = 16) against 864"""
+    n = 864
+    zs = (2, n // 2 + 5, n - 3)
+    eig = oracle.synthetic_eigenmodes(32)
+    for kw, e in ((dict(icformat="Zeldovich"), None),
+                  (dict(icformat="RVdoubleZel", qPLT=1, qPLTrescale=1, PLT_target_z=5.0, f_cluster=0.97), eig)):
+        a, b = {}, {}
+        zd.generate_planes(zd.make_params(n, stream_factor=2, **kw), ps, lambda z, rec: a.__setitem__(z, rec.copy()) if z in zs else None, eig=e)
+        zd.generate_planes(zd.make_params(n, stream_factor=8, **kw), ps, lambda z, rec: b.__setitem__(z, rec.copy()) if z in zs else None, eig=e)
+        assert sorted(a) == sorted(b) == sorted(zs)
+        for z in zs:
+            for f in ("d", "v"):
+                if f in a[z].dtype.names:
+                    assert np.abs(a[z][f]).max() > 0
+                    assert np.abs(a[z][f] - b[z][f]).max() <= 1e-12 * np.abs(a[z][f]).max(), (kw, z, f)
+    lo, hi = {}, {}
+    zd.generate_planes(zd.make_params(n, icformat="Zeldovich", stream_factor=8), ps,
+                       lambda z, rec: lo.__setitem__(z, rec["d"].copy()) if z in zs else None)
+    zd.generate_planes(zd.make_params(2 * n, icformat="Zeldovich", k_cutoff=2.0, stream_factor=16), ps,
+                       lambda z, rec: hi.__setitem__(z // 2, rec["d"][::2, ::2].copy()) if (z % 2 == 0 and z // 2 in zs) else None)
+    for z in zs:
+        assert np.abs(hi[z] - lo[z]).max() < 1e-12 * np.abs(lo[z]).max(), z
+
+
 # ---- ZD_Version = 1: legacy mt19937 streams with rejection sampling (SURVEY §8 f4) ----
 @pytest.mark.parametrize("seed", [12346, 5489, 0, 2 ** 32 + 7])
 def test_v1_stream_words(zd, seed):

@@ -1999,19 +1999,33 @@ namespace zd {
 int zfft_tile_width(int L);
 int zfft_fields_tile_columns(int L);
 
-template <int NJ, bool PLT, bool PLAW>
-static int launch_gen_t(const GenConst &g, const GenJumps &J, const JobList &jobs, const StoreLayout &S, int ky0, int nky,
+// z rows walked by one generator thread: 16, or 4 for the short composite z lines (L = 108 = 4 * 27: PPD = 6912 on ONE GPU)
+static int gen_zr(int L) { return L % GEN_ZR == 0 ? GEN_ZR : (L % 4 == 0 ? 4 : 0); }
+
+template <int ZR, int NJ, bool PLT, bool PLAW>
+static int launch_gen_z(const GenConst &g, const GenJumps &J, const JobList &jobs, const StoreLayout &S, int ky0, int nky,
                         int nrows, int L, int residue, int residue2, const void *twN, void *Y, hipStream_t st) {
     const int N = g.N;
-    dim3 grid((N + GEN_BX - 1) / GEN_BX, L / GEN_ZR, nrows), block(GEN_BX);
+    dim3 grid((N + GEN_BX - 1) / GEN_BX, L / ZR, nrows), block(GEN_BX);
     const int zw = zfft_tile_width(L) > 0 ? zfft_tile_width(L) : 16;  // (composite L: any width is a safe neighbourhood)
-    hipLaunchKernelGGL((k_gen<GEN_ZR, NJ, PLT, PLAW>), grid, block, 0, st, g, J, jobs, S, zw, ky0, nky,
+    hipLaunchKernelGGL((k_gen<ZR, NJ, PLT, PLAW>), grid, block, 0, st, g, J, jobs, S, zw, ky0, nky,
                        L, residue, residue2, (const cplx *) twN, (cplx *) Y);
     ZD_LAUNCH_CHECK();
     return 0;
 }
-template <int KIND, bool PLAW>
-static int launch_genf_t(const GenConst &g, const GenJumps &J, const StoreLayout &S, int ky0, int kyl0, int nky, int nrows,
+template <int NJ, bool PLT, bool PLAW>
+static int launch_gen_t(const GenConst &g, const GenJumps &J, const JobList &jobs, const StoreLayout &S, int ky0, int nky,
+                        int nrows, int L, int residue, int residue2, const void *twN, void *Y, hipStream_t st) {
+    if (gen_zr(L) == GEN_ZR) return launch_gen_z<GEN_ZR, NJ, PLT, PLAW>(g, J, jobs, S, ky0, nky, nrows, L, residue, residue2, twN, Y, st);
+    // the short walk exists for the field stores only (their ky = 0 row: 4 ZA jobs, 6 PLT jobs)
+    if constexpr ((NJ == 4 && !PLT) || (NJ == 6 && PLT)) {
+        if (gen_zr(L) == 4 && pack_is_fields(jobs.pack))
+            return launch_gen_z<4, NJ, PLT, PLAW>(g, J, jobs, S, ky0, nky, nrows, L, residue, residue2, twN, Y, st);
+    }
+    return 2;
+}
+template <int ZR, int KIND, bool PLAW>
+static int launch_genf_z(const GenConst &g, const GenJumps &J, const StoreLayout &S, int ky0, int kyl0, int nky, int nrows,
                          int L, int residue, int residue2, const void *twN, void *Y, unsigned *tile_ctr, int max_wgs,
                          hipStream_t st) {
     const int N = g.N;
@@ -2027,23 +2041,35 @@ static int launch_genf_t(const GenConst &g, const GenJumps &J, const StoreLayout
     const bool blk = (mirror && KIND == GENF_ZAF) || KIND == GENF_PLTF;
     const int xw = blk ? GEN_BX / FIELD_RB : GEN_BX;
     const int gx = ((mirror ? N / 2 + 1 : N) + xw - 1) / xw;
-    const long long ntiles = (long long) gx * (L / GEN_ZR) * (blk ? nky / FIELD_RB : nrows);
+    const long long ntiles = (long long) gx * (L / ZR) * (blk ? nky / FIELD_RB : nrows);
     dim3 grid((unsigned) std::min<long long>(ntiles, max_wgs)), block(GEN_BX);
     const size_t shmem = sizeof(double) * (size_t) (g.genf_n + 2);
     if constexpr (za) {
         if (mirror) {
-            hipLaunchKernelGGL((k_genf<GEN_ZR, KIND, PLAW, true>), grid, block, shmem, st, g, J, S,
+            hipLaunchKernelGGL((k_genf<ZR, KIND, PLAW, true>), grid, block, shmem, st, g, J, S,
                                KIND == GENF_ZAF ? zfft_fields_tile_columns(L) : zfft_tile_width(L), ky0, kyl0,
                                nky, nrows, L, residue, residue2, (const cplx *) twN, (cplx *) Y, tile_ctr);
             ZD_LAUNCH_CHECK();
             return 0;
         }
     }
-    hipLaunchKernelGGL((k_genf<GEN_ZR, KIND, PLAW, false>), grid, block, shmem, st, g, J, S,
+    hipLaunchKernelGGL((k_genf<ZR, KIND, PLAW, false>), grid, block, shmem, st, g, J, S,
                        KIND == GENF_PLTF ? zfft_fields_tile_columns(L) : zfft_tile_width(L), ky0, kyl0, nky,
                        nrows, L, residue, residue2, (const cplx *) twN, (cplx *) Y, tile_ctr);
     ZD_LAUNCH_CHECK();
     return 0;
+}
+template <int KIND, bool PLAW>
+static int launch_genf_t(const GenConst &g, const GenJumps &J, const StoreLayout &S, int ky0, int kyl0, int nky, int nrows,
+                         int L, int residue, int residue2, const void *twN, void *Y, unsigned *tile_ctr, int max_wgs,
+                         hipStream_t st) {
+    if (gen_zr(L) == GEN_ZR)
+        return launch_genf_z<GEN_ZR, KIND, PLAW>(g, J, S, ky0, kyl0, nky, nrows, L, residue, residue2, twN, Y, tile_ctr, max_wgs, st);
+    if constexpr (KIND == GENF_ZAF || KIND == GENF_PLTF) {  // the short walk: field stores only
+        if (gen_zr(L) == 4)
+            return launch_genf_z<4, KIND, PLAW>(g, J, S, ky0, kyl0, nky, nrows, L, residue, residue2, twN, Y, tile_ctr, max_wgs, st);
+    }
+    return 2;
 }
 template <int KIND>
 static int launch_genf_k(const GenConst &g, const GenJumps &J, const StoreLayout &S, int ky0, int kyl0, int nky, int nrows,
@@ -2077,7 +2103,7 @@ static int genf_kind(const JobList &jobs, bool plt) {
 }
 int launch_gen(const GenConst &g, const GenJumps &J, const JobList &jobs, const StoreLayout &S, int ky0, int nky, int L,
                int residue, int residue2, const void *twN, void *Y, unsigned *tile_ctr, int max_wgs, hipStream_t st) {
-    if (L % GEN_ZR != 0) return 2;
+    if (gen_zr(L) == 0) return 2;
 #ifdef ZD_TUNING
     static const bool force_general = getenv("ZD_GEN_GENERAL") != nullptr;
 #else

@@ -381,13 +381,15 @@ int launch_zfft_fields_np2(int L, const FieldLayout &F, const StoreLayout &S, in
     ZC(16, 9, 4) ZC(32, 9, 2) ZC(64, 9, 1) ZC(128, 9, 1)
     ZC(16, 27, 2) ZC(32, 27, 1) ZC(64, 27, 1)
 #undef ZC
+    // 108 = 4 * 27: four elements per thread, one thread per sub-line (PPD = 6912 at R = 64 — the whole grid on ONE GPU)
+    if (L == 108) return launch_zfft_fq_t<4, 4, 27, 2>(F, S, ky0, kyloc0, nky, Y, (const cplx *) tw, out, st);
     fprintf(stderr, "zeldovich_hip: no z transform of length %d (16*2^k * {3, 9, 27} up to 1728)\n", L);
     return 2;
 }
 int zfft_fields_np2_columns(int L) {
     switch (L) {
         case 48: case 96: case 192: case 144: return 4;
-        case 384: case 288: case 432: return 2;
+        case 384: case 288: case 432: case 108: return 2;
         default: return 1;
     }
 }
@@ -470,6 +472,7 @@ bool np2_supported_ppd(int N) {
 }
 bool np2_supported_zlen(int L) {
     int P, Q;
+    if (L == 108) return true;  // 4 * 27 (launch_zfft_fields_np2)
     if (!np2_split(L, &P, &Q) || P < 16) return false;
     return (Q == 3 && P <= 512) || (Q == 9 && P <= 128) || (Q == 27 && P <= 64);
 }
@@ -502,7 +505,7 @@ bool np2_split(int n, int *P, int *Q) {
         p /= 3;
         q *= 3;
     }
-    if (q == 1 || q > 27 || p < 8 || (p & (p - 1)) != 0) return false;
+    if (q == 1 || q > 27 || p < 4 || (p & (p - 1)) != 0) return false;
     *P = p;
     *Q = q;
     return true;
