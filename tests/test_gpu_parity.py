@@ -573,6 +573,28 @@ def test_two_ranks_equal_one_rank_at_1024(zd, ps):
     assert a["planes"] == b["planes"] == n
 
 
+def test_eight_ranks_equal_one_rank(zd, ps):
+    """the geometry the 8-GPU scaling run uses (8 ranks: rows ky = rank mod 8, Zq = L/8 planes per rank, plane-group exchange),
+    with the ranks as threads sharing this one GPU (local transport): PPD = 2048 — records of sample planes equal to the
+    single-rank run; PPD = 4096 (BASELINE C4's size; R = 32 so that eight stores fit one GPU) — the reductions over every
+    particle (max_disp per component, sum delta^2) equal to the single-rank run"""
+    n, zs = 2048, (5, 1029, 2046)
+    got = {}
+    for ngpu in (1, 8):
+        planes = {}
+        p = zd.make_params(n, icformat="ZelSimple", ngpu=ngpu, stream_factor=8 if ngpu > 1 else 0, exchange_planes=5 if ngpu > 1 else 0)
+        out = zd.generate_planes(p, ps, lambda z, rec: planes.__setitem__(z, rec["d"].copy()) if z in zs else None)
+        got[ngpu] = (planes, out)
+    for z in zs:
+        a, b = got[1][0][z], got[8][0][z]
+        assert np.abs(a - b).max() <= 1e-6 * np.abs(a).max(), z
+    assert got[1][1]["planes"] == got[8][1]["planes"] == n
+    a = zd.generate(zd.make_params(4096, icformat="RVZel"), ps, collect=False)
+    b = zd.generate(zd.make_params(4096, icformat="RVZel", ngpu=8, stream_factor=32, exchange_planes=2), ps, collect=False)
+    assert abs(a["density_variance"] - b["density_variance"]) <= 1e-11 * a["density_variance"]
+    assert np.abs(a["max_disp"] - b["max_disp"]).max() <= 1e-11 * np.abs(a["max_disp"]).max()
+
+
 @pytest.mark.parametrize("n", [24, 72, 216, 48, 144, 432, 96, 288, 864, 192, 576, 1728, 384, 1152, 3456, 768, 2304, 6912,
                                1536, 4608, 3072])
 @pytest.mark.parametrize("kind", [0, 1])
