@@ -157,10 +157,11 @@ def _planes(zd, ps, n, zs, stride=1, eig=None, fmt="Zeldovich", **kw):
     return res, info
 
 
-@pytest.mark.parametrize("n", [2048, 4096, 3456])
+@pytest.mark.parametrize("n", [2048, 4096, 3456, 1000])
 def test_oversampled_planes_exact_at_full_size(zd, n):
     """PPD = 2n, ZD_k_cutoff = 2 at even lattice sites == PPD = n, ZD_k_cutoff = 1 (8192 <-> 4096: BASELINE C5 / C4,
-    4096 <-> 2048: C3 size; 6912 <-> 3456: the production Abacus size 6912 = 2^8 3^3 on the composite-transform kernels),
+    4096 <-> 2048: C3 size; 6912 <-> 3456: the production Abacus size 6912 = 2^8 3^3 on the composite-transform kernels;
+    2000 <-> 1000: the any-PPD convolution kernels, zd_kernels_any.hip),
     records compared exactly (1e-13 of the field maximum) on planes of three different passes"""
     ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
     zs = [5, n // 2 + 3, n - 2]
@@ -176,7 +177,7 @@ def test_oversampled_planes_exact_at_full_size(zd, n):
         assert scale > 0
         err = np.abs(a["d"] - b["d"]).max() / scale
         print("  z", z, "max |d(2n, even sites) - d(n)| / max|d| =", err)
-        assert err < (1e-13 if n != 3456 else 1e-12)  # composite transforms: 27-term outer sums
+        assert err < (1e-13 if n in (2048, 4096) else 1e-12)  # composite transforms: 27-term outer sums; 1000 / 2000: convolutions
 
 
 def test_ppd16384_k_cutoff4_planes_equal_ppd4096(zd):

@@ -758,3 +758,44 @@ def test_version1_properties(zd, ps):
 def test_version1_with_fnl_rejected(zd, ps):
     with pytest.raises(RuntimeError):
         zd.generate(zd.make_params(64, numblock=4, version=1, f_NL=10.0, n_s=0.96, Omega_M=0.3), ps)
+
+
+# ---- any even PPD: convolution (Bluestein) transforms on the power-of-two engine (zd_kernels_any.hip) ----
+@pytest.mark.parametrize("n", [10, 50, 100, 125, 250, 1000, 1001, 2500, 5000, 8190])
+@pytest.mark.parametrize("kind", [0, 1])
+def test_fft_lines_any_length(zd, n, kind):
+    """arbitrary lengths (even, odd, prime factors 5, 7, 11, 13 ...) against numpy; ragged tiles (7 lines)"""
+    rng = np.random.default_rng(n + kind)
+    lines = 7
+    x = rng.standard_normal((lines, n)) + 1j * rng.standard_normal((lines, n))
+    got = zd.test_fft(x, kind)
+    ref = np.fft.ifft(x, axis=1) * n
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    assert err < 2e-14, err
+
+
+@pytest.mark.parametrize("n,kw", [
+    (50, dict()),                                               # 2 * 5^2: z lines of 50 (generator walks 2 rows)
+    (100, dict(stream_factor=2, fmt="RVZel")),
+    (70, dict(qdensity=1)),                                     # 2 * 5 * 7, density plane too
+    (110, dict(qdensity=2)),                                    # 2 * 5 * 11, density only
+    (60, dict(plt=True, fmt="RVdoubleZel")),                    # PLT + rescale: four arrays
+    (130, dict(k_cutoff=2.0, stream_factor=1)),                 # 2 * 5 * 13
+    (96, dict(qdensity=1, stream_factor=4)),                    # a 2^a 3^b size whose option (density) the composite kernels lack
+    (100, dict(corner_modes=1, k_cutoff=2.0)),                  # Nyquist-plane modes alive: the reference arrays are the only exact store
+    (100, dict(version=1, numblock=4)),                         # legacy streams
+    (100, dict(stream_factor=4, fmt="Zeldovich")),              # z lines of 25: an odd length (generator walks one row)
+    (126, dict(stream_factor=2)),                               # 2 * 3^2 * 7: z lines of 63
+])
+def test_any_even_ppd_vs_oracle(zd, oracle, ps, opk, n, kw):
+    """PPD with prime factors other than 2 and 3 (the reference plans any length with FFTW, src/zeldovich.cpp:61-66; its only
+    conditions are an even ppd divisible by NumBlock): reference arrays transformed as convolutions on the power-of-two
+    engine, every record against the oracle (whose non-power-of-two path is a plain DFT)"""
+    kw = dict(kw)
+    fmt = kw.pop("fmt", "RVdoubleZel")
+    eig = None
+    if kw.pop("plt", False):
+        eig = oracle.synthetic_eigenmodes(24)
+        kw.update(qPLT=1, qPLTrescale=1, PLT_target_z=5.0, f_cluster=0.97)
+    got, _ = _compare(zd, oracle, ps, opk, n, fmt=fmt, eig=eig, **kw)
+    assert sorted(got["planes_seen"]) == list(range(n))

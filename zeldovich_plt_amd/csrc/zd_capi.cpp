@@ -59,6 +59,64 @@ std::vector<cplx> make_twiddles(int n) {
     return tw;
 }
 
+// Bluestein tables of a length-n transform on the engine of size M = 2^m >= 2n - 1 (zd_kernels_any.hip): c_m = exp(i pi m^2/n)
+// with m^2 reduced mod 2n in integers, and the forward DFT_M of b_m = conj(c_m), |m| < n, wrapped (long double radix-2)
+int any_make_tab(int n, zd::AnyTab *tab, cplx **d_bufs) {
+    const int M = zd::any_engine_size(n);
+    const long double PI = 3.14159265358979323846264338327950288L;
+    std::vector<cplx> chirp(n), tw = make_twiddles(M);
+    std::vector<long double> br(M, 0.0L), bi(M, 0.0L);
+    for (long long m = 0; m < n; m++) {
+        const long double a = PI * (long double) ((m * m) % (2LL * n)) / (long double) n;
+        const long double c = cosl(a), sn = sinl(a);
+        chirp[m] = cplx{(double) c, (double) sn};
+        br[m] = c;
+        bi[m] = -sn;
+        if (m) {
+            br[M - m] = c;
+            bi[M - m] = -sn;
+        }
+    }
+    // forward DFT (sign -1), iterative radix-2
+    for (int i = 1, j = 0; i < M; i++) {
+        int bit = M >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) {
+            std::swap(br[i], br[j]);
+            std::swap(bi[i], bi[j]);
+        }
+    }
+    for (int len = 2; len <= M; len <<= 1) {
+        const long double ang = -2.0L * PI / (long double) len;
+        for (int i = 0; i < M; i += len)
+            for (int k = 0; k < len / 2; k++) {
+                const long double wr = cosl(ang * k), wi = sinl(ang * k);
+                const long double ur = br[i + k], ui = bi[i + k];
+                const long double vr = br[i + k + len / 2] * wr - bi[i + k + len / 2] * wi;
+                const long double vi = br[i + k + len / 2] * wi + bi[i + k + len / 2] * wr;
+                br[i + k] = ur + vr;
+                bi[i + k] = ui + vi;
+                br[i + k + len / 2] = ur - vr;
+                bi[i + k + len / 2] = ui - vi;
+            }
+    }
+    std::vector<cplx> fb(M);
+    for (int i = 0; i < M; i++) fb[i] = cplx{(double) br[i], (double) bi[i]};
+    const std::vector<cplx> *src[3] = {&tw, &chirp, &fb};
+    for (int i = 0; i < 3; i++) {
+        if (hipMalloc((void **) &d_bufs[i], sizeof(cplx) * src[i]->size()) != hipSuccess) return 1;
+        if (hipMemcpy(d_bufs[i], src[i]->data(), sizeof(cplx) * src[i]->size(), hipMemcpyHostToDevice) != hipSuccess) return 1;
+    }
+    tab->n     = n;
+    tab->M     = M;
+    tab->invM  = 1.0 / (double) M;
+    tab->twM   = d_bufs[0];
+    tab->chirp = d_bufs[1];
+    tab->fb    = d_bufs[2];
+    return 0;
+}
+
 // LDS image of k_genf; offsets must match GenfTab (zd_kernels.hip): directions {cos, sin}(2 pi j/512) at 0,
 // ln bins {c_j, -ln c_j} at 1024, 2^(j/64) at 1392, spline segment records at 1456, uint16 segment LUT after them
 std::vector<double> build_genf_table(const zd_pk *pk, int nseg, double *lut_x0, double *lut_inv_dx) {
@@ -296,7 +354,16 @@ int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes
     int R0 = 1;
     if (!p->qPLT && pack_mode(p, 2) != zd::PACK_NONE && N / 2 >= 32 && (N / 2) % nranks == 0) R0 = 2;
     const bool np2 = !is_pow2(N);
-    if (np2 && (!zd::pack_is_fields(pack_mode(p, 2)) || !zd::np2_supported_ppd((int) N) || (N / 2) % (nranks * zd::FIELD_RB))) return -1;
+    // any other even PPD (or a 2^a 3^b one whose options the composite kernels lack): reference arrays on one rank, see
+    // plan_create_ex; R a power of two dividing N
+    auto any_factor = [&]() -> int {
+        if (N % 2 || N < 8 || N > 8192 || nranks != 1 || p->f_NL != 0.) return -1;
+        const int64_t narray = p->qdensity == 2 ? 1 : (p->qPLT ? 4 : 2);
+        for (int R = 1; N % R == 0 && N / R >= 3; R *= 2)
+            if ((N / R) * narray * N * (N + store_row_pad(N)) * 16 <= budget_bytes) return R;
+        return -1;
+    };
+    if (np2 && (!zd::pack_is_fields(pack_mode(p, 2)) || !zd::np2_supported_ppd((int) N) || (N / 2) % (nranks * zd::FIELD_RB))) return any_factor();
     for (int R = R0; N / R >= 32 && N % R == 0; R *= 2) {
         if ((N / R) % nranks) break;
         if (N / R > 4096) continue;  // z-FFT kernels exist up to length 4096
@@ -311,7 +378,7 @@ int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes
             store += (int64_t) field_ring_planes(N, N / R / nranks) * 3 * N * (N + store_row_pad(N)) * 16;
         if (store <= budget_bytes) return R;
     }
-    return -1;
+    return np2 ? any_factor() : -1;
 }
 
 // phi_mode 1: first f_NL pass (one array holding phi = D/M); phik != NULL: second pass (D = phik * M)
@@ -376,10 +443,29 @@ int zd_plan_create(const zd_params *p, const zd_pk *pk, const double *eig, int64
 static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig, int64_t eig_ppd, int rank, int nranks,
                           int phi_mode, const cplx *phik, zd_plan **out) {
     const int64_t N = p->ppd;
-    const bool np2 = !is_pow2(N);  // PPD = 2^a 3^b: the composite-transform kernels (zd_kernels_np2.hip), field store only
-    if (np2 ? !zd::np2_supported_ppd((int) N) : (N < 32 || N > 16384)) {
-        fprintf(stderr, "zeldovich_hip: PPD = %lld unsupported (a power of two in [32, 16384], or 2^a 3^b with a >= 5, b <= 3 up to 6912)\n",
-                (long long) N);
+    // Three transform families: powers of two (zd_kernels.hip), 2^a 3^b on the field stores (zd_kernels_np2.hip), and ANY
+    // other even PPD — or a 2^a 3^b one with options the composite kernels lack — as convolutions on the power-of-two engine
+    // (zd_kernels_any.hip: reference arrays, one rank, no f_NL)
+    const bool pow2 = is_pow2(N);
+    bool any_path = false;
+    int np2_R = 2;
+    if (!pow2) {
+        int Rg = p->stream_factor > 0 ? p->stream_factor : 2;
+        if (p->stream_factor <= 0)  // no factor given: the first one whose z lines the composite kernels have
+            for (int r = 2; N % r == 0 && N / r >= 48; r *= 2)
+                if (zd::np2_supported_zlen((int) (N / r))) {
+                    Rg = r;
+                    break;
+                }
+        np2_R = Rg;
+        const bool comp_ok = zd::np2_supported_ppd((int) N) && phi_mode == 0 && phik == nullptr && is_pow2(Rg) && N % Rg == 0
+                             && zd::np2_supported_zlen((int) (N / Rg)) && zd::pack_is_fields(pack_mode(p, Rg))
+                             && (N / 2) % (nranks * zd::FIELD_RB) == 0;
+        any_path = !comp_ok;
+    }
+    const bool np2 = !pow2 && !any_path;  // PPD = 2^a 3^b: the composite-transform kernels, field stores only
+    if (pow2 && (N < 32 || N > 16384)) {
+        fprintf(stderr, "zeldovich_hip: PPD = %lld unsupported (powers of two: 32 ... 16384)\n", (long long) N);
         return 1;
     }
     if (p->qPLT && (eig == NULL || eig_ppd <= 0)) {
@@ -387,14 +473,16 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         return 1;
     }
     int R = p->stream_factor > 0 ? p->stream_factor : 1;
-    if (np2 && p->stream_factor <= 0) R = 2;
-    if (!is_pow2(R) || N % R || N / R < 32 || N / R > 4096 || (np2 && !zd::np2_supported_zlen((int) (N / R)))) {
+    if (np2 && p->stream_factor <= 0) R = np2_R;
+    if (any_path) {
+        if (N % 2 || N < 8 || N > 8192 || nranks != 1 || phi_mode != 0 || phik != nullptr || !is_pow2(R) || N % R || N / R < 3) {
+            fprintf(stderr, "zeldovich_hip: PPD = %lld (neither 2^a nor a supported 2^a 3^b configuration) runs as convolutions on the "
+                            "power-of-two engine: even PPD in [8, 8192], one rank, no ZD_f_NL, ZD_StreamFactor a power of two dividing PPD "
+                            "(got %d)\n", (long long) N, R);
+            return 1;
+        }
+    } else if (!is_pow2(R) || N % R || N / R < 32 || N / R > 4096 || (np2 && !zd::np2_supported_zlen((int) (N / R)))) {
         fprintf(stderr, "zeldovich_hip: stream factor %d invalid for PPD %lld\n", R, (long long) N);
-        return 1;
-    }
-    if (np2 && (phi_mode != 0 || phik != nullptr || !zd::pack_is_fields(pack_mode(p, R)) || (N / 2) % (nranks * zd::FIELD_RB))) {
-        fprintf(stderr, "zeldovich_hip: PPD = %lld (not a power of two) runs on the field stores only: ZD_StreamFactor >= 2, no "
-                        "ZD_qdensity / ZD_f_NL / ZD_qoneslab, store_mode auto, PPD/2 a multiple of 8 x ranks\n", (long long) N);
         return 1;
     }
     if (nranks < 1 || !is_pow2(nranks) || rank < 0 || rank >= nranks || (N / 2) % nranks || (N / R) % nranks) {
@@ -419,7 +507,8 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
     pl->N       = (int) N;
     pl->half    = (int) (N / 2);
     pl->narray  = (phi_mode == 1 || p->qdensity == 2) ? 1 : (p->qPLT ? 4 : 2);  // zeldovich.cpp:871-876
-    if (phi_mode == 0 && phik == nullptr && pl->narray >= 2) pl->pack = pack_mode(p, R);
+    if (phi_mode == 0 && phik == nullptr && pl->narray >= 2 && !any_path) pl->pack = pack_mode(p, R);
+    pl->any = any_path;
     if (zd::pack_is_fields(pl->pack) && ((pl->half / nranks) % zd::FIELD_RB || N / R > 2048))  // row blocks of 8, z FFT <= 2048
         pl->pack = N > 4096 ? zd::PACK_NONE : (pl->pack == zd::PACK_PLTFIELD ? zd::PACK_PLT3 : zd::PACK_ZAPAIR);
     if (N > 8192 && pl->pack != zd::PACK_ZAFIELD) {  // a 16384-point line fills a workgroup: only the field store's kernels exist
@@ -685,6 +774,7 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
     S.prune     = tune_env("ZD_PRUNE") ? atoi(tune_env("ZD_PRUNE")) : 7;  // bit 0 k_gen, 1 k_zfft, 2 k_yfft
     S.nt = tune_env("ZD_NT") ? atoi(tune_env("ZD_NT")) : 0;
     if (phik) S.prune = 0;  // f_NL second pass: every mode carries power (the zero rule is bypassed)
+    if (any_path) S.prune = 0;  // the convolution kernels transform every column: the generator must write every one
     S.kmax      = g.kmax;
     S.fund2     = g.fundamental2;
     S.k2_cutoff = p->corner_modes ? 0.0 : g.k2_cutoff;  // CornerModes: only the |k_i| == kmax rule prunes
@@ -783,7 +873,7 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         }
         while (pl->Hq % rows) rows--;
         pl->slab_rows = rows;
-        pl->overlap   = p->serial_z == 0 && !v1;  // version 1: the streams are sequential in ky
+        pl->overlap   = p->serial_z == 0 && !v1 && !any_path;  // version 1: the streams are sequential in ky
         if (v1) {
             pl->v1_block = (int) (N / p->numblock);
             PLCHECK(hipMalloc((void **) &pl->d_v1streams, sizeof(zd::V1Stream) * (size_t) pl->v1_block));
@@ -836,6 +926,16 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
             }
         }
     }
+    if (any_path) {  // Bluestein tables for the z lines (length L) and the y / x lines (length N); simple [plane][array][y][x] store
+        if (any_make_tab(pl->L, &pl->tabL, pl->d_any) || any_make_tab(pl->N, &pl->tabN, pl->d_any + 3)) {
+            zd_plan_destroy(pl);
+            return 1;
+        }
+        pl->AL.N         = pl->N;
+        pl->AL.pitch     = pl->N + store_row_pad(pl->N);
+        pl->AL.narray    = pl->narray;
+        pl->store_bytes_ = (int64_t) pl->L * pl->narray * pl->N * pl->AL.pitch * 16;
+    }
 #undef PLCHECK
     *out = pl;
     return 0;
@@ -863,6 +963,7 @@ void zd_plan_destroy(zd_plan *pl) {
     hipFree(pl->d_v1dev);
     hipFree(pl->d_v1err);
     hipFree(pl->d_phik_owned);
+    for (cplx *b : pl->d_any) hipFree(b);
     for (cplx *y : pl->d_Y) hipFree(y);
     if (pl->s_gen) hipStreamDestroy(pl->s_gen);
     if (pl->s_fft) hipStreamDestroy(pl->s_fft);
@@ -898,9 +999,34 @@ static int launch_zstage_fft(zd_plan *pl, int ky0, int kyloc0, int nky, const vo
     return zd::launch_zfft(pl->L, pl->jobs, pl->S, ky0, kyloc0, nky, pl->Zq, Y, pl->d_twL, d_send, st);
 }
 
+// Z stage of the any-PPD path (zd_kernels_any.hip): general generator -> Y, convolution transform of Y along k2 in place,
+// scatter into the [plane][array][y][x] store with the Hermitian twin rules
+static int any_stage_z(zd_plan *pl, int residue, void *d_send, hipStream_t st) {
+    const int zspan = span_begin(pl, ZD_K_ZSTAGE, st);
+    if (pl->v1_block && zd::launch_v1_seed((unsigned long long) pl->p.seed, pl->v1_block, pl->d_v1streams, st)) return 1;
+    for (int r0 = 0; r0 < pl->Hq; r0 += pl->slab_rows) {
+        const int nky = std::min(pl->slab_rows, pl->Hq - r0);
+        tick(pl, ZD_K_GEN, st, true);
+        if (pl->v1_block)  // ZD_Version = 1: rows that share a stream are drawn by successive launches (zd_plan_stage_z)
+            for (int i0 = 0; i0 < nky; i0 += pl->v1_block)
+                if (zd::launch_v1_draw(pl->g, pl->v1_block, r0 + i0, 1, std::min(pl->v1_block, nky - i0), pl->d_v1streams,
+                                       pl->d_v1dev + (size_t) i0 * pl->N * pl->N, pl->d_v1err, st))
+                    return 1;
+        if (zd::launch_gen(pl->g, pl->J, pl->jobs, pl->S, r0, nky, pl->L, residue, residue, pl->d_twN, pl->d_Y[0], nullptr, 0, st)) return 1;
+        tick(pl, ZD_K_GEN, st, false);
+        tick(pl, ZD_K_ZFFT, st, true);
+        if (zd::launch_any_cols(pl->tabL, pl->d_Y[0], (long long) pl->L * pl->N, pl->N, pl->N, pl->jobs.n * nky, -1, st)) return 1;
+        if (zd::launch_any_scatter(pl->jobs, pl->AL, r0, nky, pl->L, pl->d_Y[0], d_send, st)) return 1;
+        tick(pl, ZD_K_ZFFT, st, false);
+    }
+    span_end(pl, zspan, st);
+    return 0;
+}
+
 int zd_plan_stage_z(zd_plan *pl, int residue, void *d_send, void *hip_stream) {
     hipStream_t st = (hipStream_t) hip_stream;
     if (residue < 0 || residue >= pl->npass) return 1;
+    if (pl->any) return any_stage_z(pl, residue, d_send, st);
     const int residue2 = pl->pstep == 2 ? residue + pl->R / 2 : residue;
     pl->g.accum_var = (pl->pack != zd::PACK_NONE && pl->var_pending) ? 1 : 0;  // once per run: every pass sees every mode
     pl->var_pending = false;
@@ -1011,6 +1137,13 @@ static zd::FieldLayout fields_for_chunks(const zd_plan *pl, int chunk_planes) {
 int zd_plan_stage_y_group(zd_plan *pl, void *d_recv, int chunk_planes, int nplanes, void *hip_stream) {
     hipStream_t st = (hipStream_t) hip_stream;
     if (zd::pack_is_fields(pl->pack)) return 0;  // field stores: the y transform runs plane group by plane group in stage_x
+    if (pl->any) {  // every (plane, array) image: columns along y, the Nyquist row counted as zero (zeldovich.cpp:644-650)
+        tick(pl, ZD_K_YFFT, st, true);
+        if (zd::launch_any_cols(pl->tabN, d_recv, (long long) pl->N * pl->AL.pitch, pl->AL.pitch, pl->N, nplanes * pl->narray, pl->N / 2, st))
+            return 1;
+        tick(pl, ZD_K_YFFT, st, false);
+        return 0;
+    }
     tick(pl, ZD_K_YFFT, st, true);
     if (zd::launch_yfft(layout_for_chunks(pl, chunk_planes), nplanes, pl->d_twN, d_recv, st)) return 1;
     tick(pl, ZD_K_YFFT, st, false);
@@ -1031,6 +1164,15 @@ int zd_plan_stage_x_group(zd_plan *pl, int residue, const void *d_recv, int chun
         return 1;
     }
     if (d_density && pl->pack != zd::PACK_NONE) return 1;  // packed stores carry no density field
+    if (pl->any) {  // x lines of the planes in place (each plane once), then the particle epilogue
+        const int z_first = (int) zd_plan_plane_z(pl, residue, gplane0);
+        cplx *first = (cplx *) const_cast<void *>(d_recv) + (long long) plane0 * pl->narray * pl->N * pl->AL.pitch;
+        tick(pl, ZD_K_XFFT, st, true);
+        if (zd::launch_any_lines(pl->tabN, first, pl->AL.pitch, (long long) nplanes * pl->narray * pl->N, st)) return 1;
+        if (zd::launch_any_emit(pl->AL, pl->ec, d_recv, (int) plane0, (int) nplanes, z_first, pl->R, d_records, d_density, pl->d_red, st)) return 1;
+        tick(pl, ZD_K_XFFT, st, false);
+        return 0;
+    }
     if (zd::pack_is_fields(pl->pack)) {
         // y stage (potentials -> the three displacement arrays of a group of store planes, into the ring) + x stage
         const zd::FieldLayout F = fields_for_chunks(pl, chunk_planes);
@@ -1457,8 +1599,33 @@ static int test_fft_composite(int32_t n, int64_t lines, int32_t axis_kind, const
     return rc;
 }
 
+// any length through the convolution kernels (zd_kernels_any.hip); axis_kind as in zd_test_fft
+static int test_fft_any(int32_t n, int64_t lines, int32_t axis_kind, const double *in, double *out) {
+    zd::AnyTab tab = {};
+    cplx *bufs[3] = {nullptr, nullptr, nullptr}, *d = nullptr;
+    const size_t nb = sizeof(cplx) * (size_t) n * lines;
+    int rc = 1;
+    do {
+        if (n < 2 || n > 8192) break;
+        if (any_make_tab(n, &tab, bufs)) break;
+        if (hipMalloc((void **) &d, nb) != hipSuccess) break;
+        if (hipMemcpy(d, in, nb, hipMemcpyHostToDevice) != hipSuccess) break;
+        if (axis_kind == 1 ? zd::launch_any_cols(tab, d, 0, lines, (int) lines, 1, -1, 0) : zd::launch_any_lines(tab, d, n, lines, 0)) break;
+        if (hipDeviceSynchronize() != hipSuccess) break;
+        if (hipMemcpy(out, d, nb, hipMemcpyDeviceToHost) != hipSuccess) break;
+        rc = 0;
+    } while (0);
+    for (cplx *b : bufs) hipFree(b);
+    hipFree(d);
+    return rc;
+}
+
 int zd_test_fft(int32_t n, int64_t lines, int32_t axis_kind, const double *in, double *out) {
-    if (!is_pow2(n)) return test_fft_composite(n, lines, axis_kind, in, out);
+    if (!is_pow2(n)) {
+        int P = 0, Q = 0;
+        if (zd::np2_split(n, &P, &Q) && zd::test_fftq_tile_width(n) > 0 && P >= 8) return test_fft_composite(n, lines, axis_kind, in, out);
+        return test_fft_any(n, lines, axis_kind, in, out);
+    }
     const int W = zd::test_fft_tile_width(n);
     if (W == 0 || lines % W) {
         fprintf(stderr, "zd_test_fft: n=%d needs lines %% %d == 0\n", n, W);

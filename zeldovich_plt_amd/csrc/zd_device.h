@@ -238,6 +238,18 @@ struct EpiConst {
     double vnorm;  // (sqrt(1+24 f_cluster)-1)/4 without PLT, 1 with   output.cpp:78-82
 };
 
+// any even PPD (zd_kernels_any.hip): a length-n transform as a convolution of length M = 2^m >= 2n - 1 (Bluestein)
+struct AnyTab {
+    int n, M;
+    double invM;
+    const zdfft::cplx *twM;    // exp(2 pi i k / M), k < M
+    const zdfft::cplx *chirp;  // c_m = exp(i pi m^2 / n), m < n
+    const zdfft::cplx *fb;     // forward DFT_M of b_m = conj(c_m), |m| < n, wrapped
+};
+struct AnyLayout {  // store [plane][array][row y][x]
+    int N, pitch, narray;
+};
+
 // device-side reductions (output.cpp:28-30,190-197): NSLOT replicated accumulators
 constexpr int NSLOT = 64;
 struct Reduce {

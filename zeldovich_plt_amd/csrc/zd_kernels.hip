@@ -1999,8 +1999,9 @@ namespace zd {
 int zfft_tile_width(int L);
 int zfft_fields_tile_columns(int L);
 
-// z rows walked by one generator thread: 16, or 4 for the short composite z lines (L = 108 = 4 * 27: PPD = 6912 on ONE GPU)
-static int gen_zr(int L) { return L % GEN_ZR == 0 ? GEN_ZR : (L % 4 == 0 ? 4 : 0); }
+// z rows walked by one generator thread: 16; 4 for the short composite z lines (L = 108 = 4 * 27: PPD = 6912 on ONE GPU);
+// 4, 2 or 1 for the arbitrary lengths of the any-PPD path (zd_kernels_any.hip)
+static int gen_zr(int L) { return L % GEN_ZR == 0 ? GEN_ZR : (L % 4 == 0 ? 4 : (L % 2 == 0 ? 2 : 1)); }
 
 template <int ZR, int NJ, bool PLT, bool PLAW>
 static int launch_gen_z(const GenConst &g, const GenJumps &J, const JobList &jobs, const StoreLayout &S, int ky0, int nky,
@@ -2017,10 +2018,18 @@ template <int NJ, bool PLT, bool PLAW>
 static int launch_gen_t(const GenConst &g, const GenJumps &J, const JobList &jobs, const StoreLayout &S, int ky0, int nky,
                         int nrows, int L, int residue, int residue2, const void *twN, void *Y, hipStream_t st) {
     if (gen_zr(L) == GEN_ZR) return launch_gen_z<GEN_ZR, NJ, PLT, PLAW>(g, J, jobs, S, ky0, nky, nrows, L, residue, residue2, twN, Y, st);
-    // the short walk exists for the field stores only (their ky = 0 row: 4 ZA jobs, 6 PLT jobs)
+    // the short walks exist for the field stores (their ky = 0 row: 4 ZA jobs, 6 PLT jobs) and for the reference arrays of the
+    // any-PPD path (1, 4 or 7 jobs)
     if constexpr ((NJ == 4 && !PLT) || (NJ == 6 && PLT)) {
         if (gen_zr(L) == 4 && pack_is_fields(jobs.pack))
             return launch_gen_z<4, NJ, PLT, PLAW>(g, J, jobs, S, ky0, nky, nrows, L, residue, residue2, twN, Y, st);
+    }
+    if constexpr (NJ == 1 || (NJ == 4 && !PLT) || (NJ == 7 && PLT)) {
+        if (jobs.pack == PACK_NONE) {
+            if (gen_zr(L) == 4) return launch_gen_z<4, NJ, PLT, PLAW>(g, J, jobs, S, ky0, nky, nrows, L, residue, residue2, twN, Y, st);
+            if (gen_zr(L) == 2) return launch_gen_z<2, NJ, PLT, PLAW>(g, J, jobs, S, ky0, nky, nrows, L, residue, residue2, twN, Y, st);
+            if (gen_zr(L) == 1) return launch_gen_z<1, NJ, PLT, PLAW>(g, J, jobs, S, ky0, nky, nrows, L, residue, residue2, twN, Y, st);
+        }
     }
     return 2;
 }

@@ -56,6 +56,14 @@ int launch_xfft_np2(int N, const EpiConst &ec, const void *tw, const void *ring,
                     void *records, Reduce *red, hipStream_t st);
 int launch_test_fftq(int n, int kind, const void *twP, const void *twN, const void *twQ, const void *in, void *out, long long lines,
                      hipStream_t st);
+// ---- any even PPD (zd_kernels_any.hip) ----
+int any_engine_size(int n);
+int launch_any_cols(const AnyTab &tb, void *data, long long batch_stride, long long point_stride, int ncols, int nbatch, int zero_point,
+                    hipStream_t st);
+int launch_any_lines(const AnyTab &tb, void *data, long long pitch, long long nlines, hipStream_t st);
+int launch_any_scatter(const JobList &jobs, const AnyLayout &A, int ky0, int nky, int L, const void *Y, void *store, hipStream_t st);
+int launch_any_emit(const AnyLayout &A, const EpiConst &ec, const void *store, int plane0, int nplanes, int z_first, int z_step, void *records,
+                    float *density, Reduce *red, hipStream_t st);
 // ---- ZD_Version = 1 streams (zd_kernels_v1.hip) ----
 int launch_v1_seed(unsigned long long seed, int block, V1Stream *streams, hipStream_t st);
 int launch_v1_draw(const GenConst &g, int block, int ky0, int ky_stride, int nrows, V1Stream *streams, void *dev, int *err,

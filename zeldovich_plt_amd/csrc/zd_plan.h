@@ -66,6 +66,11 @@ struct zd_plan {
     double2 *d_v1dev = nullptr;     // [slab row][z][x]
     int *d_v1err = nullptr;
     zdfft::cplx *d_phik_owned = nullptr;  // ZD_f_NL through zd_plan_create: PhiK of the phi round (zd_generate keeps its own)
+    // any even PPD (zd_kernels_any.hip): Bluestein tables for the lengths L (z lines) and N (y, x lines)
+    bool any = false;
+    zd::AnyTab tabL = {}, tabN = {};
+    zd::AnyLayout AL = {};
+    zdfft::cplx *d_any[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // timing
     std::vector<EventPair> events;
     std::vector<hipEvent_t> pool;
