@@ -164,7 +164,9 @@ int64_t zd_plan_plane_z(const zd_plan *plan, int residue, int64_t local_plane); 
 int zd_plan_stage_z(zd_plan *plan, int residue, void *d_send, void *hip_stream);
 
 /* XY stage: in-place y FFT on `d_recv`, then x FFT + particle epilogue for local planes
- * [plane0, plane0+nplanes).  d_records: nplanes*ppd*ppd records; d_density: float32 or NULL. */
+ * [plane0, plane0+nplanes).  d_records: nplanes*ppd*ppd records; d_density: float32 or NULL.
+ * Call zd_plan_stage_x ONCE per plane and pass: for the PPDs that run as convolutions (neither 2^a nor 2^a 3^b) the x transform
+ * of a plane is done in place in `d_recv`. */
 int zd_plan_stage_y(zd_plan *plan, void *d_recv, void *hip_stream);
 int zd_plan_stage_x(zd_plan *plan, int residue, const void *d_recv, int64_t plane0, int64_t nplanes,
                     void *d_records, float *d_density, void *hip_stream);
