@@ -480,6 +480,9 @@ def test_fnl_with_plt(zd, oracle, ps, wmap_path):
     (2, 192, dict(stream_factor=2)),                                   # PPD = 2^6 3: 48 planes per rank (composite transforms)
     (4, 384, dict(stream_factor=4, k_cutoff=2.0, exchange_planes=5)),  # 24 planes per rank in groups of 5
     (2, 288, dict(stream_factor=2, exchange_planes=7)),                # 2^5 3^2
+    (2, 128, dict(qdensity=1, fmt="RVZel", exchange_planes=9)),        # density plane beside the records (reference arrays)
+    (4, 128, dict(qdensity=2, stream_factor=2)),                       # density only
+    (2, 64, dict(qoneslab=17)),                                        # one slab: finished by the single-GPU path
 ])
 def test_native_multi_gpu_driver(zd, oracle, ps, opk, ngpu, n, kw):
     """ZD_NumGPU > 1 through zd_generate: one host thread per rank, exchange in plane groups + pipelined XY stages inside
@@ -492,6 +495,15 @@ def test_native_multi_gpu_driver(zd, oracle, ps, opk, ngpu, n, kw):
     if kw.pop("plt", False):
         eig = oracle.synthetic_eigenmodes(32)
         kw.update(qPLT=1, qPLTrescale=1, PLT_target_z=5.0, f_cluster=0.97)
+    if "qoneslab" in kw:
+        p = zd.make_params(n, ngpu=ngpu, **kw)
+        got = zd.generate(p, ps)
+        ref = oracle.run(oracle.make_params(n, numblock=2, qoneslab=kw["qoneslab"]), opk)
+        z = kw["qoneslab"]
+        assert got["planes_seen"] == [z]
+        assert _rel(got["records"]["d"][z], ref["records"]["d"][z]) < TOL
+        assert abs(got["density_variance"] - ref["density_variance"]) <= TOL * ref["density_variance"]
+        return
     got, _ = _compare(zd, oracle, ps, opk, n, fmt=fmt, eig=eig, ngpu=ngpu, **kw)
     assert sorted(got["planes_seen"]) == list(range(n))
 

@@ -1254,7 +1254,9 @@ int zd_plan_stats(zd_plan *pl, zd_stats *out) {
 // ------------------------------------------------------------------------------------------------
 int zd_generate(const zd_params *p_in, const zd_pk *pk, const double *eig, int64_t eig_ppd, zd_slab_cb cb,
                 void *user, zd_stats *out) {
-    if (p_in->ngpu > 1) {  // ZD_NumGPU: one host thread per GPU, exchange inside the library (zd_multi.cpp)
+    // ZD_NumGPU: one host thread per GPU, exchange inside the library (zd_multi.cpp).  (ZD_qoneslab finishes ONE plane of one
+    // pass and reports the reductions of that slab alone, output.cpp:197: that is this single-GPU path's job.)
+    if (p_in->ngpu > 1 && p_in->qoneslab < 0) {
         int ndev = 0;
         HIPCHECK(hipGetDeviceCount(&ndev));
         // RCCL between distinct GPUs; when the ranks have to share devices (fewer GPUs than ranks: test boxes) they

@@ -228,8 +228,17 @@ int64_t zd_plan_ring_bytes(const zd_plan *pl, int32_t *group_planes) {
 //              still queued on `stream` — the consumer orders itself after it (or syncs); cb may be NULL (benchmark sink)
 typedef int (*zd_group_cb)(void *user, int64_t first_local_plane, int64_t nplanes, const void *d_records, void *hip_stream);
 
+// d_density: room for rec_planes planes of float32 (stores with a density field only) or NULL
+static int run_pass_impl(zd_plan *pl, zd_comm *c, int pass, void *d_store, void *d_records, float *d_density, int64_t rec_planes,
+                         zd_group_cb cb, void *user, void *hip_stream);
+
 int zd_plan_run_pass(zd_plan *pl, zd_comm *c, int pass, void *d_store, void *d_records, int64_t rec_planes, zd_group_cb cb,
                      void *user, void *hip_stream) {
+    return run_pass_impl(pl, c, pass, d_store, d_records, nullptr, rec_planes, cb, user, hip_stream);
+}
+
+static int run_pass_impl(zd_plan *pl, zd_comm *c, int pass, void *d_store, void *d_records, float *d_density, int64_t rec_planes,
+                         zd_group_cb cb, void *user, void *hip_stream) {
     hipStream_t st = (hipStream_t) hip_stream;
     const int ps = pl->pstep;
     const int64_t Pp = zd_plan_local_planes(pl);
@@ -242,7 +251,7 @@ int zd_plan_run_pass(zd_plan *pl, zd_comm *c, int pass, void *d_store, void *d_r
         if (zd_plan_stage_y(pl, d_store, st)) return 1;
         for (int64_t q0 = 0; q0 < Pp; q0 += rec_planes) {
             const int64_t n = std::min<int64_t>(rec_planes, Pp - q0);
-            if (zd_plan_stage_x_group(pl, pass, d_store, pl->Zq, q0, q0, n, d_records, nullptr, st)) return 1;
+            if (zd_plan_stage_x_group(pl, pass, d_store, pl->Zq, q0, q0, n, d_records, d_density, st)) return 1;
             if (cb && cb(user, q0, n, d_records, st)) return 1;
         }
         return 0;
@@ -309,7 +318,7 @@ int zd_plan_run_pass(zd_plan *pl, zd_comm *c, int pass, void *d_store, void *d_r
         // XY on the slot: chunks are gp planes long there
         for (int64_t q0 = 0; q0 < np * ps; q0 += rec_planes) {
             const int64_t n = std::min<int64_t>(rec_planes, np * ps - q0);
-            if (zd_plan_stage_x_group(pl, pass, src, gp, q0, p0 * ps + q0, n, d_records, nullptr, st)) return 1;
+            if (zd_plan_stage_x_group(pl, pass, src, gp, q0, p0 * ps + q0, n, d_records, d_density, st)) return 1;
             if (cb && cb(user, p0 * ps + q0, n, d_records, st)) return 1;
         }
         MHIP(hipEventRecord(c->ev_x[slot], st));
@@ -353,6 +362,9 @@ struct GroupSink {
     Delivery *dl;
     char *h_rec;
     size_t plane_rec_b;
+    const float *d_dens;  // device density planes of the group (ZD_qdensity) or NULL
+    float *h_dens;
+    int64_t only_z;       // ZD_qoneslab: deliver just this z (-1: every plane)
     int fail = 0;
 };
 
@@ -360,12 +372,17 @@ int sink_cb(void *user, int64_t first_local_plane, int64_t nplanes, const void *
     GroupSink *s = (GroupSink *) user;
     if (!s->dl->cb) return 0;
     hipStream_t st = (hipStream_t) hip_stream;
-    if (hipMemcpyAsync(s->h_rec, d_records, s->plane_rec_b * (size_t) nplanes, hipMemcpyDeviceToHost, st) != hipSuccess) return 1;
+    const size_t nn = (size_t) s->pl->N * s->pl->N;
+    if (s->plane_rec_b && hipMemcpyAsync(s->h_rec, d_records, s->plane_rec_b * (size_t) nplanes, hipMemcpyDeviceToHost, st) != hipSuccess) return 1;
+    if (s->d_dens && hipMemcpyAsync(s->h_dens, s->d_dens, nn * 4 * (size_t) nplanes, hipMemcpyDeviceToHost, st) != hipSuccess) return 1;
     if (hipStreamSynchronize(st) != hipSuccess) return 1;
     std::lock_guard<std::mutex> lock(s->dl->mu);
     for (int64_t i = 0; i < nplanes; i++) {
         const int64_t z = zd_plan_plane_z(s->pl, s->pass, first_local_plane + i);
-        if (s->dl->cb(s->dl->user, z, (int64_t) s->pl->N * s->pl->N, s->h_rec + (size_t) i * s->plane_rec_b, nullptr)) return 1;
+        if (s->only_z >= 0 && z != s->only_z) continue;
+        if (s->dl->cb(s->dl->user, z, (int64_t) nn, s->plane_rec_b ? s->h_rec + (size_t) i * s->plane_rec_b : nullptr,
+                      s->d_dens ? s->h_dens + (size_t) i * nn : nullptr))
+            return 1;
     }
     return 0;
 }
@@ -384,8 +401,8 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
         fprintf(stderr, "zeldovich_hip: no GPU\n");
         return 1;
     }
-    if (p_in->qdensity != 0 || p_in->f_NL != 0. || p_in->qoneslab >= 0) {
-        fprintf(stderr, "zeldovich_hip: ZD_NumGPU > 1 supports the displacement path (no ZD_qdensity / ZD_f_NL / ZD_qoneslab)\n");
+    if (p_in->f_NL != 0.) {
+        fprintf(stderr, "zeldovich_hip: ZD_f_NL != 0 runs on one GPU (the forward z transform of the phi field needs every plane)\n");
         return 1;
     }
     if (transport == 0 && ndev < G) {
@@ -433,6 +450,7 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
             me.rc       = 1;
             zd_plan *pl = nullptr;
             void *d_store = nullptr, *d_rec = nullptr;
+            float *d_dens = nullptr, *h_dens = nullptr;
             char *h_rec = nullptr;
             zd_comm *c  = new zd_comm;
             hipStream_t st = nullptr;
@@ -447,19 +465,24 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
                 c->grp    = &grp;
                 if (comm_prepare(c)) break;
                 const int ps = pl->pstep;
-                const size_t plane_rec_b = (size_t) pl->N * pl->N * pl->ec.recsize;
+                const bool want_rec = pl->narray >= 2, want_dens = p.qdensity != 0;  // ZD_qdensity = 2: density only
+                const size_t nn = (size_t) pl->N * pl->N;
+                const size_t plane_rec_b = want_rec ? nn * pl->ec.recsize : 0;
                 const int64_t ring_b = cb ? ((int64_t) 1 << 30) : ((int64_t) 4 << 30);
-                int64_t rec_planes = std::max<int64_t>(ps, std::min<int64_t>(zd_plan_local_planes(pl), ring_b / (int64_t) plane_rec_b) / ps * ps);
+                int64_t rec_planes = std::max<int64_t>(ps, std::min<int64_t>(zd_plan_local_planes(pl),
+                                                                             ring_b / (int64_t) (plane_rec_b + (want_dens ? nn * 4 : 0))) / ps * ps);
                 if (hipMalloc(&d_store, (size_t) zd_plan_exchange_bytes(pl)) != hipSuccess) {
                     fprintf(stderr, "zeldovich_hip: rank %d cannot allocate the %.2f GB block store\n", g, zd_plan_exchange_bytes(pl) / 1e9);
                     break;
                 }
-                if (hipMalloc(&d_rec, plane_rec_b * (size_t) rec_planes) != hipSuccess) break;
-                if (cb && hipHostMalloc((void **) &h_rec, plane_rec_b * (size_t) rec_planes) != hipSuccess) break;
+                if (want_rec && hipMalloc(&d_rec, plane_rec_b * (size_t) rec_planes) != hipSuccess) break;
+                if (want_rec && cb && hipHostMalloc((void **) &h_rec, plane_rec_b * (size_t) rec_planes) != hipSuccess) break;
+                if (want_dens && hipMalloc((void **) &d_dens, nn * 4 * (size_t) rec_planes) != hipSuccess) break;
+                if (want_dens && cb && hipHostMalloc((void **) &h_dens, nn * 4 * (size_t) rec_planes) != hipSuccess) break;
                 bool fail = false;
                 for (int pass = 0; pass < pl->npass && !fail; pass++) {
-                    GroupSink sink{pl, pass, &dl, h_rec, plane_rec_b};
-                    if (zd_plan_run_pass(pl, c, pass, d_store, d_rec, rec_planes, sink_cb, &sink, st)) fail = true;
+                    GroupSink sink{pl, pass, &dl, h_rec, plane_rec_b, cb ? d_dens : nullptr, h_dens, -1};
+                    if (run_pass_impl(pl, c, pass, d_store, d_rec, d_dens, rec_planes, sink_cb, &sink, st)) fail = true;
                 }
                 if (fail) break;
                 if (zd_plan_stats(pl, &me.stats)) break;
@@ -469,7 +492,9 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
             if (st) hipStreamDestroy(st);
             hipFree(d_store);
             hipFree(d_rec);
+            hipFree(d_dens);
             if (h_rec) hipHostFree(h_rec);
+            if (h_dens) hipHostFree(h_dens);
             c->nccl = nullptr;  // destroyed below, after every thread has left RCCL
             zd_comm_destroy(c);
             if (pl) zd_plan_destroy(pl);
