@@ -286,7 +286,7 @@ def test_ppd2048_plt_store_and_stream_invariance(zd, oracle):
     kw = dict(qPLT=1, qPLTrescale=1, PLT_target_z=5.0, z_initial=49.0, icformat="RVZel")
     a = zd.generate(zd.make_params(2048, **kw), ps, eig=eig, collect=False)
     b = zd.generate(zd.make_params(2048, store_mode="reference", **kw), ps, eig=eig, collect=False)
-    c = zd.generate(zd.make_params(2048, stream_factor=8, **kw), ps, eig=eig, collect=False)
+    c = zd.generate(zd.make_params(2048, stream_factor=4, **kw), ps, eig=eig, collect=False)
     for o in (b, c):
         assert abs(a["density_variance"] - o["density_variance"]) <= 1e-11 * a["density_variance"]
         assert np.abs(a["max_disp"] - o["max_disp"]).max() <= 1e-11 * np.abs(a["max_disp"]).max()

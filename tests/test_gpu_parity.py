@@ -478,7 +478,7 @@ def test_fnl_with_plt(zd, oracle, ps, wmap_path):
     (4, 128, dict(stream_factor=2, store_mode="packed")),
     (2, 128, dict(stream_factor=2, plt=True)),
     (2, 192, dict(stream_factor=2)),                                   # PPD = 2^6 3: 48 planes per rank (composite transforms)
-    (4, 384, dict(stream_factor=4, k_cutoff=2.0, exchange_planes=5)),  # 24 planes per rank in groups of 5
+    (4, 192, dict(stream_factor=4, k_cutoff=2.0, exchange_planes=5)),  # 12 planes per rank in groups of 5
     (2, 288, dict(stream_factor=2, exchange_planes=7)),                # 2^5 3^2
     (2, 128, dict(qdensity=1, fmt="RVZel", exchange_planes=9)),        # density plane beside the records (reference arrays)
     (4, 128, dict(qdensity=2, stream_factor=2)),                       # density only
@@ -627,7 +627,7 @@ def test_fft_lines_composite_lengths(zd, n, kind):
     (192, dict(stream_factor=2, fmt="RVZel")),                  # 192 = 64 * 3
     (192, dict(stream_factor=4, k_cutoff=2.0)),
     (288, dict(stream_factor=2)),                              # 288 = 32 * 9
-    (384, dict(stream_factor=8, fmt="Zeldovich", k_cutoff=1.5)),
+    (96, dict(stream_factor=2, fmt="Zeldovich", k_cutoff=1.5)),
     (864, dict(stream_factor=2, k_cutoff=4.0, fmt="ZelSimple")),  # 864 = 32 * 27 (band-limited so that the oracle's O(n^2) DFTs stay cheap? no: full DFTs)
 ])
 def test_non_power_of_two_ppd_vs_oracle(zd, oracle, ps, opk, n, kw):
@@ -647,7 +647,7 @@ def test_non_power_of_two_ppd_vs_oracle(zd, oracle, ps, opk, n, kw):
 @pytest.mark.parametrize("n,kw", [
     (96, dict(stream_factor=2, ppd_e=32)),                       # exact-stride eigenmode lookup is impossible (32 does not divide 96): trilinear
     (192, dict(stream_factor=4, ppd_e=64, resc=0)),
-    (288, dict(stream_factor=2, ppd_e=24, fmt="RVZel")),
+    (192, dict(stream_factor=2, ppd_e=24, fmt="RVZel")),
     (192, dict(stream_factor=2, ppd_e=32, ngpu=2)),              # two ranks
     (192, dict(stream_factor=2, ppd_e=32, version=1, numblock=4)),  # legacy streams on a composite grid
 ])
