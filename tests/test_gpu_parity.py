@@ -798,6 +798,9 @@ def test_fft_lines_any_length(zd, n, kind):
     (100, dict(version=1, numblock=4)),                         # legacy streams
     (100, dict(stream_factor=4, fmt="Zeldovich")),              # z lines of 25: an odd length (generator walks one row)
     (126, dict(stream_factor=2)),                               # 2 * 3^2 * 7: z lines of 63
+    (50, dict(stream_factor=5)),                                # a stream factor that is not a power of two: z lines of 10
+    (90, dict(stream_factor=3, fmt="RVZel")),                   # 2 * 3^2 * 5, three residue passes
+    (100, dict(stream_factor=25)),                              # z lines of 4
 ])
 def test_any_even_ppd_vs_oracle(zd, oracle, ps, opk, n, kw):
     """PPD with prime factors other than 2 and 3 (the reference plans any length with FFTW, src/zeldovich.cpp:61-66; its only

@@ -49,8 +49,7 @@ def _write(tmp_path, text):
 
 
 def test_stream_factor_for_any_even_ppd(zd):
-    """PPD with other prime factors than 2 and 3 (zd_kernels_any.hip): reference arrays on one rank, R a power of two dividing
-    PPD; a 2^a 3^b size falls back to the same path when its options need the reference arrays (density)"""
+    """PPD with other prime factors than 2 and 3 (zd_kernels_any.hip): reference arrays on one rank, R any divisor of PPD; a 2^a 3^b size falls back to the same path when its options need the reference arrays (density)"""
     L = zd.load_library()
     GB = 1 << 30
 
@@ -60,8 +59,8 @@ def test_stream_factor_for_any_even_ppd(zd):
     assert R(1000, 250 * GB) == 1          # 1000 * 2 * 1000 * 1024 * 16 B = 33 GB
     assert R(2000, 250 * GB) == 1 and R(2000, 200 * GB) == 2   # 259 GB at R = 1
     assert R(4000, 250 * GB) == 8          # 32 * 125: z lines of 500
-    assert R(3000, 250 * GB) == 4 and R(3000, 150 * GB) == 8   # 8 * 375: an odd z line at R = 8
-    assert R(5000, 250 * GB) == -1         # 8 * 625: even R = 8 leaves 502 GB
+    assert R(3000, 250 * GB) == 4 and R(3000, 150 * GB) == 6   # any divisor: the z-residue fold is a plain decimation
+    assert R(5000, 250 * GB) == 20         # z lines of 250
     assert R(1001, 250 * GB) == -1         # odd PPD: the reference requires an even one too
     assert R(1000, 250 * GB, nranks=2) == -1
     assert R(1000, 250 * GB, qPLT=1) == 1 and R(1000, 250 * GB, qdensity=2) == 1

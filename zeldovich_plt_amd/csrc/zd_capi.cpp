@@ -355,12 +355,12 @@ int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes
     if (!p->qPLT && pack_mode(p, 2) != zd::PACK_NONE && N / 2 >= 32 && (N / 2) % nranks == 0) R0 = 2;
     const bool np2 = !is_pow2(N);
     // any other even PPD (or a 2^a 3^b one whose options the composite kernels lack): reference arrays on one rank, see
-    // plan_create_ex; R a power of two dividing N
+    // plan_create_ex; R any divisor of N
     auto any_factor = [&]() -> int {
         if (N % 2 || N < 8 || N > 8192 || nranks != 1 || p->f_NL != 0.) return -1;
         const int64_t narray = p->qdensity == 2 ? 1 : (p->qPLT ? 4 : 2);
-        for (int R = 1; N % R == 0 && N / R >= 3; R *= 2)
-            if ((N / R) * narray * N * (N + store_row_pad(N)) * 16 <= budget_bytes) return R;
+        for (int R = 1; N / R >= 3; R++)  // any divisor of N (the z-residue fold is a plain decimation: R need not be 2^k here)
+            if (N % R == 0 && (N / R) * narray * N * (N + store_row_pad(N)) * 16 <= budget_bytes) return R;
         return -1;
     };
     if (np2 && (!zd::pack_is_fields(pack_mode(p, 2)) || !zd::np2_supported_ppd((int) N) || (N / 2) % (nranks * zd::FIELD_RB))) return any_factor();
@@ -475,9 +475,9 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
     int R = p->stream_factor > 0 ? p->stream_factor : 1;
     if (np2 && p->stream_factor <= 0) R = np2_R;
     if (any_path) {
-        if (N % 2 || N < 8 || N > 8192 || nranks != 1 || phi_mode != 0 || phik != nullptr || !is_pow2(R) || N % R || N / R < 3) {
+        if (N % 2 || N < 8 || N > 8192 || nranks != 1 || phi_mode != 0 || phik != nullptr || R < 1 || N % R || N / R < 3) {
             fprintf(stderr, "zeldovich_hip: PPD = %lld (neither 2^a nor a supported 2^a 3^b configuration) runs as convolutions on the "
-                            "power-of-two engine: even PPD in [8, 8192], one rank, no ZD_f_NL, ZD_StreamFactor a power of two dividing PPD "
+                            "power-of-two engine: even PPD in [8, 8192], one rank, no ZD_f_NL, ZD_StreamFactor any divisor of PPD "
                             "(got %d)\n", (long long) N, R);
             return 1;
         }
