@@ -1,4 +1,4 @@
-"""CPU, world_size 2 and 4 (gloo): the one-process-per-rank driver — CYCLIC rank ownership of the half-space rows, z-plane
+"""CPU, world_size 2, 4 and 8 (gloo): the one-process-per-rank driver — CYCLIC rank ownership of the half-space rows, z-plane
 ownership, the block-store chunk layout and the exchange between the Z and XY stages, in one piece and pipelined in plane
 groups through the two-slot ring — reproduces the single-process oracle result, for R = 1 and with z-residue streaming."""
 import os
@@ -52,7 +52,7 @@ def _worker(rank, world, port, n, R, outdir, group_bytes=None):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("R,world,group_bytes", [(1, 2, None), (2, 2, None), (1, 2, 3 * 16 * 16 * 32 * 2), (1, 4, 2 * 8192)])
+@pytest.mark.parametrize("R,world,group_bytes", [(1, 2, None), (2, 2, None), (1, 2, 3 * 16 * 16 * 32 * 2), (1, 4, 2 * 8192), (1, 8, None)])
 def test_multi_rank_pipeline_matches_oracle(tmp_path, oracle, R, world, group_bytes):
     n = 16
     port = _free_port()
