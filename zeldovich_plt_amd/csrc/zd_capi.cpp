@@ -1004,7 +1004,9 @@ static int launch_zstage_fft(zd_plan *pl, int ky0, int kyloc0, int nky, const vo
 static int any_stage_z(zd_plan *pl, int residue, void *d_send, hipStream_t st) {
     const int zspan = span_begin(pl, ZD_K_ZSTAGE, st);
     if (pl->v1_block && zd::launch_v1_seed((unsigned long long) pl->p.seed, pl->v1_block, pl->d_v1streams, st)) return 1;
-    for (int r0 = 0; r0 < pl->Hq; r0 += pl->slab_rows) {
+    HIPCHECK(hipMemsetAsync(pl->d_tilectr, 0, sizeof(unsigned) * pl->n_tilectr, st));
+    int slab = 0;
+    for (int r0 = 0; r0 < pl->Hq; r0 += pl->slab_rows, slab++) {
         const int nky = std::min(pl->slab_rows, pl->Hq - r0);
         tick(pl, ZD_K_GEN, st, true);
         if (pl->v1_block)  // ZD_Version = 1: rows that share a stream are drawn by successive launches (zd_plan_stage_z)
@@ -1012,7 +1014,10 @@ static int any_stage_z(zd_plan *pl, int residue, void *d_send, hipStream_t st) {
                 if (zd::launch_v1_draw(pl->g, pl->v1_block, r0 + i0, 1, std::min(pl->v1_block, nky - i0), pl->d_v1streams,
                                        pl->d_v1dev + (size_t) i0 * pl->N * pl->N, pl->d_v1err, st))
                     return 1;
-        if (zd::launch_gen(pl->g, pl->J, pl->jobs, pl->S, r0, nky, pl->L, residue, residue, pl->d_twN, pl->d_Y[0], nullptr, 0, st)) return 1;
+        // (k_genf with walks of 16 / 4 / 2 z rows where the kernel exists, else the general generator)
+        if (zd::launch_gen(pl->g, pl->J, pl->jobs, pl->S, r0, nky, pl->L, residue, residue, pl->d_twN, pl->d_Y[0], pl->d_tilectr + slab,
+                           pl->gen_max_wgs, st))
+            return 1;
         tick(pl, ZD_K_GEN, st, false);
         tick(pl, ZD_K_ZFFT, st, true);
         if (zd::launch_any_cols(pl->tabL, pl->d_Y[0], (long long) pl->L * pl->N, pl->N, pl->N, pl->jobs.n * nky, -1, st)) return 1;

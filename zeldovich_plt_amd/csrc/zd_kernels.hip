@@ -2074,9 +2074,15 @@ static int launch_genf_t(const GenConst &g, const GenJumps &J, const StoreLayout
                          hipStream_t st) {
     if (gen_zr(L) == GEN_ZR)
         return launch_genf_z<GEN_ZR, KIND, PLAW>(g, J, S, ky0, kyl0, nky, nrows, L, residue, residue2, twN, Y, tile_ctr, max_wgs, st);
-    if constexpr (KIND == GENF_ZAF || KIND == GENF_PLTF) {  // the short walk: field stores only
+    if constexpr (KIND == GENF_ZAF || KIND == GENF_PLTF) {  // the short walk of the field stores (z lines of 108)
         if (gen_zr(L) == 4)
             return launch_genf_z<4, KIND, PLAW>(g, J, S, ky0, kyl0, nky, nrows, L, residue, residue2, twN, Y, tile_ctr, max_wgs, st);
+    }
+    if constexpr (KIND == GENF_DENS || KIND == GENF_ZA || KIND == GENF_PLT) {  // reference arrays of the any-PPD path
+        if (gen_zr(L) == 4)
+            return launch_genf_z<4, KIND, PLAW>(g, J, S, ky0, kyl0, nky, nrows, L, residue, residue2, twN, Y, tile_ctr, max_wgs, st);
+        if (gen_zr(L) == 2)
+            return launch_genf_z<2, KIND, PLAW>(g, J, S, ky0, kyl0, nky, nrows, L, residue, residue2, twN, Y, tile_ctr, max_wgs, st);
     }
     return 2;
 }
@@ -2120,8 +2126,11 @@ int launch_gen(const GenConst &g, const GenJumps &J, const JobList &jobs, const 
 #endif
     // rows ky >= 1 of a production run go through k_genf; everything else through the general kernel
     const int kind = genf_kind(jobs, g.qPLT != 0);
+    const int zr = gen_zr(L);
+    const bool ref_kind = kind == GENF_DENS || kind == GENF_ZA || kind == GENF_PLT;
+    const bool zr_ok = zr == GEN_ZR || (zr == 4 && (kind == GENF_ZAF || kind == GENF_PLTF || ref_kind)) || (zr == 2 && ref_kind);
     const bool fast = g.genf_tab && tile_ctr && !g.phik && !g.gen_phi && !g.qonemode && !g.v1dev && !ZD_TUNE(g.ablate & 15) && !force_general
-                      && kind >= 0;
+                      && kind >= 0 && zr_ok;
     int general_rows = nky;
     if (fast) {
         general_rows = ky0 == 0 ? 1 : 0;  // the ky = 0 plane (conjugate "loser" modes) stays with k_gen
