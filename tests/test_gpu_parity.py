@@ -425,6 +425,46 @@ def test_fnl_end_to_end(zd, oracle, ps, wmap_path, n, kw):
     assert abs(got["density_variance"] - ref["density_variance"]) <= TOL * ref["density_variance"]
 
 
+@pytest.mark.parametrize("ngpu,n,kw", [(2, 64, dict()), (4, 128, dict(stream_factor=2, exchange_planes=3)), (2, 64, dict(plt=True))])
+def test_fnl_on_several_ranks(zd, oracle, ps, wmap_path, ngpu, n, kw):
+    """ZD_f_NL with ZD_NumGPU > 1: the phi round travels to the XY ranks in plane groups, is transformed there (inverse y, x with
+    phi + f_NL phi^2, forward y) and travels back; every rank then transforms its own rows along z (zd_multi.cpp phi_round).
+    Ranks share this GPU (local transport)."""
+    import ctypes as C
+    kw = dict(kw)
+    fnl, ns, om = 2.0e4, 0.96, 0.31
+    eig = None
+    if kw.pop("plt", False):
+        eig = oracle.synthetic_eigenmodes(32)
+        kw.update(qPLT=1, qPLTrescale=1, PLT_target_z=5.0, f_cluster=0.97)
+    opk = oracle.pk_from_file(wmap_path, 720.0)
+    oracle.lib().zdo_pk_set_primordial(C.byref(opk), ns)
+    got = zd.generate(zd.make_params(n, icformat="RVdoubleZel", f_NL=fnl, n_s=ns, Omega_M=om, ngpu=ngpu, **kw), ps, eig=eig)
+    okw = {k: v for k, v in kw.items() if k not in ("stream_factor", "exchange_planes")}
+    ref = oracle.run(oracle.make_params(n, numblock=2, icformat="RVdoubleZel", f_NL=fnl, n_s=ns, Omega_M=om, **okw), opk,
+                     eig=eig, eig_ppd=0 if eig is None else eig.shape[0])
+    for f in ("d", "v"):
+        for c in range(3):
+            assert _rel(got["records"][f][..., c], ref["records"][f][..., c]) < TOL, (f, c)
+    assert sorted(got["planes_seen"]) == list(range(n))
+    assert abs(got["density_variance"] - ref["density_variance"]) <= TOL * ref["density_variance"]
+
+
+def test_fnl_several_ranks_equal_one_rank_at_512(zd, ps):
+    """ZD_f_NL at PPD = 512: four ranks (several plane groups both ways) against the single-GPU path, records of sample planes"""
+    n, zs = 512, (3, 259, 510)
+    got = {}
+    for ngpu in (1, 4):
+        planes = {}
+        p = zd.make_params(n, icformat="RVZel", f_NL=2.0e4, n_s=0.96, Omega_M=0.31, ngpu=ngpu, exchange_planes=7 if ngpu > 1 else 0)
+        out = zd.generate_planes(p, ps, lambda z, rec: planes.__setitem__(z, rec.copy()) if z in zs else None)
+        got[ngpu] = (planes, out)
+    for z in zs:
+        a, b = got[1][0][z], got[4][0][z]
+        assert np.abs(a["d"] - b["d"]).max() <= 1e-6 * np.abs(a["d"]).max(), z
+    assert abs(got[1][1]["density_variance"] - got[4][1]["density_variance"]) <= 1e-11 * got[1][1]["density_variance"]
+
+
 def test_fnl_through_the_staged_api(zd, oracle, ps, wmap_path):
     """ZD_f_NL through zd_plan_create + the staged pipeline (what bench.py drives): the phi round runs at plan creation, the
     plan owns PhiK; every plane against the oracle"""

@@ -407,9 +407,11 @@ static int make_phik(const zd_params *p, const zd_pk *pk, cplx **d_phik) {
         }
         fprintf(stderr, "Generating phi field\n");
         if (zd_plan_stage_z(ph, 0, d_phi, 0) || zd_plan_stage_y(ph, d_phi, 0)) break;
-        if (zd::launch_fnl_stage(0, ph->S, p->f_NL, ph->d_twN, d_phi, nullptr, 0)) break;
-        if (zd::launch_fnl_stage(1, ph->S, p->f_NL, ph->d_twN, d_phi, nullptr, 0)) break;
-        if (zd::launch_fnl_stage(2, ph->S, p->f_NL, ph->d_twN, d_phi, *d_phik, 0)) break;
+        int lN = 0;
+        while ((1 << lN) < (int) N) lN++;
+        if (zd::launch_fnl_stage(0, ph->S, p->f_NL, ph->d_twN, d_phi, nullptr, (int) N, lN, 0)) break;
+        if (zd::launch_fnl_stage(1, ph->S, p->f_NL, ph->d_twN, d_phi, nullptr, (int) N, lN, 0)) break;
+        if (zd::launch_fnl_stage(2, ph->S, p->f_NL, ph->d_twN, d_phi, *d_phik, (int) N, lN, 0)) break;
         if (hipDeviceSynchronize() != hipSuccess) break;
         frc = 0;
     } while (0);
@@ -420,6 +422,36 @@ static int make_phik(const zd_params *p, const zd_pk *pk, cplx **d_phik) {
         *d_phik = nullptr;
     }
     return frc;
+}
+
+static zd::StoreLayout layout_for_chunks(const zd_plan *pl, int chunk_planes);
+
+// ---- f_NL on several ranks (zd_multi.cpp): the plans of the phi round and of the main pass, and the stages of the phi round
+// on a plane group / on the returned store ----
+int zd_plan_create_phi(const zd_params *p, const zd_pk *pk, int rank, int nranks, zd_plan **out) {
+    zd_params pp     = *p;
+    pp.stream_factor = 1;  // the forward z transform needs every plane of a row: one pass
+    pp.qPLT          = 0;
+    return plan_create_ex(&pp, pk, nullptr, 0, rank, nranks, 1, nullptr, out);
+}
+int zd_plan_create_phik(const zd_params *p, const zd_pk *pk, const double *eig, int64_t eig_ppd, int rank, int nranks, const void *d_phik,
+                        zd_plan **out) {
+    return plan_create_ex(p, pk, eig, eig_ppd, rank, nranks, 0, (const cplx *) d_phik, out);
+}
+// planes [0, nplanes) of a ring slot with `chunk_planes` planes per chunk: inverse y, x (inverse, phi + f_NL phi^2, forward),
+// forward y — ZeldovichXY_Phi (zeldovich.cpp:699-790)
+int zd_plan_phi_xy_group(zd_plan *pl, void *d_slot, int chunk_planes, int nplanes, double f_NL, void *hip_stream) {
+    hipStream_t st = (hipStream_t) hip_stream;
+    const zd::StoreLayout S = layout_for_chunks(pl, chunk_planes);
+    if (zd::launch_yfft(S, nplanes, pl->d_twN, d_slot, st)) return 1;
+    if (zd::launch_fnl_stage(0, S, f_NL, pl->d_twN, d_slot, nullptr, nplanes, 0, st)) return 1;
+    return zd::launch_fnl_stage(1, S, f_NL, pl->d_twN, d_slot, nullptr, nplanes, 0, st);
+}
+// forward z over this rank's rows of the returned store -> PhiK[row slot][kz][x]
+int zd_plan_phi_zfwd(zd_plan *pl, void *d_store, void *d_phik, void *hip_stream) {
+    int lZq = 0;
+    while ((1 << lZq) < pl->Zq) lZq++;
+    return zd::launch_fnl_stage(2, pl->S, 0.0, pl->d_twN, d_store, d_phik, pl->N, lZq, (hipStream_t) hip_stream);
 }
 
 int zd_plan_create(const zd_params *p, const zd_pk *pk, const double *eig, int64_t eig_ppd, int rank, int nranks,

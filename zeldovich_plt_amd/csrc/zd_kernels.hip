@@ -332,7 +332,7 @@ __global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, JobList 
             double dr = 0.0, di = 0.0, ik2 = 1.0;
             if (g.phik) {  // f_NL, second pass: D = phi_NG(k) * M(k) for every mode but k = 0 (zeldovich.cpp:393-400)
                 if (k2i != 0) {
-                    const cplx ph  = g.phik[((long long) ky * N + zs) * N + xs];
+                    const cplx ph  = g.phik[((long long) (ky >> S.lG) * N + zs) * N + xs];  // PhiK rows are this rank's row slots
                     const double M = g.fnl_M[k2i];
                     dr  = ph.x * M;
                     di  = ph.y * M;
@@ -1911,21 +1911,24 @@ __global__ __launch_bounds__(W *N / E) void k_yfwd(StoreLayout S, const cplx *__
     for (int e = 0; e < E; e++) base[row_offset(S, zl, 0, t2 + T * e)] = cplx{re[e], -im[e]};
 }
 
-// forward z FFT of the half-space rows: gathers a column tile across all N planes of the store and
-// writes PhiK[ky][kz][x] (what LoadBlockForward + ForwardFFT_Yonly hand to LoadPlane)
+// forward z FFT of this rank's half-space rows: gathers a column tile across all N planes — plane z sits in chunk z / Zq
+// (the rank that did its XY stage), local plane z % Zq, at this rank's row slot — and writes PhiK[row slot][kz][x] (what
+// LoadBlockForward + ForwardFFT_Yonly hand to LoadPlane; with G ranks the slot of ky is ky / G)
 template <int N, int E, int W>
-__global__ __launch_bounds__(W *N / E) void k_zfwd(StoreLayout S, const cplx *__restrict__ tw, const cplx *__restrict__ data,
+__global__ __launch_bounds__(W *N / E) void k_zfwd(StoreLayout S, int lZq, const cplx *__restrict__ tw, const cplx *__restrict__ data,
                                                   cplx *__restrict__ phik) {
     using PL  = zdfft::Plan<N, E>;
     using LDS = zdfft::ColsInner<N, W>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int T = PL::T;
     const int w = threadIdx.x % W, t = threadIdx.x / W;
-    const int x = blockIdx.x * W + w, ky = blockIdx.y;
+    const int x = blockIdx.x * W + w, ky = blockIdx.y;  // ky: row slot
+    const int zmask = (1 << lZq) - 1;
     double re[E], im[E];
 #pragma unroll
     for (int e = 0; e < E; e++) {
-        const cplx v = data[row_offset(S, t + T * e, 0, ky) + x];
+        const int z = t + T * e;
+        const cplx v = data[store_offset(S, z >> lZq, z & zmask, 0, ky) + x];
         re[e] = v.x;
         im[e] = -v.y;
     }
@@ -2526,33 +2529,37 @@ int launch_fnl_table(const GenConst &g, int n, void *tab, hipStream_t st) {
 }
 
 template <int N, int E, int W, int ROWS>
-static int launch_fnl_t(int which, const StoreLayout &S, double f_NL, const void *tw, void *data, void *phik, hipStream_t st) {
+static int launch_fnl_t(int which, const StoreLayout &S, double f_NL, const void *tw, void *data, void *phik, int nplanes, int lZq,
+                        hipStream_t st) {
     if (which == 0) {  // x: inverse + nonlinearity + forward
         constexpr int threads = ROWS * N / E;
         const size_t shmem = sizeof(double) * zdfft::LineInner<N, ROWS>::SIZE;
         hipFuncSetAttribute((const void *) k_xphi<N, E, ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
         const double inv = 1. / N / N / N;
-        hipLaunchKernelGGL((k_xphi<N, E, ROWS>), dim3(N / ROWS, N), dim3(threads), shmem, st, S, f_NL, inv, (const cplx *) tw,
+        hipLaunchKernelGGL((k_xphi<N, E, ROWS>), dim3(N / ROWS, nplanes), dim3(threads), shmem, st, S, f_NL, inv, (const cplx *) tw,
                            (cplx *) data);
     } else {
         constexpr int threads = W * N / E;
         const size_t shmem = sizeof(double) * zdfft::ColsInner<N, W>::SIZE;
         if (which == 1) {
             hipFuncSetAttribute((const void *) k_yfwd<N, E, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
-            hipLaunchKernelGGL((k_yfwd<N, E, W>), dim3(N / W, 1, N), dim3(threads), shmem, st, S, (const cplx *) tw, (cplx *) data);
+            hipLaunchKernelGGL((k_yfwd<N, E, W>), dim3(N / W, 1, nplanes), dim3(threads), shmem, st, S, (const cplx *) tw, (cplx *) data);
         } else {
             hipFuncSetAttribute((const void *) k_zfwd<N, E, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
-            hipLaunchKernelGGL((k_zfwd<N, E, W>), dim3(N / W, N / 2), dim3(threads), shmem, st, S, (const cplx *) tw,
+            hipLaunchKernelGGL((k_zfwd<N, E, W>), dim3(N / W, S.Hq), dim3(threads), shmem, st, S, lZq, (const cplx *) tw,
                                (const cplx *) data, (cplx *) phik);
         }
     }
     ZD_LAUNCH_CHECK();
     return 0;
 }
-// which: 0 = x pass (inverse, phi + f_NL phi^2, forward), 1 = forward y, 2 = forward z -> phik
-int launch_fnl_stage(int which, const StoreLayout &S, double f_NL, const void *tw, void *data, void *phik, hipStream_t st) {
+// which: 0 = x pass (inverse, phi + f_NL phi^2, forward) and 1 = forward y, on the planes [0, nplanes) of `data` (a store or a
+// ring slot of the exchange); 2 = forward z over this rank's S.Hq row slots and all N planes (lZq = log2 of the planes per
+// chunk) -> phik
+int launch_fnl_stage(int which, const StoreLayout &S, double f_NL, const void *tw, void *data, void *phik, int nplanes, int lZq,
+                     hipStream_t st) {
 #define FCASE(n, e, w, rows) \
-    case n: return launch_fnl_t<n, e, w, rows>(which, S, f_NL, tw, data, phik, st);
+    case n: return launch_fnl_t<n, e, w, rows>(which, S, f_NL, tw, data, phik, nplanes, lZq, st);
     switch (S.N) {
         FCASE(32, 16, 32, 32)
         FCASE(64, 16, 32, 32)

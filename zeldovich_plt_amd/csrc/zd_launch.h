@@ -39,7 +39,8 @@ int launch_xfft(const StoreLayout &S, const EpiConst &ec, const void *tw, const 
                 int z_first, int z_step, void *records, float *density, Reduce *red, hipStream_t st);
 int launch_yfft_variant(int variant, const StoreLayout &S, int nplanes, const void *tw, void *data, hipStream_t st);
 int launch_fnl_table(const GenConst &g, int n, void *tab, hipStream_t st);
-int launch_fnl_stage(int which, const StoreLayout &S, double f_NL, const void *tw, void *data, void *phik, hipStream_t st);
+int launch_fnl_stage(int which, const StoreLayout &S, double f_NL, const void *tw, void *data, void *phik, int nplanes, int lZq,
+                     hipStream_t st);
 int launch_test_fft(int n, int kind, const void *tw, const void *in, void *out, long long lines, hipStream_t st);
 int test_fft_tile_width(int n);
 // ---- PPD = 2^a 3^b (zd_kernels_np2.hip) ----

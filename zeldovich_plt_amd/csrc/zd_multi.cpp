@@ -98,6 +98,7 @@ RcclApi *rccl() {
 struct LocalGroup {
     int n = 0;
     std::vector<const char *> send_base;  // each rank's send store of the current pass
+    std::vector<const char *> ring_base;  // each rank's exchange ring (phi round: the reverse exchange pulls from the peers' slots)
     std::atomic<int> failed{0};
     // barrier that a failed rank can break (a plain pthread barrier would hang the survivors)
     std::mutex mu;
@@ -335,6 +336,98 @@ static int run_pass_impl(zd_plan *pl, zd_comm *c, int pass, void *d_store, void 
     return 0;
 }
 
+// The phi round of ZD_f_NL on several ranks (zeldovich.cpp:945-960: ZeldovichZ(gen_phi) + ZeldovichXY_Phi, then the forward z
+// transform that LoadBlockForward / ForwardFFT_Yonly do for the second ZeldovichZ).  `ph` is the plan of zd_plan_create_phi
+// (one array, R = 1).  Rank g generates phi = D / M for its rows into d_store; plane groups travel to their XY ranks exactly
+// as in zd_plan_run_pass, are transformed there (inverse y, x with phi + f_NL phi^2, forward y) and travel BACK into the same
+// places of d_store — the reverse exchange, on the same communication stream, so that a ring slot is reused only after its
+// return trip; finally every rank transforms its own rows along z into d_phik[row slot][kz][x].
+static int phi_round(zd_plan *ph, zd_comm *c, void *d_store, void *d_phik, double f_NL, hipStream_t st) {
+    if (zd_plan_stage_z(ph, 0, d_store, st)) return 1;
+    int gp = 0;
+    const int64_t ring_b = zd_plan_ring_bytes(ph, &gp);
+    if (!c->ring) {
+        MHIP(hipMalloc((void **) &c->ring, (size_t) ring_b));
+        c->slot_bytes   = ring_b / 2;
+        c->group_planes = gp;
+    }
+    const int G = ph->nranks, me = ph->rank;
+    const int64_t cpb = chunk_plane_bytes(ph), chunk_b = cpb * ph->Zq;
+    const int ngroups = (ph->Zq + gp - 1) / gp;
+    MHIP(hipEventRecord(c->ev_z, st));
+    MHIP(hipStreamWaitEvent(c->s_comm, c->ev_z, 0));
+    if (c->kind == 1) {
+        MHIP(hipStreamSynchronize(st));
+        c->grp->send_base[me] = (const char *) d_store;
+        c->grp->ring_base[me] = c->ring;
+        if (c->grp->wait()) return 1;
+    }
+    // forward: chunk <me> of every peer's store -> slot[source rank]; reverse: slot[rank s] -> chunk <me> of rank s's store
+    auto travel = [&](int j, bool reverse) -> int {
+        const int slot = j & 1;
+        const int64_t p0 = (int64_t) j * gp, np = std::min<int64_t>(gp, ph->Zq - p0);
+        const size_t nb = (size_t) (cpb * np);
+        char *ring = c->ring + (size_t) slot * c->slot_bytes;
+        if (c->kind == 1) {
+            for (int s = 0; s < G; s++) {
+                if (!reverse)
+                    MHIP(hipMemcpyAsync(ring + (size_t) s * cpb * gp, c->grp->send_base[s] + (size_t) me * chunk_b + (size_t) p0 * cpb, nb,
+                                        hipMemcpyDeviceToDevice, c->s_comm));
+                else  // pull what rank s finished of MY rows: its slot[me] -> my chunk s
+                    MHIP(hipMemcpyAsync((char *) d_store + (size_t) s * chunk_b + (size_t) p0 * cpb,
+                                        c->grp->ring_base[s] + (size_t) slot * c->slot_bytes + (size_t) me * cpb * gp, nb, hipMemcpyDeviceToDevice,
+                                        c->s_comm));
+            }
+        } else {
+            RcclApi *R = rccl();
+            MNCCL(R->GroupStart());
+            for (int p = 0; p < G; p++) {
+                char *sb = (char *) d_store + (size_t) p * chunk_b + (size_t) p0 * cpb;  // my rows, planes of rank p
+                char *rb = ring + (size_t) p * cpb * gp;                                 // rank p's rows, my planes
+                if (p == me) continue;
+                MNCCL(R->Send(reverse ? rb : sb, nb, ncclChar, p, c->nccl, c->s_comm));
+                MNCCL(R->Recv(reverse ? sb : rb, nb, ncclChar, p, c->nccl, c->s_comm));
+            }
+            MNCCL(R->GroupEnd());
+            char *own_s = (char *) d_store + (size_t) me * chunk_b + (size_t) p0 * cpb, *own_r = ring + (size_t) me * cpb * gp;
+            MHIP(hipMemcpyAsync(reverse ? own_s : own_r, reverse ? own_r : own_s, nb, hipMemcpyDeviceToDevice, c->s_comm));
+        }
+        if (!reverse) MHIP(hipEventRecord(c->ev_r[slot], c->s_comm));
+        return 0;
+    };
+    if (c->kind == 1) {  // local transport (test boxes): one group at a time, rendezvous around every step
+        for (int j = 0; j < ngroups; j++) {
+            const int64_t np = std::min<int64_t>(gp, ph->Zq - (int64_t) j * gp);
+            if (travel(j, false)) return 1;
+            MHIP(hipStreamSynchronize(c->s_comm));
+            if (zd_plan_phi_xy_group(ph, c->ring + (size_t) (j & 1) * c->slot_bytes, gp, (int) np, f_NL, st)) return 1;
+            MHIP(hipStreamSynchronize(st));
+            if (c->grp->wait()) return 1;  // every rank's slot is finished before anybody pulls from it
+            if (travel(j, true)) return 1;
+            MHIP(hipStreamSynchronize(c->s_comm));
+            if (c->grp->wait()) return 1;  // ... and pulled before it is overwritten
+        }
+    } else {
+        if (travel(0, false)) return 1;
+        if (ngroups > 1 && travel(1, false)) return 1;
+        for (int j = 0; j < ngroups; j++) {
+            const int slot = j & 1;
+            const int64_t np = std::min<int64_t>(gp, ph->Zq - (int64_t) j * gp);
+            MHIP(hipStreamWaitEvent(st, c->ev_r[slot], 0));
+            if (zd_plan_phi_xy_group(ph, c->ring + (size_t) slot * c->slot_bytes, gp, (int) np, f_NL, st)) return 1;
+            MHIP(hipEventRecord(c->ev_x[slot], st));
+            MHIP(hipStreamWaitEvent(c->s_comm, c->ev_x[slot], 0));
+            if (travel(j, true)) return 1;                           // the group goes home ...
+            if (j + 2 < ngroups && travel(j + 2, false)) return 1;   // ... and only then is its slot filled again
+        }
+        MHIP(hipEventRecord(c->ev_z, c->s_comm));
+        MHIP(hipStreamWaitEvent(st, c->ev_z, 0));
+    }
+    if (zd_plan_phi_zfwd(ph, d_store, d_phik, st)) return 1;
+    MHIP(hipStreamSynchronize(st));
+    return 0;
+}
+
 }  // extern "C"
 
 // ------------------------------------------------------------------------------------------------
@@ -401,8 +494,9 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
         fprintf(stderr, "zeldovich_hip: no GPU\n");
         return 1;
     }
-    if (p_in->f_NL != 0.) {
-        fprintf(stderr, "zeldovich_hip: ZD_f_NL != 0 runs on one GPU (the forward z transform of the phi field needs every plane)\n");
+    if (p_in->f_NL != 0. && (p_in->ppd > 4096 || (p_in->ppd & (p_in->ppd - 1)) || p_in->version == 1)) {
+        fprintf(stderr, "zeldovich_hip: ZD_f_NL != 0 on several GPUs needs a power-of-two PPD <= 4096 (the z lines of the phi round are not "
+                        "streamed) and ZD_Version = 2\n");
         return 1;
     }
     if (transport == 0 && ndev < G) {
@@ -414,7 +508,9 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
         size_t free_b = 0, total_b = 0;
         MHIP(hipMemGetInfo(&free_b, &total_b));
         const int ranks_per_dev = (G + ndev - 1) / ndev;
-        const int R = zd_choose_stream_factor(&p, G, ((int64_t) free_b - ((int64_t) 16 << 30)) / ranks_per_dev);
+        // (ZD_f_NL: every rank also keeps PhiK of its rows, N^3 / (2 G) complex)
+        const int64_t phik_b = p.f_NL != 0. ? (p.ppd / 2 / G) * p.ppd * p.ppd * 16 : 0;
+        const int R = zd_choose_stream_factor(&p, G, ((int64_t) free_b - ((int64_t) 16 << 30)) / ranks_per_dev - phik_b);
         if (R < 0) {
             fprintf(stderr, "zeldovich_hip: PPD %lld does not fit %d GPU(s)\n", (long long) p.ppd, G);
             return 1;
@@ -427,6 +523,7 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
     if (transport == 1) {
         grp.n = G;
         grp.send_base.assign(G, nullptr);
+        grp.ring_base.assign(G, nullptr);
     } else {
         RcclApi *R = rccl();
         if (!R) {
@@ -451,19 +548,44 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
             zd_plan *pl = nullptr;
             void *d_store = nullptr, *d_rec = nullptr;
             float *d_dens = nullptr, *h_dens = nullptr;
+            void *d_phik = nullptr;
             char *h_rec = nullptr;
             zd_comm *c  = new zd_comm;
             hipStream_t st = nullptr;
             do {
                 if (hipSetDevice(me.device) != hipSuccess) break;
                 if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
-                if (zd_plan_create(&p, pk, eig, eig_ppd, g, G, &pl)) break;
                 c->rank   = g;
                 c->nranks = G;
                 c->kind   = transport;
                 c->nccl   = nccls[g];
                 c->grp    = &grp;
                 if (comm_prepare(c)) break;
+                if (p.f_NL != 0.) {  // the phi round first (its own plan, store and ring), then the main plan reads PhiK
+                    zd_plan *ph = nullptr;
+                    void *d_phi = nullptr;
+                    bool ok     = false;
+                    do {
+                        if (zd_plan_create_phi(&p, pk, g, G, &ph)) break;
+                        if (hipMalloc(&d_phi, (size_t) zd_plan_exchange_bytes(ph)) != hipSuccess
+                            || hipMalloc(&d_phik, (size_t) ph->Hq * ph->N * ph->N * 16) != hipSuccess) {
+                            fprintf(stderr, "zeldovich_hip: rank %d: f_NL needs %.1f GB of HBM for the phi field\n", g,
+                                    (zd_plan_exchange_bytes(ph) + (double) ph->Hq * ph->N * ph->N * 16) / 1e9);
+                            break;
+                        }
+                        if (g == 0) fprintf(stderr, "Generating phi field\n");
+                        if (phi_round(ph, c, d_phi, d_phik, p.f_NL, st)) break;
+                        ok = true;
+                    } while (0);
+                    hipFree(d_phi);
+                    if (ph) zd_plan_destroy(ph);
+                    hipFree(c->ring);  // sized for the phi plan: the main pass allocates its own
+                    c->ring = nullptr;
+                    if (!ok) break;
+                    if (zd_plan_create_phik(&p, pk, eig, eig_ppd, g, G, d_phik, &pl)) break;
+                } else if (zd_plan_create(&p, pk, eig, eig_ppd, g, G, &pl)) {
+                    break;
+                }
                 const int ps = pl->pstep;
                 const bool want_rec = pl->narray >= 2, want_dens = p.qdensity != 0;  // ZD_qdensity = 2: density only
                 const size_t nn = (size_t) pl->N * pl->N;
@@ -493,6 +615,7 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
             hipFree(d_store);
             hipFree(d_rec);
             hipFree(d_dens);
+            hipFree(d_phik);
             if (h_rec) hipHostFree(h_rec);
             if (h_dens) hipHostFree(h_dens);
             c->nccl = nullptr;  // destroyed below, after every thread has left RCCL

@@ -83,6 +83,12 @@ extern "C" {
 int zd_plan_stage_y_group(zd_plan *pl, void *d_recv, int chunk_planes, int nplanes, void *hip_stream);
 int zd_plan_stage_x_group(zd_plan *pl, int residue, const void *d_recv, int chunk_planes, int64_t plane0, int64_t gplane0,
                           int64_t nplanes, void *d_records, float *d_density, void *hip_stream);
+// f_NL on several ranks (zd_multi.cpp)
+int zd_plan_create_phi(const zd_params *p, const zd_pk *pk, int rank, int nranks, zd_plan **out);
+int zd_plan_create_phik(const zd_params *p, const zd_pk *pk, const double *eig, int64_t eig_ppd, int rank, int nranks, const void *d_phik,
+                        zd_plan **out);
+int zd_plan_phi_xy_group(zd_plan *pl, void *d_slot, int chunk_planes, int nplanes, double f_NL, void *hip_stream);
+int zd_plan_phi_zfwd(zd_plan *pl, void *d_store, void *d_phik, void *hip_stream);
 }
 int zd_generate_multi(const zd_params *p, const zd_pk *pk, const double *eig, int64_t eig_ppd, zd_slab_cb cb, void *user,
                       zd_stats *out, int transport);
