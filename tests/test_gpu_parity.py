@@ -807,9 +807,17 @@ def test_version1_properties(zd, ps):
     assert np.abs(a - d).max() > 0.1 * np.abs(a).max()
 
 
-def test_version1_with_fnl_rejected(zd, ps):
-    with pytest.raises(RuntimeError):
-        zd.generate(zd.make_params(64, numblock=4, version=1, f_NL=10.0, n_s=0.96, Omega_M=0.3), ps)
+@pytest.mark.parametrize("ngpu", [1, 2])
+def test_version1_with_fnl(zd, oracle, ps, wmap_path, ngpu):
+    """ZD_f_NL on the legacy streams: the phi round draws with cgauss<1>, the second pass takes D from PhiK"""
+    import ctypes as C
+    n, fnl, ns, om = 64, 2.0e4, 0.96, 0.31
+    opk = oracle.pk_from_file(wmap_path, 720.0)
+    oracle.lib().zdo_pk_set_primordial(C.byref(opk), ns)
+    got = zd.generate(zd.make_params(n, numblock=4, version=1, f_NL=fnl, n_s=ns, Omega_M=om, ngpu=ngpu), ps)
+    ref = oracle.run(oracle.make_params(n, numblock=4, version=1, f_NL=fnl, n_s=ns, Omega_M=om), opk)
+    for f in ("d", "v"):
+        assert _rel(got["records"][f], ref["records"][f]) < TOL
 
 
 # ---- any even PPD: convolution (Bluestein) transforms on the power-of-two engine (zd_kernels_any.hip) ----

@@ -522,14 +522,15 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
                 (long long) N, R, nranks);
         return 1;
     }
-    const bool v1 = p->version == 1;  // legacy mt19937 streams, one per yres (power_spectrum.cpp:18-25)
+    // legacy mt19937 streams, one per yres (power_spectrum.cpp:18-25); the second f_NL pass takes D from PhiK and draws nothing
+    const bool v1 = p->version == 1 && phik == nullptr;
     if (p->version != 0 && p->version != 1 && p->version != 2) {
         fprintf(stderr, "zeldovich_hip: ZD_Version = %d (1 or 2 expected)\n", p->version);
         return 1;
     }
-    if (v1 && (p->numblock <= 0 || N % p->numblock || (N / p->numblock) % nranks || phi_mode != 0 || phik != nullptr)) {
-        fprintf(stderr, "zeldovich_hip: ZD_Version = 1 needs ZD_NumBlock dividing PPD, PPD/NumBlock streams divisible by the number of "
-                        "ranks (%d), and ZD_f_NL = 0\n", nranks);
+    if (v1 && (p->numblock <= 0 || N % p->numblock || (N / p->numblock) % nranks)) {
+        fprintf(stderr, "zeldovich_hip: ZD_Version = 1 needs ZD_NumBlock dividing PPD and PPD/NumBlock streams divisible by the number of "
+                        "ranks (%d)\n", nranks);
         return 1;
     }
     zd_plan *pl = new zd_plan;

@@ -494,9 +494,9 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
         fprintf(stderr, "zeldovich_hip: no GPU\n");
         return 1;
     }
-    if (p_in->f_NL != 0. && (p_in->ppd > 4096 || (p_in->ppd & (p_in->ppd - 1)) || p_in->version == 1)) {
+    if (p_in->f_NL != 0. && (p_in->ppd > 4096 || (p_in->ppd & (p_in->ppd - 1)))) {
         fprintf(stderr, "zeldovich_hip: ZD_f_NL != 0 on several GPUs needs a power-of-two PPD <= 4096 (the z lines of the phi round are not "
-                        "streamed) and ZD_Version = 2\n");
+                        "streamed)\n");
         return 1;
     }
     if (transport == 0 && ndev < G) {
