@@ -450,6 +450,29 @@ def test_fnl_on_several_ranks(zd, oracle, ps, wmap_path, ngpu, n, kw):
     assert abs(got["density_variance"] - ref["density_variance"]) <= TOL * ref["density_variance"]
 
 
+@pytest.mark.parametrize("n,kw", [(50, dict()), (96, dict(stream_factor=2)), (70, dict(plt=True, stream_factor=5))])
+def test_fnl_on_any_even_ppd(zd, oracle, ps, wmap_path, n, kw):
+    """ZD_f_NL on the convolution-transform PPDs (also 2^a 3^b ones: the composite kernels have no phi round): the forward
+    transform of the real phi + f_NL phi^2 is the conjugate of its inverse transform"""
+    import ctypes as C
+    kw = dict(kw)
+    fnl, ns, om = 2.0e4, 0.96, 0.31
+    eig = None
+    if kw.pop("plt", False):
+        eig = oracle.synthetic_eigenmodes(24)
+        kw.update(qPLT=1, qPLTrescale=1, PLT_target_z=5.0, f_cluster=0.97)
+    opk = oracle.pk_from_file(wmap_path, 720.0)
+    oracle.lib().zdo_pk_set_primordial(C.byref(opk), ns)
+    got = zd.generate(zd.make_params(n, icformat="RVdoubleZel", f_NL=fnl, n_s=ns, Omega_M=om, **kw), ps, eig=eig)
+    okw = {k: v for k, v in kw.items() if k != "stream_factor"}
+    ref = oracle.run(oracle.make_params(n, numblock=2, icformat="RVdoubleZel", f_NL=fnl, n_s=ns, Omega_M=om, **okw), opk,
+                     eig=eig, eig_ppd=0 if eig is None else eig.shape[0])
+    for f in ("d", "v"):
+        for c in range(3):
+            assert _rel(got["records"][f][..., c], ref["records"][f][..., c]) < TOL, (f, c)
+    assert abs(got["density_variance"] - ref["density_variance"]) <= TOL * ref["density_variance"]
+
+
 def test_fnl_several_ranks_equal_one_rank_at_512(zd, ps):
     """ZD_f_NL at PPD = 512: four ranks (several plane groups both ways) against the single-GPU path, records of sample planes"""
     n, zs = 512, (3, 259, 510)

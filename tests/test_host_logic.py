@@ -65,7 +65,7 @@ def test_stream_factor_for_any_even_ppd(zd):
     assert R(1000, 250 * GB, nranks=2) == -1
     assert R(1000, 250 * GB, qPLT=1) == 1 and R(1000, 250 * GB, qdensity=2) == 1
     assert R(96, 250 * GB) == 2 and R(96, 250 * GB, qdensity=1) == 1   # composite kernels / convolution kernels
-    assert R(1000, 250 * GB, f_NL=1.0, n_s=0.96, Omega_M=0.3) == -1
+    assert R(1000, 250 * GB, f_NL=1.0, n_s=0.96, Omega_M=0.3) == 1
 
 
 def test_params_from_file(zd, tmp_path):

@@ -357,7 +357,7 @@ int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes
     // any other even PPD (or a 2^a 3^b one whose options the composite kernels lack): reference arrays on one rank, see
     // plan_create_ex; R any divisor of N
     auto any_factor = [&]() -> int {
-        if (N % 2 || N < 8 || N > 8192 || nranks != 1 || p->f_NL != 0.) return -1;
+        if (N % 2 || N < 8 || N > 8192 || nranks != 1) return -1;
         const int64_t narray = p->qdensity == 2 ? 1 : (p->qPLT ? 4 : 2);
         for (int R = 1; N / R >= 3; R++)  // any divisor of N (the z-residue fold is a plain decimation: R need not be 2^k here)
             if (N % R == 0 && (N / R) * narray * N * (N + store_row_pad(N)) * 16 <= budget_bytes) return R;
@@ -407,6 +407,19 @@ static int make_phik(const zd_params *p, const zd_pk *pk, cplx **d_phik) {
         }
         fprintf(stderr, "Generating phi field\n");
         if (zd_plan_stage_z(ph, 0, d_phi, 0) || zd_plan_stage_y(ph, d_phi, 0)) break;
+        if (ph->any) {  // convolution-transform PPDs: x inverse, phi + f_NL phi^2, then the forward 3-D transform of that REAL
+                        // field as the conjugate of its inverse transform (x, y, z in place; conjugated while PhiK is laid out)
+            const long long plane = (long long) N * ph->AL.pitch;
+            if (zd::launch_any_lines(ph->tabN, d_phi, ph->AL.pitch, (long long) N * N, 0)) break;
+            if (zd::launch_any_phi_nl(ph->AL, p->f_NL, d_phi, 0)) break;
+            if (zd::launch_any_lines(ph->tabN, d_phi, ph->AL.pitch, (long long) N * N, 0)) break;
+            if (zd::launch_any_cols(ph->tabN, d_phi, plane, ph->AL.pitch, (int) N, (int) N, -1, 0)) break;
+            if (zd::launch_any_cols(ph->tabN, d_phi, ph->AL.pitch, plane, (int) N, (int) (N / 2), -1, 0)) break;  // along z, rows ky < N/2
+            if (zd::launch_any_phik(ph->AL, d_phi, *d_phik, 0)) break;
+            if (hipDeviceSynchronize() != hipSuccess) break;
+            frc = 0;
+            break;
+        }
         int lN = 0;
         while ((1 << lN) < (int) N) lN++;
         if (zd::launch_fnl_stage(0, ph->S, p->f_NL, ph->d_twN, d_phi, nullptr, (int) N, lN, 0)) break;
@@ -507,10 +520,10 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
     int R = p->stream_factor > 0 ? p->stream_factor : 1;
     if (np2 && p->stream_factor <= 0) R = np2_R;
     if (any_path) {
-        if (N % 2 || N < 8 || N > 8192 || nranks != 1 || phi_mode != 0 || phik != nullptr || R < 1 || N % R || N / R < 3) {
+        if (N % 2 || N < 8 || N > 8192 || nranks != 1 || R < 1 || N % R || N / R < 3) {
             fprintf(stderr, "zeldovich_hip: PPD = %lld (neither 2^a nor a supported 2^a 3^b configuration) runs as convolutions on the "
-                            "power-of-two engine: even PPD in [8, 8192], one rank, no ZD_f_NL, ZD_StreamFactor any divisor of PPD "
-                            "(got %d)\n", (long long) N, R);
+                            "power-of-two engine: even PPD in [8, 8192], one rank, ZD_StreamFactor any divisor of PPD (got %d)\n",
+                    (long long) N, R);
             return 1;
         }
     } else if (!is_pow2(R) || N % R || N / R < 32 || N / R > 4096 || (np2 && !zd::np2_supported_zlen((int) (N / R)))) {

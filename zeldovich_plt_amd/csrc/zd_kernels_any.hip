@@ -10,9 +10,10 @@
 // i.e. two engine transforms and three pointwise products per line; the forward transform is conj o inverse o conj.  A
 // thread holds the same indices t + T e before and after an engine transform, so the pointwise steps need no exchange.
 // It is a compatibility path (about 6x the arithmetic of a native size and lines padded to M): reference arrays
-// (include/block_array.h:26-35: 1 / 2 / 4 complex arrays with Hermitian twins), one rank, every option but ZD_f_NL.
+// (include/block_array.h:26-35: 1 / 2 / 4 complex arrays with Hermitian twins), one rank, every option (ZD_f_NL: the phi
+// round's forward transform of a real field is the conjugate of its inverse transform, k_any_phi_nl / k_any_phik).
 // The pipeline is cut into simple pieces:
-//     generator (k_gen, zd_kernels.hip)  ->  Y[job][row][k2][x]
+//     generator (k_genf / k_gen, zd_kernels.hip)  ->  Y[job][row][k2][x]
 //     k_any_cols   in-place transform of strided lines: Y along k2 (z stage), the store along y (y stage)
 //     k_any_scatter  Y -> store rows ky / N - ky with the Hermitian twin rules of k_zfft
 //     k_any_lines  in-place transform of contiguous lines (x stage)
@@ -198,7 +199,37 @@ __global__ __launch_bounds__(256) void k_any_emit(AnyLayout A, EpiConst ec, cons
     xfft_reduce<256, NA>(scr, red, ssq, mp, mn);
 }
 
+// ZD_f_NL, phi round (zeldovich.cpp:699-790): phi(x) = Re of the inverse transform -> (phi + f_NL phi^2) / N^3, real
+//   grid: (ceil(N / 256), N, N)   block: 256        store [z][y][x], one array
+__global__ __launch_bounds__(256) void k_any_phi_nl(AnyLayout A, double f_NL, double inv_ppd3, cplx *__restrict__ store) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= A.N) return;
+    cplx *p = store + ((long long) blockIdx.z * A.N + blockIdx.y) * A.pitch + x;
+    const double phi = p->x;
+    *p = cplx{(phi + f_NL * phi * phi) * inv_ppd3, 0.0};
+}
+// the forward 3-D transform of a real field is the conjugate of its inverse transform: PhiK[ky][kz][x] = conj store[kz][ky][x]
+// for the half-space rows ky < N/2     grid: (ceil(N / 256), N, N / 2)   block: 256
+__global__ __launch_bounds__(256) void k_any_phik(AnyLayout A, const cplx *__restrict__ store, cplx *__restrict__ phik) {
+    const int x = blockIdx.x * 256 + threadIdx.x, kz = blockIdx.y, ky = blockIdx.z;
+    if (x >= A.N) return;
+    const cplx v = store[((long long) kz * A.N + ky) * A.pitch + x];
+    phik[((long long) ky * A.N + kz) * A.N + x] = cplx{v.x, -v.y};
+}
+
 namespace zd {
+
+int launch_any_phi_nl(const AnyLayout &A, double f_NL, void *store, hipStream_t st) {
+    const double inv = 1. / A.N / A.N / A.N;
+    hipLaunchKernelGGL(k_any_phi_nl, dim3((A.N + 255) / 256, A.N, A.N), dim3(256), 0, st, A, f_NL, inv, (cplx *) store);
+    ZD_LAUNCH_CHECK();
+    return 0;
+}
+int launch_any_phik(const AnyLayout &A, const void *store, void *phik, hipStream_t st) {
+    hipLaunchKernelGGL(k_any_phik, dim3((A.N + 255) / 256, A.N, A.N / 2), dim3(256), 0, st, A, (const cplx *) store, (cplx *) phik);
+    ZD_LAUNCH_CHECK();
+    return 0;
+}
 
 int any_engine_size(int n) {  // M = 2^m >= 2n - 1, at least 64
     int M = 64;

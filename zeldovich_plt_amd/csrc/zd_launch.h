@@ -65,6 +65,8 @@ int launch_any_lines(const AnyTab &tb, void *data, long long pitch, long long nl
 int launch_any_scatter(const JobList &jobs, const AnyLayout &A, int ky0, int nky, int L, const void *Y, void *store, hipStream_t st);
 int launch_any_emit(const AnyLayout &A, const EpiConst &ec, const void *store, int plane0, int nplanes, int z_first, int z_step, void *records,
                     float *density, Reduce *red, hipStream_t st);
+int launch_any_phi_nl(const AnyLayout &A, double f_NL, void *store, hipStream_t st);
+int launch_any_phik(const AnyLayout &A, const void *store, void *phik, hipStream_t st);
 // ---- ZD_Version = 1 streams (zd_kernels_v1.hip) ----
 int launch_v1_seed(unsigned long long seed, int block, V1Stream *streams, hipStream_t st);
 int launch_v1_draw(const GenConst &g, int block, int ky0, int ky_stride, int nrows, V1Stream *streams, void *dev, int *err,
