@@ -236,8 +236,6 @@ int any_engine_size(int n) {  // M = 2^m >= 2n - 1, at least 64
     while (M < 2 * n - 1) M *= 2;
     return M;
 }
-static int any_cols_width(int M) { return M <= 512 ? 16 : (M <= 2048 ? 8 : (M == 4096 ? 4 : (M == 8192 ? 2 : 1))); }
-static int any_lines_width(int M) { return M <= 4096 ? 4 : (M == 8192 ? 2 : 1); }
 
 template <int M, int W>
 static int launch_any_cols_t(const AnyTab &tb, void *data, long long batch_stride, long long point_stride, int ncols, int nbatch,
@@ -261,6 +259,7 @@ static int launch_any_lines_t(const AnyTab &tb, void *data, long long pitch, lon
     return 0;
 }
 
+// engine size, columns per workgroup (strided lines), lines per workgroup (contiguous lines)
 #define ANY_SIZES(X) X(64, 16, 4) X(128, 16, 4) X(256, 16, 4) X(512, 16, 4) X(1024, 8, 4) X(2048, 8, 4) X(4096, 4, 4) X(8192, 2, 2) X(16384, 1, 1)
 
 int launch_any_cols(const AnyTab &tb, void *data, long long batch_stride, long long point_stride, int ncols, int nbatch, int zero_point,
