@@ -235,6 +235,11 @@ int zd_test_modes(const zd_params *p, const zd_pk *pk, int64_t n, const int32_t 
 /* the same through the arithmetic the production generator k_genf uses (LDS-table ln / exp / sincos / spline segments,
  * integer zero rule, Newton reciprocal): out[3*i] = {Re D, Im D, fundamental / |k|^2}; ky >= 0 */
 int zd_test_modes_table(const zd_params *p, const zd_pk *pk, int64_t n, const int32_t *kxyz, double *out);
+/* zd_generate with p->ngpu ranks as threads on the visible GPU(s), running the RCCL branch of the exchange code (buffer
+ * offsets, grouped send / receive order, stream and event ordering) on an in-process emulation of the ncclSend / ncclRecv /
+ * ncclGroup calls — real RCCL refuses two ranks on one device, and test boxes have one */
+int zd_test_generate_loopback(const zd_params *p, const zd_pk *pk, const double *eig, int64_t eig_ppd, zd_slab_cb cb, void *user,
+                              zd_stats *out);
 /* ZD_Version = 1: the first 624 * nblocks words of gsl_rng_mt19937 seeded with `seed`, from the workgroup-parallel
  * regeneration the stream kernel uses (src/power_spectrum.cpp:18-25) */
 int zd_test_v1_words(int64_t seed, int32_t nblocks, uint32_t *out);

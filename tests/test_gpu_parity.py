@@ -96,6 +96,7 @@ def test_fft_lines(zd, n, kind):
 
 
 def _compare(zd, oracle, ps, opk, n, fmt="RVdoubleZel", eig=None, tie_ok=False, **kw):
+    loopback = kw.pop("loopback", False)  # tests: the RCCL branch on the in-process emulation (zd_test_generate_loopback)
     p = zd.make_params(n, icformat=fmt, **kw)
     okw = dict(kw)
     okw.pop("stream_factor", None)
@@ -105,7 +106,7 @@ def _compare(zd, oracle, ps, opk, n, fmt="RVdoubleZel", eig=None, tie_ok=False, 
     if "corner_modes" in okw:
         okw["CornerModes"] = okw.pop("corner_modes")
     op = oracle.make_params(n, numblock=okw.pop("numblock", 2), icformat=fmt, **okw)
-    got = zd.generate(p, ps, eig=eig)
+    got = zd.generate(p, ps, eig=eig, loopback=loopback)
     ref = oracle.run(op, opk, eig=eig, eig_ppd=0 if eig is None else eig.shape[0],
                      want_density=bool(kw.get("qdensity", 0)))
     if ref["records"] is not None:
@@ -568,6 +569,42 @@ def test_native_multi_gpu_driver(zd, oracle, ps, opk, ngpu, n, kw):
         assert abs(got["density_variance"] - ref["density_variance"]) <= TOL * ref["density_variance"]
         return
     got, _ = _compare(zd, oracle, ps, opk, n, fmt=fmt, eig=eig, ngpu=ngpu, **kw)
+    assert sorted(got["planes_seen"]) == list(range(n))
+
+
+@pytest.mark.parametrize("ngpu,n,kw", [
+    (2, 128, dict(stream_factor=2)),                                   # field store, one exchange group
+    (4, 128, dict(stream_factor=2, exchange_planes=3)),                # 16 planes per rank in groups of 3 (last: 1)
+    (2, 128, dict(store_mode="reference", exchange_planes=7, qdensity=1, fmt="RVZel")),
+    (4, 256, dict(stream_factor=4, k_cutoff=2.0, exchange_planes=5, plt=True)),
+    (8, 128, dict(stream_factor=2, exchange_planes=1)),                # eight ranks
+    (2, 192, dict(stream_factor=2, exchange_planes=5)),                # composite grid
+])
+def test_rccl_branch_on_the_loopback_emulation(zd, oracle, ps, opk, ngpu, n, kw):
+    """the RCCL branch of the plane-group exchange (grouped ncclSend / ncclRecv per group on the communication stream, event
+    ordering against the XY stages, ring-slot reuse) with the ranks as threads on this one GPU, on an in-process emulation of
+    the RCCL calls (zd_test_generate_loopback): real RCCL refuses two ranks on one device.  Result == oracle."""
+    kw = dict(kw)
+    fmt = kw.pop("fmt", "RVdoubleZel")
+    eig = None
+    if kw.pop("plt", False):
+        eig = oracle.synthetic_eigenmodes(32)
+        kw.update(qPLT=1, qPLTrescale=1, PLT_target_z=5.0, f_cluster=0.97)
+    got, _ = _compare(zd, oracle, ps, opk, n, fmt=fmt, eig=eig, ngpu=ngpu, loopback=True, **kw)
+    assert sorted(got["planes_seen"]) == list(range(n))
+
+
+def test_rccl_branch_fnl_round_trip_on_the_loopback_emulation(zd, oracle, ps, wmap_path):
+    """the phi round's forward and REVERSE plane-group exchange (zd_multi.cpp phi_round, RCCL branch) on the loopback emulation"""
+    import ctypes as C
+    n, fnl, ns, om = 128, 2.0e4, 0.96, 0.31
+    opk = oracle.pk_from_file(wmap_path, 720.0)
+    oracle.lib().zdo_pk_set_primordial(C.byref(opk), ns)
+    got = zd.generate(zd.make_params(n, icformat="RVdoubleZel", f_NL=fnl, n_s=ns, Omega_M=om, ngpu=4, stream_factor=2, exchange_planes=3),
+                      ps, loopback=True)
+    ref = oracle.run(oracle.make_params(n, numblock=2, icformat="RVdoubleZel", f_NL=fnl, n_s=ns, Omega_M=om), opk)
+    for f in ("d", "v"):
+        assert _rel(got["records"][f], ref["records"][f]) < TOL
     assert sorted(got["planes_seen"]) == list(range(n))
 
 

@@ -78,7 +78,7 @@ EXPORTED_SYMBOLS = [
     "zd_plan_plane_z", "zd_plan_stage_z", "zd_plan_stage_y", "zd_plan_stage_x", "zd_plan_stats", "zd_comm_unique_id", "zd_comm_create", "zd_comm_destroy", "zd_plan_ring_bytes", "zd_plan_run_pass",
     "zd_params_from_file", "zd_pk_create_from_file", "zd_pk_create_powerlaw", "zd_pk_power",
     "zd_pk_sigmaR", "zd_pk_destroy", "zd_load_eigmodes", "zd_free", "zd_test_draws", "zd_test_modes",
-    "zd_test_modes_table", "zd_test_v1_words", "zd_test_fft",
+    "zd_test_modes_table", "zd_test_v1_words", "zd_test_generate_loopback", "zd_test_fft",
 ]
 STORE_MODES = {"auto": 0, "reference": 1, "packed": 2, "fields": 3}  # zd_params.store_mode (ZD_STORE_*)
 
@@ -103,6 +103,7 @@ def load_library():
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     L.zd_generate.argtypes = [C.POINTER(ZdParams), C.POINTER(ZdPk), vp, i64, SLAB_CB, vp, C.POINTER(ZdStats)]
+    L.zd_test_generate_loopback.argtypes = L.zd_generate.argtypes
     L.zd_choose_stream_factor.argtypes = [C.POINTER(ZdParams), C.c_int, i64]
     L.zd_plan_create.argtypes = [C.POINTER(ZdParams), C.POINTER(ZdPk), vp, i64, C.c_int, C.c_int, C.POINTER(vp)]
     L.zd_plan_destroy.argtypes = [vp]
@@ -254,12 +255,15 @@ def _stats_dict(st):
                 modes_cached=bool(st.modes_cached))
 
 
-def generate(params, ps, eig=None, collect=True):
+def generate(params, ps, eig=None, collect=True, loopback=False):
     """ZeldovichZ + ZeldovichXY on cuda:0 through zd_generate.
 
     collect=True gathers every delivered plane (host callback, like WriteParticlesSlab) into
-    records[z, y, x] (and density[z, y, x] when qdensity); collect=False uses the NULL sink."""
+    records[z, y, x] (and density[z, y, x] when qdensity); collect=False uses the NULL sink.
+    loopback=True (tests; params.ngpu >= 2): zd_test_generate_loopback — the RCCL branch of the exchange on an in-process
+    emulation of its calls."""
     L = load_library()
+    entry = L.zd_test_generate_loopback if loopback else L.zd_generate
     n = int(params.ppd)
     st = ZdStats()
     eigp, eig_ppd = (None, 0)
@@ -282,12 +286,12 @@ def generate(params, ps, eig=None, collect=True):
             return 0
 
         cb = SLAB_CB(_cb)
-        rc = L.zd_generate(C.byref(params), C.byref(ps.pk), eigp, eig_ppd, cb, None, C.byref(st))
+        rc = entry(C.byref(params), C.byref(ps.pk), eigp, eig_ppd, cb, None, C.byref(st))
         out["records"] = None if rec is None else rec.reshape(n, n, n)
         out["density"] = None if dens is None else dens.reshape(n, n, n)
         out["planes_seen"] = seen
     else:
-        rc = L.zd_generate(C.byref(params), C.byref(ps.pk), eigp, eig_ppd, SLAB_CB(), None, C.byref(st))
+        rc = entry(C.byref(params), C.byref(ps.pk), eigp, eig_ppd, SLAB_CB(), None, C.byref(st))
     if rc:
         raise RuntimeError("zd_generate failed (rc=%d); see stderr" % rc)
     out.update(_stats_dict(st))

@@ -1604,6 +1604,12 @@ int zd_test_modes_table(const zd_params *p, const zd_pk *pk, int64_t n, const in
     return rc;
 }
 
+int zd_test_generate_loopback(const zd_params *p, const zd_pk *pk, const double *eig, int64_t eig_ppd, zd_slab_cb cb, void *user,
+                              zd_stats *out) {
+    if (p->ngpu < 2) return 1;
+    return zd_generate_multi(p, pk, eig, eig_ppd, cb, user, out, 2);
+}
+
 int zd_test_v1_words(int64_t seed, int32_t nblocks, uint32_t *out) {
     zd::V1Stream *d_s = nullptr;
     uint32_t *d_o = nullptr;

@@ -58,7 +58,9 @@ struct RcclApi {
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t)     = nullptr;
     const char *(*GetErrorString)(ncclResult_t)                                            = nullptr;
 };
+RcclApi *g_rccl_override = nullptr;  // test transport (loopback emulation below): stands in for librccl
 RcclApi *rccl() {
+    if (g_rccl_override) return g_rccl_override;
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
@@ -93,6 +95,98 @@ RcclApi *rccl() {
             return 1;                                                                                        \
         }                                                                                                    \
     } while (0)
+
+// ---- loopback emulation of the RCCL calls (tests only: zd_test_generate_loopback) --------------------------------------------
+// Lets the RCCL branch of the exchange code — buffer offsets, grouped send / receive order, stream and event ordering — run
+// with several ranks as threads on ONE GPU, where real RCCL refuses duplicate devices.  Semantics kept: Send / Recv inside a
+// group are matched per (source, destination) pair in posting order; data moves on the receiver's stream after the sender's
+// stream has reached the send; the sender's stream does not run past the group before its buffers have been read.
+struct LoopComm {
+    int rank = 0, n = 1;
+};
+struct LoopMsg {
+    const void *ptr;
+    size_t nb;
+    hipEvent_t ready, done;
+    bool has_done;
+};
+struct LoopState {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::vector<LoopMsg>> box;  // box[src * n + dst]: messages in posting order
+    std::vector<size_t> taken;              // next message the receiver takes
+    int n = 0;
+} g_loop;
+struct LoopOp {
+    bool send;
+    void *ptr;
+    size_t nb;
+    int peer;
+    hipStream_t st;
+};
+thread_local std::vector<LoopOp> t_loop_ops;
+thread_local LoopComm *t_loop_comm = nullptr;
+
+ncclResult_t loop_group_start() {
+    t_loop_ops.clear();
+    return ncclSuccess;
+}
+ncclResult_t loop_send(const void *p, size_t nb, ncclDataType_t, int peer, ncclComm_t c, hipStream_t st) {
+    t_loop_comm = reinterpret_cast<LoopComm *>(c);
+    t_loop_ops.push_back(LoopOp{true, const_cast<void *>(p), nb, peer, st});
+    return ncclSuccess;
+}
+ncclResult_t loop_recv(void *p, size_t nb, ncclDataType_t, int peer, ncclComm_t c, hipStream_t st) {
+    t_loop_comm = reinterpret_cast<LoopComm *>(c);
+    t_loop_ops.push_back(LoopOp{false, p, nb, peer, st});
+    return ncclSuccess;
+}
+ncclResult_t loop_group_end() {
+    if (t_loop_ops.empty()) return ncclSuccess;
+    const int me = t_loop_comm->rank, n = g_loop.n;
+    std::vector<std::pair<int, size_t>> mine;  // (peer, index) of the messages this group posted
+    {
+        std::lock_guard<std::mutex> lk(g_loop.mu);
+        for (const LoopOp &op : t_loop_ops)
+            if (op.send) {
+                LoopMsg m{op.ptr, op.nb, nullptr, nullptr, false};
+                if (hipEventCreateWithFlags(&m.ready, hipEventDisableTiming) != hipSuccess) return ncclInternalError;
+                if (hipEventRecord(m.ready, op.st) != hipSuccess) return ncclInternalError;
+                auto &q = g_loop.box[(size_t) me * n + op.peer];
+                q.push_back(m);
+                mine.emplace_back(op.peer, q.size() - 1);
+            }
+    }
+    g_loop.cv.notify_all();
+    for (const LoopOp &op : t_loop_ops)
+        if (!op.send) {
+            std::unique_lock<std::mutex> lk(g_loop.mu);
+            const size_t key = (size_t) op.peer * n + me;
+            // (bounded: a rank that failed never posts, and a test must not hang the box)
+            if (!g_loop.cv.wait_for(lk, std::chrono::seconds(30), [&] { return g_loop.box[key].size() > g_loop.taken[key]; }))
+                return ncclInternalError;
+            LoopMsg &m = g_loop.box[key][g_loop.taken[key]++];
+            if (m.nb != op.nb) return ncclInvalidArgument;
+            if (hipStreamWaitEvent(op.st, m.ready, 0) != hipSuccess) return ncclInternalError;
+            if (hipMemcpyAsync(op.ptr, m.ptr, op.nb, hipMemcpyDeviceToDevice, op.st) != hipSuccess) return ncclInternalError;
+            if (hipEventCreateWithFlags(&m.done, hipEventDisableTiming) != hipSuccess) return ncclInternalError;
+            if (hipEventRecord(m.done, op.st) != hipSuccess) return ncclInternalError;
+            m.has_done = true;
+            lk.unlock();
+            g_loop.cv.notify_all();
+        }
+    hipStream_t st = t_loop_ops[0].st;
+    for (auto &pi : mine) {  // the send buffers may be reused only after the receivers have read them
+        std::unique_lock<std::mutex> lk(g_loop.mu);
+        const size_t key = (size_t) me * n + pi.first;
+        if (!g_loop.cv.wait_for(lk, std::chrono::seconds(30), [&] { return g_loop.box[key][pi.second].has_done; })) return ncclInternalError;
+        if (hipStreamWaitEvent(st, g_loop.box[key][pi.second].done, 0) != hipSuccess) return ncclInternalError;
+    }
+    t_loop_ops.clear();
+    return ncclSuccess;
+}
+const char *loop_error_string(ncclResult_t) { return "loopback transport"; }
+RcclApi g_loop_api;
 
 // in-process rendezvous of the local transport
 struct LocalGroup {
@@ -520,7 +614,25 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
     std::vector<RankCtx> ctx(G);
     LocalGroup grp;
     std::vector<ncclComm_t> nccls(G, nullptr);
-    if (transport == 1) {
+    std::vector<LoopComm> loops(G);
+    if (transport == 2) {  // tests: the RCCL branch of the exchange on an in-process emulation of its calls
+        g_loop.n = G;
+        g_loop.box.assign((size_t) G * G, {});
+        g_loop.taken.assign((size_t) G * G, 0);
+        g_loop_api             = RcclApi{};
+        g_loop_api.h           = &g_loop_api;
+        g_loop_api.GroupStart  = loop_group_start;
+        g_loop_api.GroupEnd    = loop_group_end;
+        g_loop_api.Send        = loop_send;
+        g_loop_api.Recv        = loop_recv;
+        g_loop_api.GetErrorString = loop_error_string;
+        g_rccl_override        = &g_loop_api;
+        for (int g = 0; g < G; g++) {
+            loops[g].rank = g;
+            loops[g].n    = G;
+            nccls[g]      = reinterpret_cast<ncclComm_t>(&loops[g]);
+        }
+    } else if (transport == 1) {
         grp.n = G;
         grp.send_base.assign(G, nullptr);
         grp.ring_base.assign(G, nullptr);
@@ -557,7 +669,7 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
                 if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
                 c->rank   = g;
                 c->nranks = G;
-                c->kind   = transport;
+                c->kind   = transport == 2 ? 0 : transport;  // the loopback emulation runs the RCCL branch
                 c->nccl   = nccls[g];
                 c->grp    = &grp;
                 if (comm_prepare(c)) break;
@@ -624,7 +736,15 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
         });
     }
     for (auto &t : threads) t.join();
-    if (transport != 1)
+    if (transport == 2) {
+        g_rccl_override = nullptr;
+        for (auto &q : g_loop.box)
+            for (LoopMsg &m : q) {
+                if (m.ready) hipEventDestroy(m.ready);
+                if (m.done) hipEventDestroy(m.done);
+            }
+        g_loop.box.clear();
+    } else if (transport != 1)
         for (int g = 0; g < G; g++)
             if (nccls[g] && rccl()->CommDestroy) rccl()->CommDestroy(nccls[g]);
     int rc = 0;
