@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--format", default="RVZel")
     ap.add_argument("--stream", type=int, default=0, help="z-residue stream factor R (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist", action="store_true",
+                    help="take the N > 1 code path (torch.distributed RCCL group, zd.Comm id broadcast, per-rank gathers) whatever "
+                         "the world size: rehearses it on one GPU under torch.distributed.run --nproc-per-node 1")
     args = ap.parse_args()
 
     import torch
@@ -114,7 +117,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    multi = world > 1 or args.dist  # the N > 1 code path
+    if multi:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -133,7 +137,7 @@ def main():
     R = args.stream
     if R <= 0:
         budget = int(free_b) - (16 << 30)  # tables, ~3 GB of folded-input slabs, 8 GB record ring, runtime
-        if world > 1:  # every rank must arrive at the same R: use the smallest budget of the job
+        if multi:  # every rank must arrive at the same R: use the smallest budget of the job
             t = torch.tensor([budget], dtype=torch.int64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             budget = int(t.item())
@@ -145,7 +149,7 @@ def main():
     plan = zd.Plan(p, ps, eig=eig, rank=rank, nranks=world)
     from zeldovich_plt_amd.parallel import HipEngine, SlabPipeline
     comm = None
-    if world > 1:  # the library's own RCCL communicator; torch.distributed only carries the 128-byte id and the timing fences
+    if multi:  # the library's own RCCL communicator; torch.distributed only carries the 128-byte id and the timing fences
         def exchange_id(raw):
             t = torch.tensor(list(raw), dtype=torch.uint8, device="cuda")
             dist.broadcast(t, 0)
@@ -160,7 +164,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -173,11 +177,23 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    st = plan.stats()
+    per_rank = None
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        # what every rank did in the timed region, so that a scaling curve can be read: Z stage, time the compute stream
+        # stood waiting for exchanged planes, XY stages (hipEvent spans on the launch stream), bytes sent to peers
+        mine = torch.tensor([dt, st["kernel_ms"]["z_stage"], st["kernel_ms"]["exchange_wait"], st["kernel_ms"]["k_yfft"],
+                             st["kernel_ms"]["k_xfft"], float(st["bytes_sent"])], dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
         dt = float(t.item())
-    st = plan.stats()
+        per_rank = [{"rank": i, "wall_ms_per_step": float(v[0]) / args.steps * 1e3, "z_stage_ms": float(v[1]) / args.steps,
+                     "exchange_wait_ms": float(v[2]) / args.steps, "y_ms": float(v[3]) / args.steps,
+                     "x_ms": float(v[4]) / args.steps, "GB_sent_per_step": float(v[5]) / args.steps / 1e9,
+                     "send_GBps_while_waiting_or_computing": (float(v[5]) / 1e9) / max(float(v[0]), 1e-9)}
+                    for i, v in enumerate(allr)]
 
     # one extra UNTIMED pass with the two-stream overlap of the Z stage switched off: every kernel alone on the chip
     # (in the timed region k_gen and k_zfft share it, so their hipEvent spans there include each other)
@@ -273,6 +289,11 @@ def main():
             "kernels": per_kernel,
             "kernels_isolated": isolated,
         }
+        if per_rank is not None:
+            out["per_rank"] = per_rank
+            out["exchange"] = {"transport": "RCCL grouped ncclSend/ncclRecv per plane group (zd_plan_run_pass)",
+                               "GB_per_step_all_ranks": sum(r["GB_sent_per_step"] for r in per_rank),
+                               "max_exchange_wait_ms": max(r["exchange_wait_ms"] for r in per_rank)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(N, plt, fmt, eig)
@@ -283,7 +304,7 @@ def main():
     plan.close()
     if comm is not None:
         comm.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -92,7 +92,8 @@ typedef struct zd_pk {
 enum { ZD_K_GEN = 0, ZD_K_ZFFT = 1, ZD_K_YFFT = 2, ZD_K_XFFT = 3,
        ZD_K_ZSTAGE = 4, /* the Z stage as one unit: first generator launch .. last z FFT of a pass (the two kernels overlap
                          * on two streams, so their own spans include each other) */
-       ZD_K_COUNT = 5 };
+       ZD_K_XWAIT = 5,  /* N > 1 ranks: time the compute stream stood waiting for an exchanged plane group to arrive */
+       ZD_K_COUNT = 6 };
 
 typedef struct zd_stats {
     double max_disp[3];      /* output.cpp:28: signed value of the largest |displacement| per axis (x,y,z) */
@@ -103,6 +104,8 @@ typedef struct zd_stats {
     int64_t bytes_intermediate; /* size of the z-FFT'd block store held in HBM per residue pass */
     int32_t stream_factor;      /* R actually used */
     int32_t modes_cached;       /* 1 if the Gaussian mode amplitudes were kept in HBM across passes */
+    int64_t bytes_sent;         /* N > 1 ranks: bytes sent to OTHER ranks since the last zd_plan_stats / by this zd_generate call
+                                 * (zd_generate: summed over the ranks) */
 } zd_stats;
 
 /* Replacement for the per-plane callback WriteParticlesSlab (src/output.cpp:41-234).
@@ -181,6 +184,14 @@ typedef struct zd_comm zd_comm;
 int zd_comm_unique_id(void *id128);  /* rank 0: 128-byte RCCL id, to be made known to all ranks by the launcher */
 int zd_comm_create(int rank, int nranks, const void *id128, zd_comm **out); /* ncclCommInitRank on the current device */
 void zd_comm_destroy(zd_comm *comm);
+/* A rank that cannot go on (failed allocation, consumer error, ...) calls this before returning its error: ncclCommAbort on
+ * its communicator, so that the send / receive kernels it has already queued drain instead of spinning on peers for ever.
+ * zd_plan_run_pass does it by itself on every failure path; the launcher is expected to stop the other ranks when one
+ * process exits non-zero (torch.distributed.run does). */
+void zd_comm_abort(zd_comm *comm);
+/* bytes this rank has sent to / received from other ranks since the communicator was created (or since the last call with
+ * reset != 0) */
+void zd_comm_traffic(zd_comm *comm, int64_t *bytes_sent, int64_t *bytes_received, int reset);
 /* bytes of the two-slot receive ring zd_plan_run_pass allocates (0 for one rank) and the planes per exchange group */
 int64_t zd_plan_ring_bytes(const zd_plan *plan, int32_t *group_planes);
 /* consumer of finished planes: `nplanes` delivered planes starting at local plane `first_local_plane` of the pass lie
@@ -227,25 +238,6 @@ void zd_pk_destroy(zd_pk_handle *h);
 int zd_load_eigmodes(const char *path, double **eig, int64_t *eig_ppd);
 void zd_free(void *p);
 
-/* ---- device test hooks (used by tests/ and bench.py only; each needs a GPU) -------------------- */
-/* n counter-addressed draws: out[2*i], out[2*i+1] = the two uint64 of mode (kx,ky,kz)[i] */
-int zd_test_draws(int64_t seed, int64_t n, const int32_t *kxyz, uint64_t *out);
-/* Gaussian amplitudes D(k) for the same mode list (cgauss<2>, src/power_spectrum.cpp:338-359) */
-int zd_test_modes(const zd_params *p, const zd_pk *pk, int64_t n, const int32_t *kxyz, double *D);
-/* the same through the arithmetic the production generator k_genf uses (LDS-table ln / exp / sincos / spline segments,
- * integer zero rule, Newton reciprocal): out[3*i] = {Re D, Im D, fundamental / |k|^2}; ky >= 0 */
-int zd_test_modes_table(const zd_params *p, const zd_pk *pk, int64_t n, const int32_t *kxyz, double *out);
-/* zd_generate with p->ngpu ranks as threads on the visible GPU(s), running the RCCL branch of the exchange code (buffer
- * offsets, grouped send / receive order, stream and event ordering) on an in-process emulation of the ncclSend / ncclRecv /
- * ncclGroup calls — real RCCL refuses two ranks on one device, and test boxes have one */
-int zd_test_generate_loopback(const zd_params *p, const zd_pk *pk, const double *eig, int64_t eig_ppd, zd_slab_cb cb, void *user,
-                              zd_stats *out);
-/* ZD_Version = 1: the first 624 * nblocks words of gsl_rng_mt19937 seeded with `seed`, from the workgroup-parallel
- * regeneration the stream kernel uses (src/power_spectrum.cpp:18-25) */
-int zd_test_v1_words(int64_t seed, int32_t nblocks, uint32_t *out);
-/* batch of `lines` independent length-n inverse FFTs, host in/out [lines][n] complex double;
- * axis_kind 0: the contiguous-line kernel path (x pass), 1: the strided-line path (y/z passes) */
-int zd_test_fft(int32_t n, int64_t lines, int32_t axis_kind, const double *in, double *out);
 #ifdef __cplusplus
 }
 #endif

@@ -65,6 +65,23 @@ def test_product_library_has_no_tuning_switches():
     assert "getenv" not in subprocess.check_output(["nm", "-D", "--undefined-only", api.LIB_PATH], text=True)
 
 
+def test_product_library_has_no_test_scaffolding():
+    """the device test hooks (zd_test_*), the test kernels and the in-process emulation of the RCCL calls exist only in the
+    -DZD_TESTING build (csrc/zd_testing.h, `make testing`), which exports every one of them"""
+    import subprocess
+    import zeldovich_plt_amd.api as api
+    for args in (["nm", "-D", "--defined-only"], ["nm", "--defined-only"]):
+        syms = subprocess.run(args + [api.LIB_PATH], capture_output=True, text=True).stdout
+        for name in ("zd_test_", "k_test_", "g_rccl_override", "loop_group_end", "g_loop"):
+            assert name not in syms, name
+    blob = open(api.LIB_PATH, "rb").read()
+    assert b"k_test_" not in blob and b"loopback transport" not in blob
+    if os.path.exists(api.TESTING_LIB_PATH):
+        tsyms = subprocess.check_output(["nm", "-D", "--defined-only", api.TESTING_LIB_PATH], text=True)
+        for name in api.TESTING_SYMBOLS + api.EXPORTED_SYMBOLS:
+            assert name in tsyms, name
+
+
 def test_trans_hazard_checker_detects_back_to_back_use():
     """check_trans_hazard.py (run on the shipped ISA by build()): flags a TRANS result read in the next issue slot,
     accepts an intervening instruction or s_nop"""

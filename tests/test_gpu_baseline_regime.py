@@ -157,12 +157,16 @@ def _planes(zd, ps, n, zs, stride=1, eig=None, fmt="Zeldovich", **kw):
     return res, info
 
 
-@pytest.mark.parametrize("n", [2048, 4096, 3456, 1000])
+@pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096, 3456, 1000])
 def test_oversampled_planes_exact_at_full_size(zd, n):
     """PPD = 2n, ZD_k_cutoff = 2 at even lattice sites == PPD = n, ZD_k_cutoff = 1 (8192 <-> 4096: BASELINE C5 / C4,
     4096 <-> 2048: C3 size; 6912 <-> 3456: the production Abacus size 6912 = 2^8 3^3 on the composite-transform kernels;
     2000 <-> 1000: the any-PPD convolution kernels, zd_kernels_any.hip),
-    records compared exactly (1e-13 of the field maximum) on planes of three different passes"""
+    records compared exactly (1e-13 of the field maximum) on planes of three different passes.
+    The links 2048 <-> 1024 <-> 512 <-> 256 close the chain: PPD = 512 and 256 are compared with the ORACLE record by record
+    on the same default store (test_ppd512_za_default_store_vs_oracle, test_za_extrapolated_pk_vs_oracle), so every BASELINE
+    size is tied to an oracle-checked run through exact links of HIP runs at different sizes (different z / y / x kernels
+    and stream factors at each size)"""
     ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
     zs = [5, n // 2 + 3, n - 2]
     lo, ilo = _planes(zd, ps, n, zs)
@@ -197,6 +201,7 @@ def test_ppd16384_k_cutoff4_planes_equal_ppd4096(zd):
 
 
 @pytest.mark.parametrize("n,kc,Ra,Rb,modes", [
+    (2048, 1.0, 2, 4, [(3, 5, -7), (-601, 577, 800), (0, 2, 0)]),        # BASELINE C3: packed PLT arrays (k_genf PLTN / k_zfft / k_yfft / k_xfft)
     (8192, 2.0, 64, 128, [(3, 5, -7), (-1001, 777, 1200), (0, 2, 0)]),   # k_xfft_two<8192, PLT>
     (6912, 4.0, 8, 16, [(3, 5, -7), (-401, 377, 500)]),                  # composite kernels, x pass in two launches
     (3456, 2.0, 4, 8, [(-3, 5, 7), (401, 377, -500)]),                   # composite kernels, three lines per workgroup
@@ -249,22 +254,37 @@ def test_large_plt_plane_waves_and_stream_invariance(zd, oracle, n, kc, Ra, Rb, 
         assert np.abs(a[z][f_] - b[z][f_]).max() <= 1e-12 * np.abs(a[z][f_]).max()
 
 
-def test_ppd6912_on_one_gpu_plane_waves(zd, oracle):
-    """PPD = 6912 = 2^8 3^3 at ZD_k_cutoff = 1 — the production Abacus grid — on ONE GPU: R = 64, z lines of 108 = 4 * 27.
+def test_ppd512_za_default_store_vs_oracle(zd, oracle):
+    """PPD = 512 ZA on the DEFAULT store (field store, two z-residues per pass) against the oracle: 1.3e8 particles, every
+    record — the anchor of the oversampling chain 8192 <-> 4096 <-> 2048 <-> 1024 <-> 512 (test_oversampled_planes_exact_at_full_size)"""
+    ps, opk = _pair(zd, oracle, 720.0)
+    got, _ = _compare(zd, oracle, ps, opk, 512)
+    assert got["stream_factor"] >= 2  # the field store carries two residues per pass
+
+
+@pytest.mark.parametrize("n,R,modes", [
+    (6912, 64, [(-2001, 1777, 1200), (5, 3, -7)]),
+    (4096, 8, [(-1001, 1177, 1200), (5, 3, -7), (0, 2, 0)]),   # the bench workload: k_genf / k_zfft_f<512> / k_yfft_f<4096> / k_xfft<4096,16,3,1>
+])
+def test_ppd6912_on_one_gpu_plane_waves(zd, oracle, n, R, modes):
+    """PPD = 6912 = 2^8 3^3 at ZD_k_cutoff = 1 — the production Abacus grid — on ONE GPU: R = 64, z lines of 108 = 4 * 27;
+    and PPD = 4096 at ZD_k_cutoff = 1 (the headline workload, R = 8) through the general one-mode generator + the
+    production z / y / x kernels.
     One-mode runs against the closed form q_j(x) = -2 (k_j fund / k^2) (Re D sin t + Im D cos t), v = vnorm q, with D(k) from
-    the oracle's per-mode draw; the random-field path of these kernels is covered at PPD = 864 / 1728
-    (test_non_power_of_two_short_z_lines) and by 6912 (k_cutoff = 2) <-> 3456."""
+    the oracle's per-mode draw (one mode of each list lies beyond the last tabulated k = 5.13 h/Mpc = 588 fundamentals); the
+    random-field path of the composite kernels is covered at PPD = 864 / 1728 (test_non_power_of_two_short_z_lines) and by
+    6912 (k_cutoff = 2) <-> 3456."""
     ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
     opk = oracle.pk_from_file(WMAP, 720.0)
-    n, z, fc = 6912, 3461, 0.9
+    z, fc = n // 2 + 5, 0.9
     op = oracle.make_params(n, f_cluster=fc)
     L = oracle.lib()
     fund = 2 * np.pi / 720.0
     vnorm = (np.sqrt(1 + 24 * fc) - 1) / 4
     yy, xx = np.meshgrid(np.arange(0, n, 16), np.arange(0, n, 16), indexing="ij")
-    for mode in [(-2001, 1777, 1200), (5, 3, -7)]:
+    for mode in modes:
         got, info = _planes(zd, ps, n, [z], stride=16, fmt="RVdoubleZel", f_cluster=fc, qonemode=1, one_mode=mode)
-        assert info["R"] == 64
+        assert info["R"] == R
         r, D = (C.c_uint64 * 2)(), (C.c_double * 2)()
         L.zdo_mode_draw(C.byref(op), C.byref(opk), mode[0], mode[1], mode[2], r, D)
         k2 = sum(m * m for m in mode) * fund * fund
@@ -309,7 +329,7 @@ def test_plain_fma_build_passes_the_parity_suite():
     lib = os.path.join(ROOT, "zeldovich_plt_amd", "csrc", "build", "libzeldovich_hip_nofma.so")
     if not os.path.exists(lib):
         pytest.skip("nofma variant not built (make -C zeldovich_plt_amd/csrc nofma)")
-    env = dict(os.environ, ZD_LIB_PATH=lib)
+    env = dict(os.environ, ZD_LIB_PATH=lib, ZD_TESTING_LIB_PATH=lib)  # (the variant carries the test hooks too)
     sel = "test_za_extrapolated_pk_vs_oracle or test_plt_rescale_extrapolated_pk_vs_oracle or test_table_generator_arithmetic_vs_oracle"
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k", sel],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)

@@ -21,7 +21,7 @@ RECORD_DTYPES = {
     "RVdoubleZel": np.dtype([("ijk", "<u2", 3), ("pad", "<u2"), ("d", "<f8", 3), ("v", "<f8", 3)]),
     "ZelSimple": np.dtype([("d", "<f4", 3)]),
 }
-KERNEL_NAMES = ("k_gen", "k_zfft", "k_yfft", "k_xfft", "z_stage")
+KERNEL_NAMES = ("k_gen", "k_zfft", "k_yfft", "k_xfft", "z_stage", "exchange_wait")
 
 
 class ZdParams(C.Structure):
@@ -51,8 +51,9 @@ class ZdPk(C.Structure):
 class ZdStats(C.Structure):
     _fields_ = [
         ("max_disp", C.c_double * 3), ("density_variance", C.c_double), ("seconds_total", C.c_double),
-        ("kernel_ms", C.c_double * 5), ("kernel_launches", C.c_int64 * 5),
+        ("kernel_ms", C.c_double * 6), ("kernel_launches", C.c_int64 * 6),
         ("bytes_intermediate", C.c_int64), ("stream_factor", C.c_int32), ("modes_cached", C.c_int32),
+        ("bytes_sent", C.c_int64),
     ]
 
 
@@ -77,33 +78,56 @@ EXPORTED_SYMBOLS = [
     "zd_plan_stream_factor", "zd_plan_passes", "zd_plan_plane_step", "zd_plan_record_size", "zd_plan_exchange_bytes", "zd_plan_local_planes",
     "zd_plan_plane_z", "zd_plan_stage_z", "zd_plan_stage_y", "zd_plan_stage_x", "zd_plan_stats", "zd_comm_unique_id", "zd_comm_create", "zd_comm_destroy", "zd_plan_ring_bytes", "zd_plan_run_pass",
     "zd_params_from_file", "zd_pk_create_from_file", "zd_pk_create_powerlaw", "zd_pk_power",
-    "zd_pk_sigmaR", "zd_pk_destroy", "zd_load_eigmodes", "zd_free", "zd_test_draws", "zd_test_modes",
-    "zd_test_modes_table", "zd_test_v1_words", "zd_test_generate_loopback", "zd_test_fft",
+    "zd_pk_sigmaR", "zd_pk_destroy", "zd_load_eigmodes", "zd_free", "zd_comm_abort", "zd_comm_traffic",
 ]
+# test scaffolding: exists only in the -DZD_TESTING library (csrc/zd_testing.h, `make testing`), never in the product
+TESTING_SYMBOLS = ["zd_test_draws", "zd_test_modes", "zd_test_modes_table", "zd_test_v1_words", "zd_test_generate_loopback",
+                   "zd_test_fft"]
 STORE_MODES = {"auto": 0, "reference": 1, "packed": 2, "fields": 3}  # zd_params.store_mode (ZD_STORE_*)
 
 _lib = None
+_testing_lib = None
+TESTING_LIB_PATH = os.environ.get("ZD_TESTING_LIB_PATH") or os.path.join(_HERE, "csrc", "build", "libzeldovich_hip_testing.so")
 
 
 def load_library():
     """Load libzeldovich_hip.so; raises (never falls back) when it has not been built."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    if _lib is None:
+        _lib = _load(LIB_PATH, testing=False)
+    return _lib
+
+
+def load_testing_library():
+    """The -DZD_TESTING build of the same sources: the product plus the device test hooks (zd_test_*) and the in-process
+    emulation of the RCCL calls.  Only tests/ use it."""
+    global _testing_lib
+    if _testing_lib is None:
+        _testing_lib = _load(TESTING_LIB_PATH, testing=True)
+    return _testing_lib
+
+
+def _load(path, testing):
+    if not os.path.exists(path):
         raise RuntimeError(
             "zeldovich_plt_amd: %s is missing — run `python -c 'import __graft_entry__ as g; g.build()'` "
-            "or `make -C zeldovich_plt_amd/csrc`; there is no CPU fallback." % LIB_PATH)
+            "or `make -C zeldovich_plt_amd/csrc%s`; there is no CPU fallback." % (path, " testing" if testing else ""))
     try:
         # torch bundles its own HIP runtime; it must be the first one initialised in the process,
         # otherwise torch later reports "No HIP GPUs are available" (measured on the MI355X box)
         import torch  # noqa: F401
     except ImportError:
         pass
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     L.zd_generate.argtypes = [C.POINTER(ZdParams), C.POINTER(ZdPk), vp, i64, SLAB_CB, vp, C.POINTER(ZdStats)]
-    L.zd_test_generate_loopback.argtypes = L.zd_generate.argtypes
+    if testing:
+        L.zd_test_generate_loopback.argtypes = L.zd_generate.argtypes
+        L.zd_test_draws.argtypes = [i64, i64, vp, vp]
+        L.zd_test_modes.argtypes = [C.POINTER(ZdParams), C.POINTER(ZdPk), i64, vp, vp]
+        L.zd_test_modes_table.argtypes = [C.POINTER(ZdParams), C.POINTER(ZdPk), i64, vp, vp]
+        L.zd_test_v1_words.argtypes = [i64, C.c_int32, vp]
+        L.zd_test_fft.argtypes = [i32, i64, i32, vp, vp]
     L.zd_choose_stream_factor.argtypes = [C.POINTER(ZdParams), C.c_int, i64]
     L.zd_plan_create.argtypes = [C.POINTER(ZdParams), C.POINTER(ZdPk), vp, i64, C.c_int, C.c_int, C.POINTER(vp)]
     L.zd_plan_destroy.argtypes = [vp]
@@ -124,6 +148,10 @@ def load_library():
     L.zd_comm_create.argtypes = [C.c_int, C.c_int, vp, C.POINTER(vp)]
     L.zd_comm_destroy.argtypes = [vp]
     L.zd_comm_destroy.restype = None
+    L.zd_comm_abort.argtypes = [vp]
+    L.zd_comm_abort.restype = None
+    L.zd_comm_traffic.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.c_int]
+    L.zd_comm_traffic.restype = None
     L.zd_plan_ring_bytes.argtypes = [vp, C.POINTER(i32)]
     L.zd_plan_ring_bytes.restype = i64
     L.zd_plan_run_pass.argtypes = [vp, vp, C.c_int, vp, vp, i64, GROUP_CB, vp, vp]
@@ -139,11 +167,6 @@ def load_library():
     L.zd_load_eigmodes.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(i64)]
     L.zd_free.argtypes = [vp]
     L.zd_free.restype = None
-    L.zd_test_draws.argtypes = [i64, i64, vp, vp]
-    L.zd_test_modes.argtypes = [C.POINTER(ZdParams), C.POINTER(ZdPk), i64, vp, vp]
-    L.zd_test_modes_table.argtypes = [C.POINTER(ZdParams), C.POINTER(ZdPk), i64, vp, vp]
-    L.zd_test_v1_words.argtypes = [i64, C.c_int32, vp]
-    L.zd_test_fft.argtypes = [i32, i64, i32, vp, vp]
     _lib = L
     return L
 
@@ -252,7 +275,7 @@ def _stats_dict(st):
                 seconds_total=st.seconds_total, kernel_ms=dict(zip(KERNEL_NAMES, list(st.kernel_ms))),
                 kernel_launches=dict(zip(KERNEL_NAMES, list(st.kernel_launches))),
                 bytes_intermediate=st.bytes_intermediate, stream_factor=st.stream_factor,
-                modes_cached=bool(st.modes_cached))
+                modes_cached=bool(st.modes_cached), bytes_sent=st.bytes_sent)
 
 
 def generate(params, ps, eig=None, collect=True, loopback=False):
@@ -262,7 +285,7 @@ def generate(params, ps, eig=None, collect=True, loopback=False):
     records[z, y, x] (and density[z, y, x] when qdensity); collect=False uses the NULL sink.
     loopback=True (tests; params.ngpu >= 2): zd_test_generate_loopback — the RCCL branch of the exchange on an in-process
     emulation of its calls."""
-    L = load_library()
+    L = load_testing_library() if loopback else load_library()
     entry = L.zd_test_generate_loopback if loopback else L.zd_generate
     n = int(params.ppd)
     st = ZdStats()
@@ -315,7 +338,7 @@ def generate_planes(params, ps, on_plane, eig=None):
         count[0] += 1
         if recp:
             buf = (C.c_char * (nrec * dt.itemsize)).from_address(recp)
-            on_plane(int(z), np.frombuffer(buf, dtype=dt).reshape(n, n))
+            return int(on_plane(int(z), np.frombuffer(buf, dtype=dt).reshape(n, n)) or 0)  # non-zero aborts (WriteParticlesSlab failing)
         return 0
 
     cb = SLAB_CB(_cb)
@@ -409,15 +432,25 @@ class Comm:
             raise RuntimeError("zd_comm_create failed")
         self.h = h
 
+    def traffic(self, reset=False):
+        """(bytes sent to, bytes received from) other ranks"""
+        a, b = C.c_int64(), C.c_int64()
+        self.L.zd_comm_traffic(self.h, C.byref(a), C.byref(b), int(reset))
+        return a.value, b.value
+
+    def abort(self):
+        if self.h:
+            self.L.zd_comm_abort(self.h)
+
     def close(self):
         if self.h:
             self.L.zd_comm_destroy(self.h)
             self.h = None
 
 
-# ---- device test hooks ---------------------------------------------------------------------------
+# ---- device test hooks (the -DZD_TESTING library) ---------------------------------------------------------------------------
 def test_draws(seed, kxyz):
-    L = load_library()
+    L = load_testing_library()
     k = np.ascontiguousarray(kxyz, dtype=np.int32).reshape(-1, 3)
     out = np.zeros((k.shape[0], 2), dtype=np.uint64)
     if L.zd_test_draws(int(seed), k.shape[0], k.ctypes.data, out.ctypes.data):
@@ -426,7 +459,7 @@ def test_draws(seed, kxyz):
 
 
 def test_modes(params, ps, kxyz):
-    L = load_library()
+    L = load_testing_library()
     k = np.ascontiguousarray(kxyz, dtype=np.int32).reshape(-1, 3)
     out = np.zeros((k.shape[0], 2), dtype=np.float64)
     if L.zd_test_modes(C.byref(params), C.byref(ps.pk), k.shape[0], k.ctypes.data, out.ctypes.data):
@@ -436,7 +469,7 @@ def test_modes(params, ps, kxyz):
 
 def test_modes_table(params, ps, kxyz):
     """D(k) and fundamental/k^2 through k_genf's table arithmetic; returns (complex D [n], float64 [n])"""
-    L = load_library()
+    L = load_testing_library()
     k = np.ascontiguousarray(kxyz, dtype=np.int32).reshape(-1, 3)
     out = np.zeros((k.shape[0], 3), dtype=np.float64)
     if L.zd_test_modes_table(C.byref(params), C.byref(ps.pk), k.shape[0], k.ctypes.data, out.ctypes.data):
@@ -446,7 +479,7 @@ def test_modes_table(params, ps, kxyz):
 
 def test_v1_words(seed, nblocks):
     """first 624 * nblocks words of the ZD_Version = 1 stream generator (gsl_rng_mt19937) for `seed`"""
-    L = load_library()
+    L = load_testing_library()
     out = np.zeros(624 * nblocks, dtype=np.uint32)
     if L.zd_test_v1_words(int(seed), int(nblocks), out.ctypes.data):
         raise RuntimeError("zd_test_v1_words failed")
@@ -455,7 +488,7 @@ def test_v1_words(seed, nblocks):
 
 def test_fft(x, axis_kind):
     """x: complex128 [lines, n]; returns the unnormalised inverse DFT of every line computed on the GPU."""
-    L = load_library()
+    L = load_testing_library()
     x = np.ascontiguousarray(x, dtype=np.complex128)
     lines, n = x.shape
     if axis_kind == 1:  # strided situation: device layout [n][lines]

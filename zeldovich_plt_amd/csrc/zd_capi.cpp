@@ -21,6 +21,9 @@
 #ifdef ZD_TUNING
 #include "zd_tuning.h"
 #endif
+#ifdef ZD_TESTING
+#include "zd_testing.h"
+#endif
 
 using zdfft::cplx;
 using zdpcg::u128;
@@ -663,12 +666,12 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         PLCHECK(hipMalloc((void **) &pl->d_rowstate, sizeof(u128) * rows.size()));
         PLCHECK(hipMemcpy(pl->d_rowstate, rows.data(), sizeof(u128) * rows.size(), hipMemcpyHostToDevice));
         g.row_state = pl->d_rowstate;
-        static zdpcg::BitTable bt;
-        static bool bt_ready = false;
-        if (!bt_ready) {
-            zdpcg::make_bit_table(bt);
-            bt_ready = true;
-        }
+        // (built once; ZD_NumGPU creates its plans from several host threads at a time)
+        static const zdpcg::BitTable bt = [] {
+            zdpcg::BitTable b;
+            zdpcg::make_bit_table(b);
+            return b;
+        }();
         if (zdk_upload_bit_table(&bt) != 0) {
             fprintf(stderr, "zeldovich_hip: uploading the RNG jump table failed\n");
             zd_plan_destroy(pl);
@@ -1258,6 +1261,8 @@ int zd_plan_stage_x(zd_plan *pl, int residue, const void *d_recv, int64_t plane0
     return zd_plan_stage_x_group(pl, residue, d_recv, pl->Zq, plane0, plane0, nplanes, d_records, d_density, hip_stream);
 }
 
+void zd_plan_tick(zd_plan *pl, int kind, void *hip_stream, int begin) { tick(pl, kind, (hipStream_t) hip_stream, begin != 0); }
+
 int zd_plan_stats(zd_plan *pl, zd_stats *out) {
     HIPCHECK(hipDeviceSynchronize());
     collect_events(pl);
@@ -1289,6 +1294,8 @@ int zd_plan_stats(zd_plan *pl, zd_stats *out) {
         pl->launches[k]         = 0;
     }
     out->bytes_intermediate = zd_plan_exchange_bytes(pl);
+    out->bytes_sent         = pl->bytes_sent;
+    pl->bytes_sent          = 0;
     out->stream_factor      = pl->R;
     out->modes_cached       = 0;  // modes are regenerated per residue pass (counter-addressed RNG)
     if (pl->d_v1err) {  // ZD_Version = 1: a stream that stopped accepting pairs (k_v1_draw's guard)
@@ -1519,6 +1526,7 @@ int zd_generate(const zd_params *p_in, const zd_pk *pk, const double *eig, int64
     return rc;
 }
 
+#ifdef ZD_TESTING
 // ------------------------------------------------------------------------------------------------
 // device test hooks
 
@@ -1710,6 +1718,8 @@ int zd_test_fft(int32_t n, int64_t lines, int32_t axis_kind, const double *in, d
     hipFree(d_out);
     return rc;
 }
+
+#endif  // ZD_TESTING
 
 #ifdef ZD_TUNING
 // tuning harness (not part of the product path): time y-pass tile variants on a synthetic store

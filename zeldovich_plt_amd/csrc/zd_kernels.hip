@@ -43,6 +43,24 @@ __device__ __forceinline__ void st_stream(cplx *p, cplx v, bool nt) {
         *p = v;
 }
 
+#ifdef ZD_TUNING
+// Diagnostic stamps (tuning library only): wave 0 of every workgroup of the y stage records shader-clock times of its phases,
+// the 100 MHz real-time clock at its start and the hardware id of its CU into zd_stamps[unit * 8 ...] (scripts/yf_stamps.py).
+__device__ unsigned long long *zd_stamps = nullptr;
+extern "C" int zdk_set_stamps(unsigned long long *buf) { return (int) hipMemcpyToSymbol(HIP_SYMBOL(zd_stamps), &buf, sizeof(buf)); }
+#define ZD_STAMP(slot, unit, drain)                                                                        \
+    do {                                                                                                   \
+        if (zd_stamps) {                                                                                   \
+            if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                    \
+            if (threadIdx.x == 0) zd_stamps[(size_t) (unit) * 8 + (slot)] = __builtin_amdgcn_s_memtime();   \
+        }                                                                                                  \
+    } while (0)
+#else
+#define ZD_STAMP(slot, unit, drain) \
+    do {                            \
+    } while (0)
+#endif
+
 extern "C" int zdk_upload_bit_table(const zdpcg::BitTable *host) {
     return (int) hipMemcpyToSymbol(HIP_SYMBOL(c_bits), host, sizeof(zdpcg::BitTable));
 }
@@ -1178,6 +1196,7 @@ __global__ __launch_bounds__(GEN_BX) void k_genf(GenConst g, GenJumps J, StoreLa
     }
 }
 
+#ifdef ZD_TESTING
 // test hook: raw draws / amplitudes for an explicit mode list (counter addressing, no walk)
 __global__ void k_test_modes(GenConst g, long long n, const int *__restrict__ kxyz, uint64_t *__restrict__ draws,
                              double *__restrict__ D) {
@@ -1241,6 +1260,7 @@ __global__ void k_test_modes_table(GenConst g, long long n, const int *__restric
     out[3 * i + 2] = g.fundamental * ik2;
 }
 
+#endif  // ZD_TESTING
 // ------------------------------------------------------------------------------------------------
 // k_zfft: length-L FFT of one job's folded inputs for a W-wide column tile of row ky, then the
 // Hermitian stores: "self" columns at (row ky, column x), "twin" columns conjugated at
@@ -1430,34 +1450,43 @@ __global__ __launch_bounds__(NC *FIELD_RB *L / E) void k_zfft_f(FieldLayout F, S
 //   row y = N/2 and columns the zero rule kills: 0, not read.
 // Output: ring[plane][a][row slot][x] in the single-rank block-store layout k_xfft reads.
 //   grid: (3*N/W, 1, planes)   block: W*N/E
+// One (plane pz of the launch, workgroup index id) unit of the y stage; all threads of the workgroup call it.
 template <int N, int E, int W>
-__global__ __launch_bounds__(W *N / E) void k_yfft_f(FieldLayout F, StoreLayout S, const cplx *__restrict__ tw,
-                                                    const cplx *__restrict__ store, int plane0, int ring_pitch,
-                                                    cplx *__restrict__ ring) {
+__device__ __forceinline__ void yfft_f_unit(const FieldLayout &F, const StoreLayout &S, const cplx *__restrict__ tw,
+                                            const cplx *__restrict__ store, int plane0, int ring_pitch, cplx *__restrict__ ring,
+                                            int id, int pz, int t, int w, double *lds) {
     using PL  = zdfft::Plan<N, E>;
     using LDS = zdfft::ColsInner<N, W>;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int T = PL::T;
-    const int w = threadIdx.x % W, t = threadIdx.x / W;
-    // Workgroup -> (column tile, array).  Workgroups go to the 8 XCDs round-robin by their linear index and every XCD has
-    // its own L2, so the 12 workgroups that read the same lines are made consecutive ON ONE XCD: the tiles 2j, 2j+1 (they
-    // share 128-byte lines when W < 8), their mirror images NT-1-2j, NT-2-2j (rows y > N/2 are read at column N - x: a
-    // tile's mirrored reads are its mirror tile's direct reads, off by one column), for each of the three arrays.
     constexpr int NT = N / W;
+    // Workgroup -> (column tile, array).  Workgroups go to the 8 XCDs round-robin by their linear index and every XCD has
+    // its own L2, so the workgroups that read or write the same lines are made consecutive ON ONE XCD: the TPL tiles of a
+    // 128-byte ring line (W < 8), their mirror images (rows y > N/2 are read at column N - x: a tile's mirrored reads are
+    // its mirror tile's direct reads, off by one column), for each of the three arrays.
+    constexpr int TPL = W >= 8 ? 1 : 8 / W, GS = 6 * TPL;
     int tile, a;
-    if constexpr (NT % 32 == 0) {
-        const int id = blockIdx.x, xcd = id & 7, s = id >> 3;  // s: position in this XCD's stream
+    if constexpr (NT % (16 * TPL) == 0) {
+        const int xcd = id & 7, s = id >> 3;  // s: position in this XCD's stream
         // (groups interleaved over the XCDs; giving each XCD a contiguous range of groups measured 12 % slower)
-        const int g = (s / 12) * 8 + xcd, m = s % 12;          // group of 4 tiles, member
-        const int q = m & 3;
-        a    = m >> 2;
-        tile = (q & 2) ? NT - 1 - 2 * g - (q & 1) : 2 * g + (q & 1);
+        const int g = (s / GS) * 8 + xcd, m = s % GS;  // group of 2*TPL tiles, member
+        const int q = m % (2 * TPL);
+        a    = m / (2 * TPL);
+        tile = q >= TPL ? NT - 1 - (TPL * g + (q - TPL)) : TPL * g + q;
     } else {
-        tile = blockIdx.x % NT;
-        a    = blockIdx.x / NT;
+        tile = id % NT;
+        a    = id / NT;
     }
     const int x = tile * W + w, xm = (N - x) & (N - 1);
-    const int zl = plane0 + blockIdx.z;
+    const int zl = plane0 + pz;
+    [[maybe_unused]] const int unit = pz * 3 * NT + id;
+#ifdef ZD_TUNING
+    if (zd_stamps && threadIdx.x == 0) {
+        zd_stamps[(size_t) unit * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+        zd_stamps[(size_t) unit * 8 + 7] = (unsigned long long) __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11))  /* HW_ID */
+                                           | ((unsigned long long) __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);  /* XCC_ID */
+    }
+#endif
+    ZD_STAMP(0, unit, false);
     const int kx = x > N / 2 ? x - N : x;
     // potentials this array is made of.  ZA: E_a alone (a < 2), or (Z_0, Z_1).  PLT: the pairs (X, fX), (Y, Z), (fY, fZ) of
     // the fields X, Y, Z, fX, fY, fZ — every array is i P - Q like the ZA one of two
@@ -1480,6 +1509,7 @@ __global__ __launch_bounds__(W *N / E) void k_yfft_f(FieldLayout F, StoreLayout 
         kyp = kyp < N / 2 ? kyp : N / 2 - 1;  // the Nyquist row is never used: any valid record
         rows[e] = F.rows[(kyp >> F.lG) / FIELD_RB];  // the row block
     }
+    ZD_STAMP(1, unit, true);  // row records in
     constexpr int BATCH = 4;
 #pragma unroll
     for (int b = 0; b < E; b += BATCH) {
@@ -1519,9 +1549,11 @@ __global__ __launch_bounds__(W *N / E) void k_yfft_f(FieldLayout F, StoreLayout 
         }
     }
     if (ZD_TUNE(S.prune & 4096) && a == 2) return;                           // bit 12: tuning ablation (no x array)
+    ZD_STAMP(2, unit, true);  // potentials in
     if (!ZD_TUNE(S.prune & 128)) zdfft::fft_line<PL, LDS>(re, im, t, w, lds, tw);  // bit 7: tuning ablation
-    if (ZD_TUNE(S.prune & 256) && re[0] != 123.456) return;                  // bit 8: tuning ablation (no stores)
-    char *base = reinterpret_cast<char *>(ring + ((long long) ((int) blockIdx.z * 3 + a) * N) * ring_pitch);
+    ZD_STAMP(3, unit, false);  // transformed
+    if (ZD_TUNE(S.prune & 256) && re[0] != 123.456) return;                    // bit 8: tuning ablation (no stores)
+    char *base = reinterpret_cast<char *>(ring + ((long long) (pz * 3 + a) * N) * ring_pitch);
     const unsigned xb = (unsigned) x * 16u, pb = (unsigned) ring_pitch * 16u;
     int t2 = t;
     asm volatile("" : "+v"(t2));
@@ -1533,6 +1565,34 @@ __global__ __launch_bounds__(W *N / E) void k_yfft_f(FieldLayout F, StoreLayout 
             *reinterpret_cast<cplx *>(base + ((size_t) slot * pb + xb)) = cplx{re[e], im[e]};
         else
             *reinterpret_cast<cplx *>(base + (slot * pb + xb)) = cplx{re[e], im[e]};
+    }
+    ZD_STAMP(4, unit, false);  // stores issued
+    ZD_STAMP(5, unit, true);   // stores acknowledged (wave 0's)
+}
+//   grid: (3*N/W, 1, planes)   block: W*N/E
+template <int N, int E, int W, int MINW = 1>
+__global__ __launch_bounds__(W *N / E, MINW) void k_yfft_f(FieldLayout F, StoreLayout S, const cplx *__restrict__ tw,
+                                                          const cplx *__restrict__ store, int plane0, int ring_pitch,
+                                                          cplx *__restrict__ ring) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    yfft_f_unit<N, E, W>(F, S, tw, store, plane0, ring_pitch, ring, (int) blockIdx.x, (int) blockIdx.z, (int) threadIdx.x / W,
+                         (int) threadIdx.x % W, lds);
+}
+// Persistent form: gridDim.x workgroups (a multiple of 8, so that a workgroup keeps its XCD class = linear index mod 8) walk
+// the (plane, workgroup index) list with stride gridDim.x: the ring stores of one unit and the potential loads of the next
+// are in flight together (as separate workgroups filling the CU, the next one's loads wait for the previous one's stores).
+template <int N, int E, int W, int MINW = 1>
+__global__ __launch_bounds__(W *N / E, MINW) void k_yfft_fp(FieldLayout F, StoreLayout S, const cplx *__restrict__ tw,
+                                                           const cplx *__restrict__ store, int plane0, int ring_pitch,
+                                                           cplx *__restrict__ ring, int nplanes) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int PER = 3 * (N / W);
+    const int nwork = PER * nplanes;
+#pragma unroll 1
+    for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));  // per-iteration value: nothing that depends on the thread index is hoisted (and spilled)
+        yfft_f_unit<N, E, W>(F, S, tw, store, plane0, ring_pitch, ring, work % PER, work / PER, tid / W, tid % W, lds);
     }
 }
 
@@ -1939,6 +1999,7 @@ __global__ __launch_bounds__(W *N / E) void k_zfwd(StoreLayout S, int lZq, const
     for (int e = 0; e < E; e++) phik[((long long) ky * N + (t2 + T * e)) * N + x] = cplx{re[e], -im[e]};
 }
 
+#ifdef ZD_TESTING
 // ------------------------------------------------------------------------------------------------
 // test kernels: batches of independent lines through the two LDS layouts
 template <int N, int E, int W>
@@ -1984,6 +2045,7 @@ __global__ __launch_bounds__(W *N / E) void k_test_fft_lines(const cplx *__restr
     for (int e = 0; e < E; e++) out[line * N + t + T * e] = cplx{re[e], im[e]};
 }
 
+#endif  // ZD_TESTING
 #ifdef ZD_TUNING
 __global__ void k_copy16(const uint4 *__restrict__ in, uint4 *__restrict__ out, long long n) {
     long long i      = (long long) blockIdx.x * blockDim.x + threadIdx.x;
@@ -2180,6 +2242,7 @@ int launch_pk_table(const GenConst &g, int n, void *tab, hipStream_t st) {
     return 0;
 }
 
+#ifdef ZD_TESTING
 int launch_test_modes(const GenConst &g, long long n, const int *kxyz, uint64_t *draws, double *D, hipStream_t st) {
     dim3 grid((unsigned) ((n + 255) / 256)), block(256);
     hipLaunchKernelGGL(k_test_modes, grid, block, 0, st, g, n, kxyz, draws, D);
@@ -2199,16 +2262,13 @@ int launch_test_modes_table(const GenConst &g, long long n, const int *kxyz, dou
     return 0;
 }
 
+#endif  // ZD_TESTING
 template <int L, int E, int W>
 static int launch_zfft_t(const JobList &jobs, const StoreLayout &S, int ky0, int kyloc0, int nky, int Zq, const void *Y,
                          const void *twL, void *out, hipStream_t st) {
     constexpr int threads = W * L / E;
     const size_t shmem = sizeof(double) * zdfft::ColsInner<L, W>::SIZE;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void *) k_zfft<L, E, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
-        attr_set = true;
-    }
+    set_dyn_lds<k_zfft<L, E, W>>(shmem);
     dim3 grid(S.N / W, nky, jobs.n), block(threads);
     hipLaunchKernelGGL((k_zfft<L, E, W>), grid, block, shmem, st, jobs, S, ky0, kyloc0, nky, Zq, (const cplx *) Y,
                        (const cplx *) twL, (cplx *) out);
@@ -2250,12 +2310,8 @@ template <int N, int E, int W>
 static int launch_yfft_t(const StoreLayout &S, int nplanes, const void *tw, void *data, hipStream_t st) {
     constexpr int threads = W * N / E;
     const size_t shmem = sizeof(double) * zdfft::ColsInner<N, W>::SIZE;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void *) k_yfft<N, E, W, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
-        hipFuncSetAttribute((const void *) k_yfft<N, E, W, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
-        attr_set = true;
-    }
+    set_dyn_lds<k_yfft<N, E, W, 1, false>>(shmem);
+    set_dyn_lds<k_yfft<N, E, W, 1, true>>(shmem);
     dim3 grid(N / W, S.narray, nplanes), block(threads);
     if (S.one_block)
         hipLaunchKernelGGL((k_yfft<N, E, W, 1, true>), grid, block, shmem, st, S, (const cplx *) tw, (cplx *) data);
@@ -2269,11 +2325,7 @@ static int launch_zfft_f_t(const FieldLayout &F, const StoreLayout &S, int ky0, 
                            const void *twL, void *out, hipStream_t st) {
     constexpr int W = NC * FIELD_RB, threads = W * L / E;
     const size_t shmem = sizeof(double) * zdfft::ColsInner<L, W>::SIZE;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void *) k_zfft_f<L, E, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
-        attr_set = true;
-    }
+    set_dyn_lds<k_zfft_f<L, E, NC>>(shmem);
     if (nky % FIELD_RB || kyloc0 % FIELD_RB) return 2;
     dim3 grid(S.N / NC, nky / FIELD_RB, F.nfield), block(threads);
     hipLaunchKernelGGL((k_zfft_f<L, E, NC>), grid, block, shmem, st, F, S, ky0, kyloc0, nky, (const cplx *) Y,
@@ -2309,19 +2361,26 @@ int launch_zfft_fields(int L, const FieldLayout &F, const StoreLayout &S, int ky
     return 2;
 }
 
-template <int N, int E, int W>
+template <int N, int E, int W, bool PERSIST = false, int MINW = 1>
 static int launch_yfft_f_t(const FieldLayout &F, const StoreLayout &S, const void *tw, const void *store, int plane0,
                            int nplanes, int ring_pitch, void *ring, hipStream_t st) {
     constexpr int threads = W * N / E;
     const size_t shmem = sizeof(double) * zdfft::ColsInner<N, W>::SIZE;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void *) k_yfft_f<N, E, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
-        attr_set = true;
+    if constexpr (PERSIST) {
+        set_dyn_lds<k_yfft_fp<N, E, W, MINW>>(shmem);
+        int dev = 0, ncu = 256;
+        hipGetDevice(&dev);
+        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        const int per_cu = std::max(1, std::min((int) (160 * 1024 / shmem), 2048 / (threads * (MINW > 1 ? 1 : 2))));
+        dim3 grid((unsigned) std::max(8, ncu * per_cu / 8 * 8)), block(threads);
+        hipLaunchKernelGGL((k_yfft_fp<N, E, W, MINW>), grid, block, shmem, st, F, S, (const cplx *) tw, (const cplx *) store, plane0,
+                           ring_pitch, (cplx *) ring, nplanes);
+    } else {
+        set_dyn_lds<k_yfft_f<N, E, W, MINW>>(shmem);
+        dim3 grid(3 * (N / W), 1, nplanes), block(threads);
+        hipLaunchKernelGGL((k_yfft_f<N, E, W, MINW>), grid, block, shmem, st, F, S, (const cplx *) tw, (const cplx *) store, plane0,
+                           ring_pitch, (cplx *) ring);
     }
-    dim3 grid(3 * (N / W), 1, nplanes), block(threads);
-    hipLaunchKernelGGL((k_yfft_f<N, E, W>), grid, block, shmem, st, F, S, (const cplx *) tw, (const cplx *) store, plane0,
-                       ring_pitch, (cplx *) ring);
     ZD_LAUNCH_CHECK();
     return 0;
 }
@@ -2330,6 +2389,17 @@ int launch_yfft_fields(const FieldLayout &F, const StoreLayout &S, const void *t
                        int nplanes, int ring_pitch, void *ring, hipStream_t st) {
 #define YCASE(n, e, w) \
     case n: return launch_yfft_f_t<n, e, w>(F, S, tw, store, plane0, nplanes, ring_pitch, ring, st);
+#ifdef ZD_TUNING
+    {
+        const int yw = getenv("ZD_YW") ? atoi(getenv("ZD_YW")) : 0, yp = getenv("ZD_YPERSIST") ? atoi(getenv("ZD_YPERSIST")) : 0;
+        if (S.N == 4096 && yw == 2 && !yp) return launch_yfft_f_t<4096, 16, 2, false, 4>(F, S, tw, store, plane0, nplanes, ring_pitch, ring, st);
+        if (S.N == 4096 && yw == 2 && yp) return launch_yfft_f_t<4096, 16, 2, true, 4>(F, S, tw, store, plane0, nplanes, ring_pitch, ring, st);
+        if (S.N == 4096 && yp) return launch_yfft_f_t<4096, 16, 4, true>(F, S, tw, store, plane0, nplanes, ring_pitch, ring, st);
+        if (S.N == 2048 && yw == 4 && !yp) return launch_yfft_f_t<2048, 16, 4, false, 4>(F, S, tw, store, plane0, nplanes, ring_pitch, ring, st);
+        if (S.N == 2048 && yw == 4 && yp) return launch_yfft_f_t<2048, 16, 4, true, 4>(F, S, tw, store, plane0, nplanes, ring_pitch, ring, st);
+        if (S.N == 2048 && yp) return launch_yfft_f_t<2048, 16, 8, true>(F, S, tw, store, plane0, nplanes, ring_pitch, ring, st);
+    }
+#endif
     switch (S.N) {
         YCASE(64, 16, 32)
         YCASE(128, 16, 32)
@@ -2379,11 +2449,7 @@ static int launch_xfft_t(const StoreLayout &S, const EpiConst &ec, const void *t
         fprintf(stderr, "zeldovich_hip: x pass for PPD %d with %d arrays needs %zu B of LDS (> 160 KB): unsupported\n", N, NA, shmem);
         return 2;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void *) k_xfft<N, E, NA, ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
-        attr_set = true;
-    }
+    set_dyn_lds<k_xfft<N, E, NA, ROWS>>(shmem);
     dim3 grid(N / ROWS, nplanes), block(threads);
     hipLaunchKernelGGL((k_xfft<N, E, NA, ROWS>), grid, block, shmem, st, S, ec, (const cplx *) tw, (const cplx *) data,
                        plane0, z_first, z_step, (char *) records, density, red);
@@ -2394,11 +2460,7 @@ template <int N, int E>
 static int launch_xfft_seq_t(const StoreLayout &S, const EpiConst &ec, const void *tw, const void *data, int plane0,
                              int nplanes, int z_first, int z_step, void *records, Reduce *red, hipStream_t st) {
     const size_t shmem = sizeof(double) * zdfft::LineInner<N, 1>::SIZE;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void *) k_xfft_seq<N, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
-        attr_set = true;
-    }
+    set_dyn_lds<k_xfft_seq<N, E>>(shmem);
     dim3 grid(N, nplanes), block(N / E);
     hipLaunchKernelGGL((k_xfft_seq<N, E>), grid, block, shmem, st, S, ec, (const cplx *) tw, (const cplx *) data, plane0, z_first,
                        z_step, (char *) records, red);
@@ -2410,7 +2472,7 @@ template <int N, int E, bool PLT>
 static int launch_xfft_two_t(const StoreLayout &S, const EpiConst &ec, const void *tw, const void *data, int plane0,
                              int nplanes, int z_first, int z_step, void *records, Reduce *red, hipStream_t st) {
     const size_t shmem = sizeof(double) * zdfft::LineInner<N, 1>::SIZE;
-    hipFuncSetAttribute((const void *) k_xfft_two<N, E, PLT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+    set_dyn_lds<k_xfft_two<N, E, PLT>>(shmem);
     for (int emit = 0; emit < 2; emit++) {
         dim3 grid(N, nplanes, (emit != 0) == PLT ? 1 : 2), block(N / E);
         hipLaunchKernelGGL((k_xfft_two<N, E, PLT>), grid, block, shmem, st, S, ec, (const cplx *) tw, (cplx *) data, emit, plane0, z_first,
@@ -2455,18 +2517,19 @@ int launch_xfft(const StoreLayout &S, const EpiConst &ec, const void *tw, const 
     return 2;
 }
 
+#ifdef ZD_TESTING
 template <int N, int E, int W>
 static int launch_test_fft_t(int kind, const void *tw, const void *in, void *out, long long lines, hipStream_t st) {
     constexpr int threads = W * N / E;
     if (lines % W) return 3;
     if (kind == 1) {
         const size_t shmem = sizeof(double) * zdfft::ColsInner<N, W>::SIZE;
-        hipFuncSetAttribute((const void *) k_test_fft_cols<N, E, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+        set_dyn_lds<k_test_fft_cols<N, E, W>>(shmem);
         hipLaunchKernelGGL((k_test_fft_cols<N, E, W>), dim3((unsigned) (lines / W)), dim3(threads), shmem, st,
                            (const cplx *) tw, (const cplx *) in, (cplx *) out, lines);
     } else {
         const size_t shmem = sizeof(double) * zdfft::LineInner<N, W>::SIZE;
-        hipFuncSetAttribute((const void *) k_test_fft_lines<N, E, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+        set_dyn_lds<k_test_fft_lines<N, E, W>>(shmem);
         hipLaunchKernelGGL((k_test_fft_lines<N, E, W>), dim3((unsigned) (lines / W)), dim3(threads), shmem, st,
                            (const cplx *) tw, (const cplx *) in, (cplx *) out, lines);
     }
@@ -2493,13 +2556,14 @@ int launch_test_fft(int n, int kind, const void *tw, const void *in, void *out, 
 }
 int test_fft_tile_width(int n) { return zfft_tile_width(n); }
 
+#endif  // ZD_TESTING
 #ifdef ZD_TUNING
 // ---- tuning harness: the y pass in alternative tile shapes (zd_test_yfft_variant) ----
 template <int N, int E, int W, int MINW>
 static int launch_yfft_v(const StoreLayout &S, int nplanes, const void *tw, void *data, hipStream_t st) {
     constexpr int threads = W * N / E;
     const size_t shmem = sizeof(double) * zdfft::ColsInner<N, W>::SIZE;
-    hipFuncSetAttribute((const void *) k_yfft<N, E, W, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+    set_dyn_lds<k_yfft<N, E, W, MINW>>(shmem);
     dim3 grid(N / W, S.narray, nplanes), block(threads);
     hipLaunchKernelGGL((k_yfft<N, E, W, MINW>), grid, block, shmem, st, S, (const cplx *) tw, (cplx *) data);
     ZD_LAUNCH_CHECK();
@@ -2534,7 +2598,7 @@ static int launch_fnl_t(int which, const StoreLayout &S, double f_NL, const void
     if (which == 0) {  // x: inverse + nonlinearity + forward
         constexpr int threads = ROWS * N / E;
         const size_t shmem = sizeof(double) * zdfft::LineInner<N, ROWS>::SIZE;
-        hipFuncSetAttribute((const void *) k_xphi<N, E, ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+        set_dyn_lds<k_xphi<N, E, ROWS>>(shmem);
         const double inv = 1. / N / N / N;
         hipLaunchKernelGGL((k_xphi<N, E, ROWS>), dim3(N / ROWS, nplanes), dim3(threads), shmem, st, S, f_NL, inv, (const cplx *) tw,
                            (cplx *) data);
@@ -2542,10 +2606,10 @@ static int launch_fnl_t(int which, const StoreLayout &S, double f_NL, const void
         constexpr int threads = W * N / E;
         const size_t shmem = sizeof(double) * zdfft::ColsInner<N, W>::SIZE;
         if (which == 1) {
-            hipFuncSetAttribute((const void *) k_yfwd<N, E, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+            set_dyn_lds<k_yfwd<N, E, W>>(shmem);
             hipLaunchKernelGGL((k_yfwd<N, E, W>), dim3(N / W, 1, nplanes), dim3(threads), shmem, st, S, (const cplx *) tw, (cplx *) data);
         } else {
-            hipFuncSetAttribute((const void *) k_zfwd<N, E, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+            set_dyn_lds<k_zfwd<N, E, W>>(shmem);
             hipLaunchKernelGGL((k_zfwd<N, E, W>), dim3(N / W, S.Hq), dim3(threads), shmem, st, S, lZq, (const cplx *) tw,
                                (const cplx *) data, (cplx *) phik);
         }

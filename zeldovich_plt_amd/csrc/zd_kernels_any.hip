@@ -242,7 +242,7 @@ static int launch_any_cols_t(const AnyTab &tb, void *data, long long batch_strid
                              int zero_point, hipStream_t st) {
     constexpr int E = 16, threads = W * M / E;
     const size_t shmem = sizeof(double) * zdfft::ColsInner<M, W>::SIZE;
-    hipFuncSetAttribute((const void *) k_any_cols<M, E, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+    set_dyn_lds<k_any_cols<M, E, W>>(shmem);
     hipLaunchKernelGGL((k_any_cols<M, E, W>), dim3((ncols + W - 1) / W, nbatch), dim3(threads), shmem, st, tb, (cplx *) data, batch_stride,
                        point_stride, ncols, zero_point);
     ZD_LAUNCH_CHECK();
@@ -252,7 +252,7 @@ template <int M, int W>
 static int launch_any_lines_t(const AnyTab &tb, void *data, long long pitch, long long nlines, hipStream_t st) {
     constexpr int E = 16, threads = W * M / E;
     const size_t shmem = sizeof(double) * zdfft::LineInner<M, W>::SIZE;
-    hipFuncSetAttribute((const void *) k_any_lines<M, E, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+    set_dyn_lds<k_any_lines<M, E, W>>(shmem);
     hipLaunchKernelGGL((k_any_lines<M, E, W>), dim3((unsigned) ((nlines + W - 1) / W)), dim3(threads), shmem, st, tb, (cplx *) data, pitch,
                        nlines);
     ZD_LAUNCH_CHECK();

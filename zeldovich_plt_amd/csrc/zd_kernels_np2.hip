@@ -14,6 +14,7 @@ using namespace zd;
 using zdfft::cplx;
 
 
+#ifdef ZD_TESTING
 // ------------------------------------------------------------------------------------------------
 // test kernels: batches of independent lines of length P*Q through the two LDS layouts
 template <int P, int E, int Q, int W>
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(W *Q *P / E) void k_test_fftq_lines(const cplx *__r
     for (int e = 0; e < E; e++) out[line * N + (t + T * e) + P * n2] = cplx{re[e], im[e]};
 }
 
+#endif  // ZD_TESTING
 // ------------------------------------------------------------------------------------------------
 // Field-store pipeline for PPD = P*Q (ZA, one rank): the roles of k_zfft_f, k_yfft_f and k_xfft_seq of zd_kernels.hip with
 // the composite line transform.  A thread enters a transform with elements Q (t + T e) + n2 of its line and leaves with
@@ -365,7 +367,7 @@ static int launch_zfft_fq_t(const FieldLayout &F, const StoreLayout &S, int ky0,
     static_assert(threads <= 1024, "workgroup too large");
     const size_t shmem = sizeof(double) * zdfft::LineQ<P, E, Q, W, false>::LDS_DOUBLES;
     if (shmem > 160 * 1024 || nky % FIELD_RB || kyloc0 % FIELD_RB) return 2;
-    hipFuncSetAttribute((const void *) k_zfft_fq<P, E, Q, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+    set_dyn_lds<k_zfft_fq<P, E, Q, NC>>(shmem);
     dim3 grid(S.N / NC, nky / FIELD_RB, F.nfield), block(threads);
     hipLaunchKernelGGL((k_zfft_fq<P, E, Q, NC>), grid, block, shmem, st, F, S, ky0, kyloc0, nky, (const cplx *) Y, tw, tw + P,
                        tw + P + P * Q, (cplx *) out);
@@ -401,7 +403,7 @@ static int launch_yfft_fq_t(const FieldLayout &F, const StoreLayout &S, const cp
     static_assert(threads <= 1024, "workgroup too large");
     const size_t shmem = sizeof(double) * zdfft::LineQ<P, E, Q, W, false>::LDS_DOUBLES;
     if (shmem > 160 * 1024) return 2;
-    hipFuncSetAttribute((const void *) k_yfft_fq<P, E, Q, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+    set_dyn_lds<k_yfft_fq<P, E, Q, W>>(shmem);
     dim3 grid(3 * (N / W), 1, nplanes), block(threads);
     hipLaunchKernelGGL((k_yfft_fq<P, E, Q, W>), grid, block, shmem, st, F, S, tw, tw + P, tw + P + N, (const cplx *) store, plane0,
                        ring_pitch, (cplx *) ring);
@@ -418,7 +420,7 @@ static int launch_xfft_q_t(const EpiConst &ec, const cplx *tw, const void *ring,
         constexpr size_t dbl = LQ3::LDS_DOUBLES > stash ? LQ3::LDS_DOUBLES : stash;
         const size_t shmem3 = sizeof(double) * (dbl > (size_t) 18 * threads ? dbl : (size_t) 18 * threads);
         if (shmem3 <= 160 * 1024) {
-            hipFuncSetAttribute((const void *) k_xfft_q3<P, E, Q, PLT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem3);
+            set_dyn_lds<k_xfft_q3<P, E, Q, PLT>>(shmem3);
             hipLaunchKernelGGL((k_xfft_q3<P, E, Q, PLT>), dim3(N, nplanes), dim3(3 * threads), shmem3, st, ec, tw, tw + P, tw + P + N,
                                (const cplx *) ring, ring_pitch, z_first, z_step, (char *) records, red);
             ZD_LAUNCH_CHECK();
@@ -429,7 +431,7 @@ static int launch_xfft_q_t(const EpiConst &ec, const cplx *tw, const void *ring,
     const size_t need = sizeof(double) * (size_t) LQ::LDS_DOUBLES, red_b = sizeof(double) * 6 * threads;
     const size_t shmem = need > red_b ? need : red_b;
     if (shmem > 160 * 1024) return 2;
-    hipFuncSetAttribute((const void *) k_xfft_seq_q<P, E, Q, PLT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+    set_dyn_lds<k_xfft_seq_q<P, E, Q, PLT>>(shmem);
     for (int emit = 0; emit < 2; emit++) {
         dim3 grid(N, nplanes, (emit != 0) == PLT ? 1 : 2), block(threads);
         hipLaunchKernelGGL((k_xfft_seq_q<P, E, Q, PLT>), grid, block, shmem, st, ec, tw, tw + P, tw + P + N, (cplx *) ring, emit, ring_pitch,
@@ -477,6 +479,7 @@ bool np2_supported_zlen(int L) {
     return (Q == 3 && P <= 512) || (Q == 9 && P <= 128) || (Q == 27 && P <= 64);
 }
 
+#ifdef ZD_TESTING
 template <int P, int E, int Q, int W>
 static int launch_test_fftq_t(int kind, const void *twP, const void *twN, const void *twQ, const void *in, void *out, long long lines,
                               hipStream_t st) {
@@ -485,18 +488,19 @@ static int launch_test_fftq_t(int kind, const void *twP, const void *twN, const 
     if (lines % W) return 3;
     if (kind == 1) {
         const size_t shmem = sizeof(double) * zdfft::LineQ<P, E, Q, W, false>::LDS_DOUBLES;
-        hipFuncSetAttribute((const void *) k_test_fftq_cols<P, E, Q, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+        set_dyn_lds<k_test_fftq_cols<P, E, Q, W>>(shmem);
         hipLaunchKernelGGL((k_test_fftq_cols<P, E, Q, W>), dim3((unsigned) (lines / W)), dim3(threads), shmem, st, (const cplx *) twP,
                            (const cplx *) twN, (const cplx *) twQ, (const cplx *) in, (cplx *) out, lines);
     } else {
         const size_t shmem = sizeof(double) * zdfft::LineQ<P, E, Q, W, true>::LDS_DOUBLES;
-        hipFuncSetAttribute((const void *) k_test_fftq_lines<P, E, Q, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+        set_dyn_lds<k_test_fftq_lines<P, E, Q, W>>(shmem);
         hipLaunchKernelGGL((k_test_fftq_lines<P, E, Q, W>), dim3((unsigned) (lines / W)), dim3(threads), shmem, st, (const cplx *) twP,
                            (const cplx *) twN, (const cplx *) twQ, (const cplx *) in, (cplx *) out, lines);
     }
     ZD_LAUNCH_CHECK();
     return 0;
 }
+#endif  // ZD_TESTING
 
 // n = P*Q -> (P, Q): Q = the whole power of three in n (3, 9 or 27), P the power of two
 bool np2_split(int n, int *P, int *Q) {
@@ -510,6 +514,7 @@ bool np2_split(int n, int *P, int *Q) {
     *Q = q;
     return true;
 }
+#ifdef ZD_TESTING
 int test_fftq_tile_width(int n) {
     int P, Q;
     if (!np2_split(n, &P, &Q)) return 0;
@@ -532,5 +537,6 @@ int launch_test_fftq(int n, int kind, const void *twP, const void *twN, const vo
     fprintf(stderr, "zeldovich_hip: no composite FFT for length %d\n", n);
     return 2;
 }
+#endif  // ZD_TESTING
 
 }  // namespace zd

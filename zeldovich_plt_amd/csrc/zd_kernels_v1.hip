@@ -150,6 +150,7 @@ __global__ __launch_bounds__(V1_T) void k_v1_draw(GenConst g, int block, int ky0
     if (t == 0) S.nq = (uint32_t) count;
 }
 
+#ifdef ZD_TESTING
 // test hook: the first 624 * nblocks tempered words of one stream (pins the parallel regeneration against the serial one)
 __global__ __launch_bounds__(V1_T) void k_test_v1_words(V1Stream *streams, int nblocks, uint32_t *__restrict__ out) {
     __shared__ uint32_t mt[624];
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(V1_T) void k_test_v1_words(V1Stream *streams, int n
     }
 }
 
+#endif  // ZD_TESTING
 int launch_v1_seed(unsigned long long seed, int block, V1Stream *streams, hipStream_t st) {
     hipLaunchKernelGGL(k_v1_seed, dim3((block + 63) / 64), dim3(64), 0, st, seed, block, streams);
     ZD_LAUNCH_CHECK();
@@ -173,10 +175,12 @@ int launch_v1_draw(const GenConst &g, int block, int ky0, int ky_stride, int nro
     ZD_LAUNCH_CHECK();
     return 0;
 }
+#ifdef ZD_TESTING
 int launch_test_v1_words(V1Stream *streams, int nblocks, uint32_t *out, hipStream_t st) {
     hipLaunchKernelGGL(k_test_v1_words, dim3(1), dim3(V1_T), 0, st, streams, nblocks, out);
     ZD_LAUNCH_CHECK();
     return 0;
 }
 
+#endif  // ZD_TESTING
 }  // namespace zd

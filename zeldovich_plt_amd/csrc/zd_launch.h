@@ -14,6 +14,23 @@
         }                                                                                       \
     } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to (kernel, device): ZD_NumGPU runs one host thread per device through
+// the same launchers, so "already set" is kept per device (bit d of one word per kernel) — a process-wide flag would leave
+// every device but the first with the 64 KB default and the launches of the large-LDS kernels would fail there.
+#if defined(__HIPCC__)
+#include <atomic>
+template <auto Kernel>
+static inline void set_dyn_lds(size_t bytes) {
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const unsigned long long bit = 1ULL << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return;
+    hipFuncSetAttribute((const void *) Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
+    done.fetch_or(bit, std::memory_order_release);
+}
+#endif
+
 namespace zd {
 constexpr int GEN_BX = 256;  // threads (consecutive x) per generator workgroup
 constexpr int GEN_ZR = 16;   // z rows walked by one generator thread

@@ -52,15 +52,21 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int)                     = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *)                            = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t)                                                = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t)                                                  = nullptr;
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *)                          = nullptr;
     ncclResult_t (*GroupStart)()                                                           = nullptr;
     ncclResult_t (*GroupEnd)()                                                             = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t)     = nullptr;
     const char *(*GetErrorString)(ncclResult_t)                                            = nullptr;
 };
+#ifdef ZD_TESTING
 RcclApi *g_rccl_override = nullptr;  // test transport (loopback emulation below): stands in for librccl
+#endif
 RcclApi *rccl() {
+#ifdef ZD_TESTING
     if (g_rccl_override) return g_rccl_override;
+#endif
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
@@ -75,6 +81,8 @@ RcclApi *rccl() {
         BIND(CommInitRank);
         BIND(CommInitAll);
         BIND(CommDestroy);
+        BIND(CommAbort);
+        BIND(CommGetAsyncError);
         BIND(GroupStart);
         BIND(GroupEnd);
         BIND(Send);
@@ -96,6 +104,7 @@ RcclApi *rccl() {
         }                                                                                                    \
     } while (0)
 
+#ifdef ZD_TESTING
 // ---- loopback emulation of the RCCL calls (tests only: zd_test_generate_loopback) --------------------------------------------
 // Lets the RCCL branch of the exchange code — buffer offsets, grouped send / receive order, stream and event ordering — run
 // with several ranks as threads on ONE GPU, where real RCCL refuses duplicate devices.  Semantics kept: Send / Recv inside a
@@ -188,6 +197,8 @@ ncclResult_t loop_group_end() {
 const char *loop_error_string(ncclResult_t) { return "loopback transport"; }
 RcclApi g_loop_api;
 
+#endif  // ZD_TESTING
+
 // in-process rendezvous of the local transport
 struct LocalGroup {
     int n = 0;
@@ -224,12 +235,21 @@ struct zd_comm {
     int rank = 0, nranks = 1;
     int kind = 0;  // 0 RCCL, 1 local
     ncclComm_t nccl = nullptr;
+    bool owns_nccl = false;  // zd_comm_create: this object aborts / destroys the communicator; thread-per-GPU driver: the driver does
     LocalGroup *grp = nullptr;
     hipStream_t s_comm = nullptr;
     hipEvent_t ev_z = nullptr, ev_x[2] = {nullptr, nullptr}, ev_r[2] = {nullptr, nullptr};
     char *ring = nullptr;  // two slots of [source rank][planes of a group]...
+    int64_t ring_bytes = 0;  // bytes allocated at `ring`
     int64_t slot_bytes = 0;
     int group_planes = 0;
+    // Set when ANY rank of the job has failed (thread-per-GPU driver: shared by the ranks; one process per GPU: this rank's
+    // own).  A rank that fails aborts the communicators it can reach (ncclCommAbort) so that send / receive kernels already
+    // queued — which would spin for ever on the missing rank — drain, and every rank returns non-zero from its next check.
+    std::atomic<int> *failed = nullptr;
+    std::atomic<int> own_failed{0};
+    // per-rank accounting of the exchange (zd_comm_stats)
+    int64_t bytes_sent = 0, bytes_received = 0;
 };
 
 namespace {
@@ -246,6 +266,31 @@ int comm_prepare(zd_comm *c) {
 
 // bytes of ONE store plane inside one chunk (chunks are plane-major)
 int64_t chunk_plane_bytes(const zd_plan *pl) { return zd_plan_exchange_bytes(pl) / pl->nranks / pl->Zq; }
+
+// The exchange ring belongs to the communicator and is sized by the plan that uses it: a later plan on the same
+// communicator (another PPD, stream factor, store or exchange_planes) may need a larger one.  `st` and the communication
+// stream are drained before the old ring goes away.
+int comm_ring(zd_comm *c, int64_t ring_b, int gp, hipStream_t st) {
+    if (c->ring && c->ring_bytes >= ring_b) {
+        c->slot_bytes   = ring_b / 2;
+        c->group_planes = gp;
+        return 0;
+    }
+    if (c->ring) {
+        MHIP(hipStreamSynchronize(st));
+        MHIP(hipStreamSynchronize(c->s_comm));
+        MHIP(hipFree(c->ring));
+        c->ring       = nullptr;
+        c->ring_bytes = 0;
+    }
+    MHIP(hipMalloc((void **) &c->ring, (size_t) ring_b));
+    c->ring_bytes   = ring_b;
+    c->slot_bytes   = ring_b / 2;
+    c->group_planes = gp;
+    return 0;
+}
+
+bool comm_failed(const zd_comm *c) { return c->failed && c->failed->load(std::memory_order_acquire) != 0; }
 
 }  // namespace
 
@@ -276,6 +321,8 @@ int zd_comm_create(int rank, int nranks, const void *id128, zd_comm **out) {
     c->rank    = rank;
     c->nranks  = nranks;
     c->kind    = 0;
+    c->failed  = &c->own_failed;
+    c->owns_nccl = true;
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
     ncclResult_t r = R->CommInitRank(&c->nccl, nranks, id, rank);
@@ -288,9 +335,25 @@ int zd_comm_create(int rank, int nranks, const void *id128, zd_comm **out) {
     return 0;
 }
 
+void zd_comm_abort(zd_comm *c) {
+    if (!c) return;
+    c->own_failed.store(1);
+    if (c->failed) c->failed->store(1, std::memory_order_release);
+    if (c->kind == 0 && c->owns_nccl && c->nccl && rccl() && rccl()->CommAbort) {
+        rccl()->CommAbort(c->nccl);  // frees the communicator: not destroyed again
+        c->nccl = nullptr;
+    }
+}
+
+void zd_comm_traffic(zd_comm *c, int64_t *bytes_sent, int64_t *bytes_received, int reset) {
+    if (bytes_sent) *bytes_sent = c ? c->bytes_sent : 0;
+    if (bytes_received) *bytes_received = c ? c->bytes_received : 0;
+    if (c && reset) c->bytes_sent = c->bytes_received = 0;
+}
+
 void zd_comm_destroy(zd_comm *c) {
     if (!c) return;
-    if (c->nccl && rccl() && rccl()->CommDestroy) rccl()->CommDestroy(c->nccl);
+    if (c->nccl && c->owns_nccl && rccl() && rccl()->CommDestroy) rccl()->CommDestroy(c->nccl);
     if (c->s_comm) hipStreamDestroy(c->s_comm);
     if (c->ev_z) hipEventDestroy(c->ev_z);
     for (int i = 0; i < 2; i++) {
@@ -332,7 +395,25 @@ int zd_plan_run_pass(zd_plan *pl, zd_comm *c, int pass, void *d_store, void *d_r
     return run_pass_impl(pl, c, pass, d_store, d_records, nullptr, rec_planes, cb, user, hip_stream);
 }
 
+static int run_pass_body(zd_plan *pl, zd_comm *c, int pass, void *d_store, void *d_records, float *d_density, int64_t rec_planes,
+                         zd_group_cb cb, void *user, void *hip_stream);
+
+// A rank that fails (allocation, launch, RCCL error, consumer returning non-zero) must not leave its peers spinning in the
+// send / receive kernels they have already queued for it: the failure is published (zd_comm::failed) and this rank's
+// communicator is aborted before the error is returned.  Peers notice at their next check and return 1 as well.
 static int run_pass_impl(zd_plan *pl, zd_comm *c, int pass, void *d_store, void *d_records, float *d_density, int64_t rec_planes,
+                         zd_group_cb cb, void *user, void *hip_stream) {
+    if (c && comm_failed(c)) return 1;
+    const int rc = run_pass_body(pl, c, pass, d_store, d_records, d_density, rec_planes, cb, user, hip_stream);
+    if (rc && c && pl->nranks > 1) {
+        if (c->failed) c->failed->store(1, std::memory_order_release);
+        if (c->kind == 0) zd_comm_abort(c);
+        if (c->kind == 1 && c->grp) c->grp->fail();
+    }
+    return rc;
+}
+
+static int run_pass_body(zd_plan *pl, zd_comm *c, int pass, void *d_store, void *d_records, float *d_density, int64_t rec_planes,
                          zd_group_cb cb, void *user, void *hip_stream) {
     hipStream_t st = (hipStream_t) hip_stream;
     const int ps = pl->pstep;
@@ -359,11 +440,7 @@ static int run_pass_impl(zd_plan *pl, zd_comm *c, int pass, void *d_store, void 
     // ---- ring ----
     int gp = 0;
     const int64_t ring_b = zd_plan_ring_bytes(pl, &gp);
-    if (!c->ring) {
-        MHIP(hipMalloc((void **) &c->ring, (size_t) ring_b));
-        c->slot_bytes   = ring_b / 2;
-        c->group_planes = gp;
-    }
+    if (comm_ring(c, ring_b, gp, st)) return 1;
     const int G = pl->nranks, me = pl->rank;
     const int64_t cpb = chunk_plane_bytes(pl), chunk_b = cpb * pl->Zq;
     const int ngroups = (pl->Zq + gp - 1) / gp;
@@ -399,6 +476,10 @@ static int run_pass_impl(zd_plan *pl, zd_comm *c, int pass, void *d_store, void 
             MHIP(hipMemcpyAsync(dst + (size_t) me * cpb * gp, (const char *) d_store + (size_t) me * chunk_b + (size_t) p0 * cpb, nb,
                                 hipMemcpyDeviceToDevice, c->s_comm));
         }
+        const int64_t moved = (int64_t) nb * (G - 1);
+        c->bytes_sent += moved;
+        c->bytes_received += moved;
+        pl->bytes_sent += moved;
         MHIP(hipEventRecord(c->ev_r[slot], c->s_comm));
         return 0;
     };
@@ -407,7 +488,10 @@ static int run_pass_impl(zd_plan *pl, zd_comm *c, int pass, void *d_store, void 
         if (j + 1 < ngroups && exchange(j + 1)) return 1;  // next group travels while this one is transformed
         const int slot = j & 1;
         const int64_t p0 = (int64_t) j * gp, np = std::min<int64_t>(gp, pl->Zq - p0);
+        if (comm_failed(c)) return 1;
+        zd_plan_tick(pl, ZD_K_XWAIT, st, 1);  // two events around the wait: their distance = the time the compute stream stood
         MHIP(hipStreamWaitEvent(st, c->ev_r[slot], 0));
+        zd_plan_tick(pl, ZD_K_XWAIT, st, 0);
         const void *src = c->ring + (size_t) slot * c->slot_bytes;
         if (zd_plan_stage_y_group(pl, const_cast<void *>(src), gp, (int) np, st)) return 1;
         // XY on the slot: chunks are gp planes long there
@@ -440,11 +524,7 @@ static int phi_round(zd_plan *ph, zd_comm *c, void *d_store, void *d_phik, doubl
     if (zd_plan_stage_z(ph, 0, d_store, st)) return 1;
     int gp = 0;
     const int64_t ring_b = zd_plan_ring_bytes(ph, &gp);
-    if (!c->ring) {
-        MHIP(hipMalloc((void **) &c->ring, (size_t) ring_b));
-        c->slot_bytes   = ring_b / 2;
-        c->group_planes = gp;
-    }
+    if (comm_ring(c, ring_b, gp, st)) return 1;
     const int G = ph->nranks, me = ph->rank;
     const int64_t cpb = chunk_plane_bytes(ph), chunk_b = cpb * ph->Zq;
     const int ngroups = (ph->Zq + gp - 1) / gp;
@@ -552,7 +632,7 @@ struct GroupSink {
     const float *d_dens;  // device density planes of the group (ZD_qdensity) or NULL
     float *h_dens;
     int64_t only_z;       // ZD_qoneslab: deliver just this z (-1: every plane)
-    int fail = 0;
+    const std::atomic<int> *failed = nullptr;  // the job's failure flag
 };
 
 int sink_cb(void *user, int64_t first_local_plane, int64_t nplanes, const void *d_records, void *hip_stream) {
@@ -563,6 +643,7 @@ int sink_cb(void *user, int64_t first_local_plane, int64_t nplanes, const void *
     if (s->plane_rec_b && hipMemcpyAsync(s->h_rec, d_records, s->plane_rec_b * (size_t) nplanes, hipMemcpyDeviceToHost, st) != hipSuccess) return 1;
     if (s->d_dens && hipMemcpyAsync(s->h_dens, s->d_dens, nn * 4 * (size_t) nplanes, hipMemcpyDeviceToHost, st) != hipSuccess) return 1;
     if (hipStreamSynchronize(st) != hipSuccess) return 1;
+    if (s->failed && s->failed->load(std::memory_order_acquire)) return 1;  // a peer failed: what arrived may be incomplete
     std::lock_guard<std::mutex> lock(s->dl->mu);
     for (int64_t i = 0; i < nplanes; i++) {
         const int64_t z = zd_plan_plane_z(s->pl, s->pass, first_local_plane + i);
@@ -614,8 +695,11 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
     std::vector<RankCtx> ctx(G);
     LocalGroup grp;
     std::vector<ncclComm_t> nccls(G, nullptr);
+#ifdef ZD_TESTING
     std::vector<LoopComm> loops(G);
+#endif
     if (transport == 2) {  // tests: the RCCL branch of the exchange on an in-process emulation of its calls
+#ifdef ZD_TESTING
         g_loop.n = G;
         g_loop.box.assign((size_t) G * G, {});
         g_loop.taken.assign((size_t) G * G, 0);
@@ -632,6 +716,10 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
             loops[g].n    = G;
             nccls[g]      = reinterpret_cast<ncclComm_t>(&loops[g]);
         }
+#else
+        fprintf(stderr, "zeldovich_hip: transport 2 is test scaffolding (-DZD_TESTING build only)\n");
+        return 1;
+#endif
     } else if (transport == 1) {
         grp.n = G;
         grp.send_base.assign(G, nullptr);
@@ -649,6 +737,25 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
     Delivery dl;
     dl.cb   = cb;
     dl.user = user;
+    // One failure flag for the job.  The rank that fails sets it and aborts EVERY communicator of the process (they are all
+    // here): the send / receive kernels its peers have queued for it drain instead of spinning, the peers' stream syncs
+    // return, they see the flag and leave.  Aborted communicators are freed by the abort, not destroyed again.
+    std::atomic<int> job_failed{0};
+    std::mutex abort_mu;
+    bool aborted = false;
+    auto abort_all = [&]() {
+        job_failed.store(1, std::memory_order_release);
+        grp.fail();
+        std::lock_guard<std::mutex> lk(abort_mu);
+        if (aborted || transport != 0) return;
+        aborted = true;
+        RcclApi *R = rccl();
+        for (int g = 0; g < G; g++)
+            if (nccls[g] && R && R->CommAbort) {
+                R->CommAbort(nccls[g]);
+                nccls[g] = nullptr;
+            }
+    };
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> threads;
     for (int g = 0; g < G; g++) {
@@ -672,6 +779,7 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
                 c->kind   = transport == 2 ? 0 : transport;  // the loopback emulation runs the RCCL branch
                 c->nccl   = nccls[g];
                 c->grp    = &grp;
+                c->failed = &job_failed;
                 if (comm_prepare(c)) break;
                 if (p.f_NL != 0.) {  // the phi round first (its own plan, store and ring), then the main plan reads PhiK
                     zd_plan *ph = nullptr;
@@ -691,8 +799,6 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
                     } while (0);
                     hipFree(d_phi);
                     if (ph) zd_plan_destroy(ph);
-                    hipFree(c->ring);  // sized for the phi plan: the main pass allocates its own
-                    c->ring = nullptr;
                     if (!ok) break;
                     if (zd_plan_create_phik(&p, pk, eig, eig_ppd, g, G, d_phik, &pl)) break;
                 } else if (zd_plan_create(&p, pk, eig, eig_ppd, g, G, &pl)) {
@@ -715,14 +821,15 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
                 if (want_dens && cb && hipHostMalloc((void **) &h_dens, nn * 4 * (size_t) rec_planes) != hipSuccess) break;
                 bool fail = false;
                 for (int pass = 0; pass < pl->npass && !fail; pass++) {
-                    GroupSink sink{pl, pass, &dl, h_rec, plane_rec_b, cb ? d_dens : nullptr, h_dens, -1};
+                    GroupSink sink{pl, pass, &dl, h_rec, plane_rec_b, cb ? d_dens : nullptr, h_dens, -1, &job_failed};
                     if (run_pass_impl(pl, c, pass, d_store, d_rec, d_dens, rec_planes, sink_cb, &sink, st)) fail = true;
                 }
                 if (fail) break;
                 if (zd_plan_stats(pl, &me.stats)) break;
+                if (job_failed.load(std::memory_order_acquire)) break;  // a peer failed: this rank's planes are not a result
                 me.rc = 0;
             } while (0);
-            if (me.rc) grp.fail();
+            if (me.rc) abort_all();
             if (st) hipStreamDestroy(st);
             hipFree(d_store);
             hipFree(d_rec);
@@ -730,13 +837,14 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
             hipFree(d_phik);
             if (h_rec) hipHostFree(h_rec);
             if (h_dens) hipHostFree(h_dens);
-            c->nccl = nullptr;  // destroyed below, after every thread has left RCCL
+            c->nccl = nullptr;  // destroyed (or aborted) by the driver, after every thread has left RCCL
             zd_comm_destroy(c);
             if (pl) zd_plan_destroy(pl);
         });
     }
     for (auto &t : threads) t.join();
     if (transport == 2) {
+#ifdef ZD_TESTING
         g_rccl_override = nullptr;
         for (auto &q : g_loop.box)
             for (LoopMsg &m : q) {
@@ -744,6 +852,7 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
                 if (m.done) hipEventDestroy(m.done);
             }
         g_loop.box.clear();
+#endif
     } else if (transport != 1)
         for (int g = 0; g < G; g++)
             if (nccls[g] && rccl()->CommDestroy) rccl()->CommDestroy(nccls[g]);
@@ -761,6 +870,7 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
             out->kernel_ms[k] = std::max(out->kernel_ms[k], ctx[g].stats.kernel_ms[k]);
             out->kernel_launches[k] += ctx[g].stats.kernel_launches[k];
         }
+        out->bytes_sent += ctx[g].stats.bytes_sent;
     }
     out->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return 0;

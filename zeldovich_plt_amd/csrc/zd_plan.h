@@ -74,8 +74,9 @@ struct zd_plan {
     // timing
     std::vector<EventPair> events;
     std::vector<hipEvent_t> pool;
-    double kernel_ms[ZD_K_COUNT] = {0, 0, 0, 0, 0};
-    int64_t launches[ZD_K_COUNT] = {0, 0, 0, 0, 0};
+    double kernel_ms[ZD_K_COUNT] = {};
+    int64_t launches[ZD_K_COUNT] = {};
+    int64_t bytes_sent = 0;  // N > 1 ranks: accounted by zd_plan_run_pass, reported and reset by zd_plan_stats
 };
 
 // internal entry points shared by zd_capi.cpp and zd_multi.cpp
@@ -89,6 +90,9 @@ int zd_plan_create_phik(const zd_params *p, const zd_pk *pk, const double *eig, 
                         zd_plan **out);
 int zd_plan_phi_xy_group(zd_plan *pl, void *d_slot, int chunk_planes, int nplanes, double f_NL, void *hip_stream);
 int zd_plan_phi_zfwd(zd_plan *pl, void *d_store, void *d_phik, void *hip_stream);
+// hipEvent pair around something on `hip_stream` that is not a kernel of this file (zd_multi.cpp: the wait for an exchanged
+// plane group); summed into kernel_ms[kind] by zd_plan_stats when the plan profiles
+void zd_plan_tick(zd_plan *pl, int kind, void *hip_stream, int begin);
 }
 int zd_generate_multi(const zd_params *p, const zd_pk *pk, const double *eig, int64_t eig_ppd, zd_slab_cb cb, void *user,
                       zd_stats *out, int transport);
