@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--no-isolated", action="store_true", help="skip the extra untimed pass that times every kernel alone")
     ap.add_argument("--format", default="RVZel")
     ap.add_argument("--stream", type=int, default=0, help="z-residue stream factor R (0 = auto)")
+    ap.add_argument("--groups", type=int, default=0,
+                    help="N > 1: independent groups of GPUs, residue passes dealt round-robin over them (0 = the library's choice: "
+                         "one GPU per group while there are at least N passes, else one group with the all-to-all exchange)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist", action="store_true",
                     help="take the N > 1 code path (torch.distributed RCCL group, zd.Comm id broadcast, per-rank gathers) whatever "
@@ -134,33 +137,41 @@ def main():
     recsize = zd.RECORD_DTYPES[fmt].itemsize
 
     free_b, total_b = torch.cuda.mem_get_info()
-    R = args.stream
-    if R <= 0:
-        budget = int(free_b) - (16 << 30)  # tables, ~3 GB of folded-input slabs, 8 GB record ring, runtime
-        if multi:  # every rank must arrive at the same R: use the smallest budget of the job
-            t = torch.tensor([budget], dtype=torch.int64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            budget = int(t.item())
-        import ctypes
-        R = zd.load_library().zd_choose_stream_factor(ctypes.byref(p), world, budget)
-        if R < 0:
-            raise SystemExit("PPD=%d does not fit %d GPU(s)" % (N, world))
+    import ctypes
+    from zeldovich_plt_amd.parallel import HipEngine, SlabPipeline, split_ranks
+    budget = int(free_b) - (16 << 30)  # tables, ~3 GB of folded-input slabs, 8 GB record ring, runtime
+    if multi:  # every rank must arrive at the same split and R: use the smallest budget of the job
+        t = torch.tensor([budget], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        budget = int(t.item())
+    # How the GPUs share the job (the library's policy, zd_choose_pass_groups): `groups` independent groups of gsz ranks;
+    # group j runs the residue passes j, j + groups, ...; inside a group the rows / planes are sharded with one exchange per pass
+    p.stream_factor = args.stream
+    p.pass_groups = args.groups
+    g_, R_ = ctypes.c_int32(), ctypes.c_int32()
+    if zd.load_library().zd_choose_pass_groups(ctypes.byref(p), world, budget, ctypes.byref(g_), ctypes.byref(R_)):
+        raise SystemExit("PPD=%d does not fit %d GPU(s)" % (N, world))
+    groups, R = g_.value, R_.value
     p.stream_factor = R
-    plan = zd.Plan(p, ps, eig=eig, rank=rank, nranks=world)
-    from zeldovich_plt_amd.parallel import HipEngine, SlabPipeline
+    grp_id, grank, gsz = split_ranks(rank, world, groups)
+    plan = zd.Plan(p, ps, eig=eig, rank=grank, nranks=gsz)
+    assert plan.passes % groups == 0
     comm = None
-    if multi:  # the library's own RCCL communicator; torch.distributed only carries the 128-byte id and the timing fences
+    if multi and (gsz > 1 or args.dist):
+        # the library's own RCCL communicator, one per group; torch.distributed only carries the 128-byte ids (rank 0 of every
+        # group makes one) and the timing fences
         def exchange_id(raw):
-            t = torch.tensor(list(raw), dtype=torch.uint8, device="cuda")
-            dist.broadcast(t, 0)
-            return bytes(t.cpu().tolist())
-        comm = zd.Comm(rank, world, exchange_id)
-    pipe = SlabPipeline(HipEngine(plan, N, comm=comm), N, world=world, dist=dist, device="cuda")
+            mine = torch.tensor(list(raw), dtype=torch.uint8, device="cuda")
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            return bytes(allr[grp_id * gsz].cpu().tolist())
+        comm = zd.Comm(grank, gsz, exchange_id)
+    pipe = SlabPipeline(HipEngine(plan, N, comm=comm), N, world=gsz, dist=dist, device="cuda")
 
     def step():
         # per residue pass, inside the library (zd_plan_run_pass): Z stage -> exchange in plane groups over RCCL/xGMI,
         # overlapped with -> y FFT -> x FFT + epilogue of the previous group
-        pipe.run()
+        pipe.run(pass_first=grp_id, pass_step=groups)
 
     def fence():
         torch.cuda.synchronize()
@@ -275,7 +286,9 @@ def main():
                 "stream_factor": R, "narray_reference": narray,
                 "store": ("fields E,Z of the half-space rows, zero columns not stored" if fields else
                           "%d arrays" % plan.narray), "passes": plan.passes,
-                "block_store_GB": plan.exchange_bytes / 1e9, "parallelism": "ky/z slabs x%d" % world},
+                "block_store_GB": plan.exchange_bytes / 1e9,
+                "parallelism": ("%d group(s) of %d GPU(s): residue passes round-robin over the groups%s" % (
+                    groups, gsz, ", ky/z slabs + one RCCL exchange per pass inside a group" if gsz > 1 else ", no exchange"))},
             "hbm_GBps_path": (64.0 * narray + recsize) * value / 1e9,
             "roofline_path_frac": (64.0 * narray + recsize) * value / 1e9 / (HBM_PEAK_GBS * world),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": du["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

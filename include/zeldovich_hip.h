@@ -61,7 +61,13 @@ typedef struct zd_params {
      * the field depend on `numblock` — pass the value AFTER the reader's adjustment numblock = numblock * k_cutoff + .5
      * (src/parameters.cpp:129-141; zd_read_params does it) --- */
     int32_t version;
-    int32_t reserved_;
+    int32_t pass_groups;   /* ZD_PassGroups, with ngpu > 1: the GPUs work as `pass_groups` independent groups of ngpu / pass_groups
+                            * ranks; group j takes the residue passes j, j + pass_groups, ... and nothing travels between
+                            * groups (the z-residue classes of the streaming are independent partitions of the output).
+                            * Inside a group the rows / planes are sharded with the exchange described below.  0 = automatic:
+                            * one GPU per group while the job has at least ngpu passes (2 and 4 GPUs at PPD = 4096: no
+                            * exchange at all, where a pairwise exchange would be bound by ONE xGMI link), else one group
+                            * of all GPUs (the all-to-all of 8 GPUs, every link of the mesh busy) */
 } zd_params;
 
 /* zd_params.store_mode */
@@ -129,6 +135,11 @@ int zd_generate(const zd_params *p, const zd_pk *pk, const double *eig, int64_t 
 /* Smallest power-of-two stream factor R whose block store of one pass (+ the y->x ring of the field store, + the exchange
  * ring for nranks > 1) fits in budget_bytes; -1 if none. */
 int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes);
+/* How `ngpu` GPUs share the job (zd_params.pass_groups, 0 = automatic): *groups independent groups of ngpu / *groups ranks
+ * and the stream factor *stream_factor whose number of passes is a multiple of *groups (budget_bytes: free HBM per rank, as
+ * for zd_choose_stream_factor).  zd_generate applies it; one-process-per-GPU drivers call it so that every rank arrives at
+ * the same split.  Returns non-zero if nothing fits. */
+int zd_choose_pass_groups(const zd_params *p, int ngpu, int64_t budget_bytes, int32_t *groups, int32_t *stream_factor);
 
 /* ---- staged API (device pointers) for one-process-per-GPU drivers and for tests ---------------
  * Rank `rank` of `nranks` (a power of two) owns the half-space rows ky = rank, rank + nranks, ... (H = ppd/2/nranks

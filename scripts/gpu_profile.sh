@@ -53,5 +53,5 @@ cat $(find $R/gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1) | head -
 cp gpurun_out/traffic_$TAG.json profiles/traffic_latest.json
 timeout 900 python bench.py $ARGS 2>&1 | tail -1 > gpurun_out/bench_$TAG.json; python3 -c "
 import json;d=json.load(open('gpurun_out/bench_$TAG.json'));print(d['value'],d['ms_per_step'],d['roofline_path_frac']);print(d['cpu_baseline']);print(d['roofline']);print(d['kernels_isolated'])"
-cp gpurun_out/bench_$TAG.json gpurun_out/prof_${TAG}_bench.log gpurun_out/pmc_${TAG}_*_summary.csv gpurun_out/traffic_$TAG.json gpurun_out/ 2>/dev/null
-find gpurun_out/prof_$TAG -name "*kernel_stats.csv" -exec cp {} gpurun_out/${TAG}_kernel_stats.csv \;
+# (everything stays under gpurun_out/, which gpurun merges back; the summaries are copied into profiles/ by hand afterwards)
+i=0; for f in $(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | sort); do cp $f gpurun_out/${TAG}_kernel_stats$([ $i -gt 0 ] && echo _$i).csv; i=$((i+1)); done

@@ -12,10 +12,10 @@ p = zd.make_params(N, icformat="RVZel", profile=1, stream_factor=int(os.environ.
 nplanes = int(os.environ.get("PLANES", "32"))
 store = None
 ref = None
-VARS = [("default", {}), ("W/2", {"ZD_YW": str(2 if N == 4096 else 4)}), ("persistent", {"ZD_YPERSIST": "1"}),
-        ("W/2 persistent", {"ZD_YW": str(2 if N == 4096 else 4), "ZD_YPERSIST": "1"}), ("default", {})]
+VARS = [("default", {}), ("same row order", {"ZD_PRUNE": str(7 | 2048)}), ("W/2", {"ZD_YW": str(2 if N == 4096 else 4)}),
+        ("persistent", {"ZD_YPERSIST": "1"}), ("default", {}), ("same row order", {"ZD_PRUNE": str(7 | 2048)})]
 for name, env in VARS:
-    for k in ("ZD_YW", "ZD_YPERSIST"):
+    for k in ("ZD_YW", "ZD_YPERSIST", "ZD_PRUNE"):
         os.environ.pop(k, None)
     os.environ.update(env)
     plan = zd.Plan(p, ps)

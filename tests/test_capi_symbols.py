@@ -103,3 +103,22 @@ def test_trans_hazard_checker_detects_back_to_back_use():
 """
     n, viol = m.check(bad)
     assert n == 3 and len(viol) == 1 and "v_rcp_f64" in viol[0][1]
+
+
+def test_choose_pass_groups_policy():
+    """PPD = 4096 ZA on 288 GB GPUs: 4 passes on one rank -> 2 and 4 GPUs run one GPU per group (no exchange); 8 GPUs run as ONE
+    group (the all-to-all of BASELINE config 4) unless ZD_PassGroups asks otherwise"""
+    import ctypes as C
+    import zeldovich_plt_amd.api as zd
+    L = zd.load_library()
+    budget = (288 - 32) << 30
+    for ngpu, want_g in ((1, 1), (2, 2), (4, 4), (8, 1)):
+        p = zd.make_params(4096, icformat="RVZel", numblock=64)
+        g, R = C.c_int32(), C.c_int32()
+        assert L.zd_choose_pass_groups(C.byref(p), ngpu, budget, C.byref(g), C.byref(R)) == 0
+        assert g.value == want_g, (ngpu, g.value, R.value)
+        assert (R.value // 2) % g.value == 0
+    p = zd.make_params(4096, icformat="RVZel", numblock=64, pass_groups=8)
+    g, R = C.c_int32(), C.c_int32()
+    assert L.zd_choose_pass_groups(C.byref(p), 8, budget, C.byref(g), C.byref(R)) == 0
+    assert g.value == 8 and R.value == 16  # eight passes, one per GPU

@@ -201,7 +201,7 @@ def test_ppd16384_k_cutoff4_planes_equal_ppd4096(zd):
 
 
 @pytest.mark.parametrize("n,kc,Ra,Rb,modes", [
-    (2048, 1.0, 2, 4, [(3, 5, -7), (-601, 577, 800), (0, 2, 0)]),        # BASELINE C3: packed PLT arrays (k_genf PLTN / k_zfft / k_yfft / k_xfft)
+    (2048, 1.0, 2, 4, [(3, 5, -7), (-401, 577, 600), (0, 2, 0)]),          # BASELINE C3: packed PLT arrays (k_genf PLTN / k_zfft / k_yfft / k_xfft)
     (8192, 2.0, 64, 128, [(3, 5, -7), (-1001, 777, 1200), (0, 2, 0)]),   # k_xfft_two<8192, PLT>
     (6912, 4.0, 8, 16, [(3, 5, -7), (-401, 377, 500)]),                  # composite kernels, x pass in two launches
     (3456, 2.0, 4, 8, [(-3, 5, 7), (401, 377, -500)]),                   # composite kernels, three lines per workgroup

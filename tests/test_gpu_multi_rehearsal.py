@@ -83,3 +83,23 @@ def test_multi_rank_driver_twice_in_one_process_reports_traffic(zd, oracle):
         plan = zd.Plan(p, ps, rank=0, nranks=2)
         assert got["bytes_sent"] == 2 * plan.passes * plan.exchange_bytes // 2  # 2 ranks x passes x half a store each
         plan.close()
+
+
+@pytest.mark.parametrize("n,ngpu,groups,kw", [
+    (128, 2, 0, dict(stream_factor=4)),                       # automatic: 2 passes (ZA field store) >= 2 GPUs -> one GPU per group, no exchange
+    (256, 4, 2, dict(stream_factor=8, exchange_planes=3)),    # two groups of two ranks: exchange inside a group only
+    (256, 4, 4, dict(stream_factor=8)),
+    (128, 2, 2, dict(stream_factor=2, store_mode="reference", qdensity=1)),  # density planes, reductions from the planes
+    (128, 2, 2, dict(stream_factor=2, qPLT=1, qPLTrescale=1, PLT_target_z=5.0, z_initial=49.0)),
+])
+def test_pass_groups_vs_oracle(zd, oracle, n, ngpu, groups, kw):
+    """ZD_PassGroups: the GPUs as independent groups, residue passes dealt round-robin over them (zd_multi.cpp; threads sharing
+    the one device here): every record, max_disp and density_variance against the oracle"""
+    from test_gpu_parity import _compare
+    ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
+    opk = oracle.pk_from_file(WMAP, 720.0)
+    eig = oracle.synthetic_eigenmodes(32) if kw.get("qPLT") else None
+    got, _ = _compare(zd, oracle, ps, opk, n, eig=eig, ngpu=ngpu, pass_groups=groups, **kw)
+    assert sorted(got["planes_seen"]) == list(range(n))
+    if groups == ngpu or groups == 0:
+        assert got["bytes_sent"] == 0  # one rank per group: nothing is exchanged

@@ -103,6 +103,7 @@ def _compare(zd, oracle, ps, opk, n, fmt="RVdoubleZel", eig=None, tie_ok=False, 
     okw.pop("store_mode", None)
     okw.pop("ngpu", None)
     okw.pop("exchange_planes", None)
+    okw.pop("pass_groups", None)
     if "corner_modes" in okw:
         okw["CornerModes"] = okw.pop("corner_modes")
     op = oracle.make_params(n, numblock=okw.pop("numblock", 2), icformat=fmt, **okw)

@@ -35,7 +35,7 @@ class ZdParams(C.Structure):
         ("stream_factor", C.c_int32), ("profile", C.c_int32),
         ("store_mode", C.c_int32), ("serial_z", C.c_int32), ("ngpu", C.c_int32), ("exchange_planes", C.c_int32),
         ("f_NL", C.c_double), ("n_s", C.c_double), ("Omega_M", C.c_double),
-        ("version", C.c_int32), ("reserved_", C.c_int32),
+        ("version", C.c_int32), ("pass_groups", C.c_int32),
     ]
 
 
@@ -78,7 +78,7 @@ EXPORTED_SYMBOLS = [
     "zd_plan_stream_factor", "zd_plan_passes", "zd_plan_plane_step", "zd_plan_record_size", "zd_plan_exchange_bytes", "zd_plan_local_planes",
     "zd_plan_plane_z", "zd_plan_stage_z", "zd_plan_stage_y", "zd_plan_stage_x", "zd_plan_stats", "zd_comm_unique_id", "zd_comm_create", "zd_comm_destroy", "zd_plan_ring_bytes", "zd_plan_run_pass",
     "zd_params_from_file", "zd_pk_create_from_file", "zd_pk_create_powerlaw", "zd_pk_power",
-    "zd_pk_sigmaR", "zd_pk_destroy", "zd_load_eigmodes", "zd_free", "zd_comm_abort", "zd_comm_traffic",
+    "zd_pk_sigmaR", "zd_pk_destroy", "zd_load_eigmodes", "zd_free", "zd_comm_abort", "zd_comm_traffic", "zd_choose_pass_groups",
 ]
 # test scaffolding: exists only in the -DZD_TESTING library (csrc/zd_testing.h, `make testing`), never in the product
 TESTING_SYMBOLS = ["zd_test_draws", "zd_test_modes", "zd_test_modes_table", "zd_test_v1_words", "zd_test_generate_loopback",
@@ -129,6 +129,7 @@ def _load(path, testing):
         L.zd_test_v1_words.argtypes = [i64, C.c_int32, vp]
         L.zd_test_fft.argtypes = [i32, i64, i32, vp, vp]
     L.zd_choose_stream_factor.argtypes = [C.POINTER(ZdParams), C.c_int, i64]
+    L.zd_choose_pass_groups.argtypes = [C.POINTER(ZdParams), C.c_int, i64, C.POINTER(i32), C.POINTER(i32)]
     L.zd_plan_create.argtypes = [C.POINTER(ZdParams), C.POINTER(ZdPk), vp, i64, C.c_int, C.c_int, C.POINTER(vp)]
     L.zd_plan_destroy.argtypes = [vp]
     L.zd_plan_destroy.restype = None
@@ -175,7 +176,7 @@ def make_params(ppd, numblock=2, boxsize=720.0, seed=12346, k_cutoff=1.0, qPLT=0
                 PLT_target_z=0.0, z_initial=49.0, f_cluster=1.0, icformat="RVdoubleZel", qdensity=0,
                 qoneslab=-1, qonemode=0, one_mode=(0, 0, 0), corner_modes=0, cpd=None, stream_factor=0,
                 profile=0, f_NL=0.0, n_s=1.0, Omega_M=1.0, store_mode="auto", serial_z=0, ngpu=0, exchange_planes=0,
-                version=2):
+                version=2, pass_groups=0):
     """Parameters with the derived quantities of Parameters::setup (src/parameters.cpp:172-174); version = 1 (legacy
     mt19937 streams) adjusts NumBlock by k_cutoff as the reader does (src/parameters.cpp:129-141)."""
     p = ZdParams()
@@ -207,6 +208,7 @@ def make_params(ppd, numblock=2, boxsize=720.0, seed=12346, k_cutoff=1.0, qPLT=0
     p.serial_z = serial_z
     p.ngpu = ngpu
     p.exchange_planes = exchange_planes
+    p.pass_groups = pass_groups
     p.f_NL, p.n_s, p.Omega_M = f_NL, n_s, Omega_M
     return p
 

@@ -384,6 +384,59 @@ int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes
     return np2 ? any_factor() : -1;
 }
 
+// planes a store plane delivers for (p, R) on `nranks` ranks: 2 with the ZA packings (plan_create_ex's choice of store)
+static int plan_plane_step(const zd_params *p, int R, int nranks) {
+    const int64_t N = p->ppd;
+    if (!is_pow2(N)) {  // composite kernels (field stores) or the convolution path (reference arrays)
+        const bool comp = zd::np2_supported_ppd((int) N) && p->f_NL == 0. && is_pow2(R) && N % R == 0 && zd::np2_supported_zlen((int) (N / R))
+                          && zd::pack_is_fields(pack_mode(p, R)) && (N / 2) % (nranks * zd::FIELD_RB) == 0;
+        if (!comp) return 1;
+    }
+    int pm = pack_mode(p, R);
+    if (zd::pack_is_fields(pm) && (((N / 2) / nranks) % zd::FIELD_RB || N / R > 2048))
+        pm = N > 4096 ? zd::PACK_NONE : (pm == zd::PACK_PLTFIELD ? zd::PACK_PLT3 : zd::PACK_ZAPAIR);
+    return (pm == zd::PACK_ZAPAIR || pm == zd::PACK_ZAFIELD) ? 2 : 1;
+}
+
+int zd_choose_pass_groups(const zd_params *p, int ngpu, int64_t budget_bytes, int32_t *groups, int32_t *stream_factor) {
+    if (ngpu < 1) ngpu = 1;
+    int g = p->pass_groups;
+    if (g < 0 || (g > 0 && ngpu % g)) {
+        fprintf(stderr, "zeldovich_hip: ZD_PassGroups = %d does not divide ZD_NumGPU = %d\n", g, ngpu);
+        return 1;
+    }
+    if (p->f_NL != 0.) g = g > 0 ? g : 1;  // the phi round is one collective job
+    if (g > 1 && p->f_NL != 0.) {
+        fprintf(stderr, "zeldovich_hip: ZD_f_NL != 0 runs as one group of ranks (ZD_PassGroups = 1)\n");
+        return 1;
+    }
+    if (g == 0) {  // automatic: one GPU per group while a single rank's job has that many passes
+        g = 1;
+        zd_params q = *p;
+        const int R1 = q.stream_factor > 0 ? q.stream_factor : zd_choose_stream_factor(&q, 1, budget_bytes);
+        if (R1 > 0 && ngpu > 1) {
+            const int np1 = R1 / plan_plane_step(&q, R1, 1);
+            if (np1 >= ngpu && np1 % ngpu == 0) g = ngpu;
+        }
+    }
+    const int gsz = ngpu / g;
+    int R = p->stream_factor > 0 ? p->stream_factor : zd_choose_stream_factor(p, gsz, budget_bytes);
+    if (R < 0) return 1;
+    // the passes must deal out evenly over the groups: a larger stream factor (smaller stores) always fits
+    while ((R / plan_plane_step(p, R, gsz)) % g) {
+        if (p->stream_factor > 0) {
+            fprintf(stderr, "zeldovich_hip: ZD_StreamFactor = %d gives %d passes, not a multiple of the %d pass groups\n", R,
+                    R / plan_plane_step(p, R, gsz), g);
+            return 1;
+        }
+        R *= 2;
+        if (p->ppd % R || p->ppd / R < 32 || (p->ppd / R) % gsz) return 1;
+    }
+    *groups        = g;
+    *stream_factor = R;
+    return 0;
+}
+
 // phi_mode 1: first f_NL pass (one array holding phi = D/M); phik != NULL: second pass (D = phik * M)
 static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig, int64_t eig_ppd, int rank, int nranks,
                           int phi_mode, const cplx *phik, zd_plan **out);

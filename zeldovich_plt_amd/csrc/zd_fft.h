@@ -191,6 +191,45 @@ ZD_HD void pass_compute(double (&re)[PL::E], double (&im)[PL::E], int t, const c
     dft_all<R, B, E>(re, im);
 }
 
+// The inter-pass twiddles w1 of a thread depend on its index only: a caller that has to wait for its input data anyway
+// can fetch them up front (TwSet / load_twiddles) and run fft_line with them, instead of two or three dependent loads
+// from the table in the middle of the transform.
+// (Only passes with at most two butterflies per thread are fetched ahead — the full-radix ones: a short last pass has E/2
+// twiddles per thread, more registers than the wait is worth.)
+template <class PL>
+struct TwSet {
+    static constexpr bool ahead(int p) { return PL::E / PL::radix(p) <= 2; }
+    cplx v[PL::NPASS][2];  // [pass][q]; pass 0 has none
+};
+template <class PL, int P = 1>
+ZD_HD void load_twiddles(TwSet<PL> &T, int t, const cplx *__restrict__ tw) {
+    if constexpr (P < PL::NPASS) {
+        constexpr int E = PL::E, R = PL::radix(P), B = E / R, NS = PL::ns(P), N = PL::N;
+        if constexpr (TwSet<PL>::ahead(P)) {
+#pragma unroll
+            for (int q = 0; q < B; q++) T.v[P][q] = tw[((t + q * PL::T) & (NS - 1)) * (N / (NS * R))];
+        }
+        load_twiddles<PL, P + 1>(T, t, tw);
+    }
+}
+template <class PL, int P>
+ZD_HD void pass_compute_tw(double (&re)[PL::E], double (&im)[PL::E], int t, const cplx *__restrict__ tw, const TwSet<PL> &T) {
+    constexpr int E = PL::E, R = PL::radix(P), B = E / R;
+    if constexpr (P > 0 && !TwSet<PL>::ahead(P)) {
+        pass_compute<PL, P>(re, im, t, tw);
+    } else {
+        if constexpr (P > 0) {
+#pragma unroll
+            for (int q = 0; q < B; q++) {
+                const cplx w1 = T.v[P][q];
+                const double w2r = w1.x * w1.x - w1.y * w1.y, w2i = 2.0 * w1.x * w1.y;
+                twiddle_chain<R, B, E, 1>(re, im, q, w1.x, w1.y, w2r, w2i, 1.0, 0.0);
+            }
+        }
+        dft_all<R, B, E>(re, im);
+    }
+}
+
 // Where output r of butterfly j (pass P) lives in the natural-order line.
 template <class PL, int P>
 ZD_HD int out_index(int t, int q, int r) {
@@ -277,6 +316,23 @@ __device__ __forceinline__ void fft_line(double (&re)[PL::E], double (&im)[PL::E
         xchg_read<PL, LDS>(im, t, w, lds);
         __syncthreads();
         fft_line<PL, LDS, P + 1>(re, im, t, w, lds, tw);
+    }
+}
+// the same with the twiddles already in registers (load_twiddles)
+template <class PL, class LDS, int P = 0>
+__device__ __forceinline__ void fft_line_tw(double (&re)[PL::E], double (&im)[PL::E], int t, int w, double *lds,
+                                            const cplx *__restrict__ tw, const TwSet<PL> &T) {
+    pass_compute_tw<PL, P>(re, im, t, tw, T);
+    if constexpr (P + 1 < PL::NPASS) {
+        xchg_write<PL, P, LDS>(re, t, w, lds);
+        __syncthreads();
+        xchg_read<PL, LDS>(re, t, w, lds);
+        __syncthreads();
+        xchg_write<PL, P, LDS>(im, t, w, lds);
+        __syncthreads();
+        xchg_read<PL, LDS>(im, t, w, lds);
+        __syncthreads();
+        fft_line_tw<PL, LDS, P + 1>(re, im, t, w, lds, tw, T);
     }
 }
 #endif

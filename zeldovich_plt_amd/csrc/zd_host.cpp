@@ -616,6 +616,7 @@ int zd_params_from_file(const char *path, zd_params *p, zd_param_strings *s) {
     I("ZD_StreamFactor", p->stream_factor);
     I("ZD_NumGPU", p->ngpu);  // GPUs of this node to drive (default: 1)
     I("ZD_ExchangePlanes", p->exchange_planes);
+    I("ZD_PassGroups", p->pass_groups);  // independent groups of GPUs, residue passes dealt round-robin (0: automatic)
     (void) have_cpd;
     p->cpd = cpd;
 

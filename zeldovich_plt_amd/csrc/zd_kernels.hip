@@ -1451,6 +1451,14 @@ __global__ __launch_bounds__(NC *FIELD_RB *L / E) void k_zfft_f(FieldLayout F, S
 // Output: ring[plane][a][row slot][x] in the single-rank block-store layout k_xfft reads.
 //   grid: (3*N/W, 1, planes)   block: W*N/E
 // One (plane pz of the launch, workgroup index id) unit of the y stage; all threads of the workgroup call it.
+// TWO: the array is made of two potentials (a = 2, and every PLT array).  Compiled as two separate bodies so that the
+// one-potential arrays (two thirds of the ZA workgroups) keep their E loads in flight without the register pressure of the
+// second potential's batches.
+template <int N, int E, int W, bool TWO>
+__device__ __forceinline__ void yfft_f_unit_t(const FieldLayout &F, const StoreLayout &S, const cplx *__restrict__ tw,
+                                              const cplx *__restrict__ store, int plane0, int ring_pitch, cplx *__restrict__ ring,
+                                              int tile, int a, int pz, int unit, int t, int w, double *lds);
+
 template <int N, int E, int W>
 __device__ __forceinline__ void yfft_f_unit(const FieldLayout &F, const StoreLayout &S, const cplx *__restrict__ tw,
                                             const cplx *__restrict__ store, int plane0, int ring_pitch, cplx *__restrict__ ring,
@@ -1476,9 +1484,22 @@ __device__ __forceinline__ void yfft_f_unit(const FieldLayout &F, const StoreLay
         tile = id % NT;
         a    = id / NT;
     }
+    const int unit = pz * 3 * NT + id;
+    if (F.nfield == 6 || a == 2)  // workgroup-uniform
+        yfft_f_unit_t<N, E, W, true>(F, S, tw, store, plane0, ring_pitch, ring, tile, a, pz, unit, t, w, lds);
+    else
+        yfft_f_unit_t<N, E, W, false>(F, S, tw, store, plane0, ring_pitch, ring, tile, a, pz, unit, t, w, lds);
+}
+
+template <int N, int E, int W, bool TWO>
+__device__ __forceinline__ void yfft_f_unit_t(const FieldLayout &F, const StoreLayout &S, const cplx *__restrict__ tw,
+                                              const cplx *__restrict__ store, int plane0, int ring_pitch, cplx *__restrict__ ring,
+                                              int tile, int a, int pz, [[maybe_unused]] int unit, int t, int w, double *lds) {
+    using PL  = zdfft::Plan<N, E>;
+    using LDS = zdfft::ColsInner<N, W>;
+    constexpr int T = PL::T;
     const int x = tile * W + w, xm = (N - x) & (N - 1);
     const int zl = plane0 + pz;
-    [[maybe_unused]] const int unit = pz * 3 * NT + id;
 #ifdef ZD_TUNING
     if (zd_stamps && threadIdx.x == 0) {
         zd_stamps[(size_t) unit * 8 + 6] = __builtin_amdgcn_s_memrealtime();
@@ -1490,67 +1511,119 @@ __device__ __forceinline__ void yfft_f_unit(const FieldLayout &F, const StoreLay
     const int kx = x > N / 2 ? x - N : x;
     // potentials this array is made of.  ZA: E_a alone (a < 2), or (Z_0, Z_1).  PLT: the pairs (X, fX), (Y, Z), (fY, fZ) of
     // the fields X, Y, Z, fX, fY, fZ — every array is i P - Q like the ZA one of two
-    const bool plt = F.nfield == 6, two = plt || a == 2;
+    const bool plt = F.nfield == 6;
+    constexpr bool two = TWO;
     const int f0 = plt ? (a == 0 ? 0 : (a == 1 ? 1 : 4)) : (a == 2 ? 1 : 2 * a);
     const int f1 = plt ? (a == 0 ? 3 : (a == 1 ? 2 : 5)) : 3;
     const cplx *p0 = store + (long long) (zl * F.nfield + f0) * F.field_elems;
     const long long d01 = two ? (long long) (f1 - f0) * F.field_elems : 0;
     const int gmask = (1 << F.lG) - 1;
     double re[E], im[E];
-    // Branch-free in three steps so that the loads of many rows are in flight together (as `if (!skip) { table load,
-    // two data loads, combine }` the compiler emitted one branch and one full wait per row: 1.65x the time of k_yfft):
-    // (1) the row records of all E rows, (2) in batches of BATCH rows the two potentials, from a clamped (always valid)
-    // address, (3) combine, zero for skipped rows.
-    FieldRow rows[E];
-#pragma unroll
-    for (int e = 0; e < E; e++) {
-        const int y = t + T * e;
-        int kyp = y > N / 2 ? N - y : y;
-        kyp = kyp < N / 2 ? kyp : N / 2 - 1;  // the Nyquist row is never used: any valid record
-        rows[e] = F.rows[(kyp >> F.lG) / FIELD_RB];  // the row block
-    }
-    ZD_STAMP(1, unit, true);  // row records in
-    constexpr int BATCH = 4;
-#pragma unroll
-    for (int b = 0; b < E; b += BATCH) {
-        cplx u[BATCH], v[BATCH];
-        bool skip[BATCH];
-#pragma unroll
-        for (int j = 0; j < BATCH; j++) {
-            const int e = b + j, y = t + T * e;
-            const bool mir = y > N / 2;
-            const int kyp = mir ? N - y : y;  // the half-space row that holds the data
-            const int xs  = (mir && !ZD_TUNE(S.prune & 1024)) ? xm : x;  // bit 10: tuning ablation (aligned mirror reads)
-            skip[j] = (y == N / 2) || ((S.prune & 4) && column_is_zero(S, kx, kyp));
-            const int split = rows[e].split, gap = rows[e].gap;
-            // skipped rows read element 0 of the chunk image (their own record may describe an empty row at the very end)
-            const unsigned off = skip[j] ? 0u : (unsigned) rows[e].base + (unsigned) (xs < split ? xs : xs - gap) * FIELD_RB
-                                                    + (unsigned) ((kyp >> F.lG) & (FIELD_RB - 1));
-            const cplx *q = p0 + ((long long) (kyp & gmask) * F.chunk_elems + off);
-            u[j] = q[0];
-            if (two) v[j] = q[d01];  // workgroup-uniform: the ZA arrays of one potential issue one load per row
+    // Where the time went (in-kernel stamps, PPD = 4096: 59 k cycles per workgroup): 6 k waiting for the row records, 32 k for
+    // the potentials in four dependent batches of 4 rows, 21 k in the transform (2 k of it the two table twiddles), 3 k for the
+    // stores.  One workgroup fills a CU, so nothing else runs while it waits: every wait is taken ONCE, with everything the
+    // workgroup will need already requested —
+    //   (1) the row-block table (8 B x Hq/8 blocks) goes to LDS behind the transform's area: one coalesced load per thread
+    //       instead of 16 scattered dependent ones; the twiddles of the later passes are requested at the same time;
+    //   (2) all E rows of the first potential are loaded straight into re / im (64 registers: the ones the transform uses
+    //       anyway), skipped rows from a clamped, always valid address; a second potential follows in two half batches;
+    //   (3) combine in place, zero for skipped rows.
+    FieldRow *rtab = reinterpret_cast<FieldRow *>(lds + LDS::SIZE);
+    const int nblk = (S.Hq + FIELD_RB - 1) / FIELD_RB;
+    for (int i = threadIdx.x; i < nblk; i += W * T) rtab[i] = F.rows[i];
+    zdfft::TwSet<PL> twp;
+    zdfft::load_twiddles<PL>(twp, t, tw);
+    // which rows are skipped — integer arithmetic, done while the table is on its way.  column_is_zero's comparison
+    // double(kx^2 + ky^2) * fund2 >= k2_cutoff is monotonic in the integer: c2 = the smallest integer that satisfies it
+    unsigned skipm = 1u << ((N / 2 - t) / T);  // the Nyquist row y = N/2 is thread 0's (bit E/2; other threads: a bit they do not own)
+    if (t != 0) skipm = 0;
+    if (S.prune & 4) {
+        int c2 = 0x7fffffff;
+        if (S.k2_cutoff > 0) {
+            int m = (int) (S.k2_cutoff / S.fund2);
+            while (m > 0 && (double) m * S.fund2 >= S.k2_cutoff) m--;
+            while ((double) m * S.fund2 < S.k2_cutoff) m++;
+            c2 = m;
         }
+        const int akx = kx < 0 ? -kx : kx, kx2 = kx * kx;
 #pragma unroll
-        for (int j = 0; j < BATCH; j++) {
-            const int e = b + j, y = t + T * e;
-            const bool mir = y > N / 2;
-            const double s = mir ? -1.0 : 1.0;
-            double vr, vi;
-            if (two) {  // (u, v) = (Z_0, Z_1) or a PLT pair (P, Q):  i u - v,  mirrored -i conj u + conj v (anti-Hermitian sums)
-                vr = -u[j].y - s * v[j].x;
-                vi = s * u[j].x - v[j].y;
-            } else {  // u = E_r:  (i kx - ky) u,  mirrored (i kx + (N - y)) conj u
-                const double dky = (double) (mir ? N - y : y), dkx = (double) kx;
-                vr = -s * (dky * u[j].x + dkx * u[j].y);
-                vi = dkx * u[j].x - dky * u[j].y;
+        for (int e = 0; e < E; e++) {
+            const int y = t + T * e, kyp = y > N / 2 ? N - y : y;
+            if (akx == S.kmax || kyp == S.kmax || kx2 + kyp * kyp >= c2) skipm |= 1u << e;
+        }
+    }
+    __syncthreads();
+    ZD_STAMP(1, unit, false);  // row records in
+    // element of row slot e inside the (plane, field) image of its chunk (32 bits: an image is < 2^32 elements) + the chunk
+    // (= source rank, several ranks only); skipped rows read element 0 of their chunk (their own record may describe an empty
+    // row at the very end).  `tt` is the thread's line index through a register the compiler cannot see through: each phase
+    // below gets its own, so that the address arithmetic of a later phase is not hoisted above the loads of an earlier one
+    // (the scheduler did, and spilled 60-90 registers around the loads).
+    auto locate = [&](int tt, int e) -> long long {
+        const int y = tt + T * e;
+        const bool mir = y > N / 2;
+        int kyp = mir ? N - y : y;            // the half-space row that holds the data
+        kyp = kyp < N / 2 ? kyp : N / 2 - 1;  // the Nyquist row is never used: any valid record
+        const FieldRow row = rtab[(kyp >> F.lG) / FIELD_RB];
+        const int xs = (mir && !ZD_TUNE(S.prune & 1024)) ? xm : x;  // bit 10: tuning ablation (aligned mirror reads)
+        const unsigned off = (unsigned) row.base + (unsigned) (xs < row.split ? xs : xs - row.gap) * FIELD_RB + (unsigned) ((kyp >> F.lG) & (FIELD_RB - 1));
+        return (long long) (kyp & gmask) * F.chunk_elems + (((skipm >> e) & 1u) ? 0u : off);
+    };
+    // (Measured and dropped: the tiles of the upper half issuing their rows in the opposite order, so that a tile and its mirror
+    // tile — whose mirrored rows are the other's direct rows — ask for the same lines at the same point of their load phase:
+    // y stage 724 -> 817 ms at PPD = 4096.)
+    {
+        int ta = t;
+        asm volatile("" : "+v"(ta));
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const cplx u = p0[locate(ta, e)];
+            re[e] = u.x;
+            im[e] = u.y;
+        }
+    }
+    if constexpr (TWO) {  // (u, v) = (Z_0, Z_1) or a PLT pair (P, Q):  i u - v,  mirrored -i conj u + conj v
+#ifndef ZD_YHB
+#define ZD_YHB (E / 2)
+#endif
+        constexpr int HB = ZD_YHB;
+        const cplx *p1 = p0 + d01;
+#pragma unroll
+        for (int b = 0; b < E; b += HB) {
+            cplx v[HB];
+            int tb = t;
+            asm volatile("" : "+v"(tb));
+#pragma unroll
+            for (int j = 0; j < HB; j++) v[j] = p1[locate(tb, b + j)];
+            asm volatile("" : "+v"(tb));
+#pragma unroll
+            for (int j = 0; j < HB; j++) {
+                const int e = b + j, y = tb + T * e;
+                const double s = y > N / 2 ? -1.0 : 1.0;
+                const double ur = re[e], ui = im[e];
+                const bool skip = (skipm >> e) & 1u;
+                re[e] = skip ? 0.0 : -ui - s * v[j].x;
+                im[e] = skip ? 0.0 : s * ur - v[j].y;
             }
-            re[e] = skip[j] ? 0.0 : vr;
-            im[e] = skip[j] ? 0.0 : vi;
+        }
+    } else {  // u = E_r:  (i kx - ky) u,  mirrored (i kx + (N - y)) conj u
+        const double dkx = (double) kx;
+        int tc = t;
+        asm volatile("" : "+v"(tc));
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int y = tc + T * e;
+            const bool mir = y > N / 2;
+            const double s = mir ? -1.0 : 1.0, dky = (double) (mir ? N - y : y);
+            const double ur = re[e], ui = im[e];
+            const bool skip = (skipm >> e) & 1u;
+            re[e] = skip ? 0.0 : -s * (dky * ur + dkx * ui);
+            im[e] = skip ? 0.0 : dkx * ur - dky * ui;
         }
     }
     if (ZD_TUNE(S.prune & 4096) && a == 2) return;                           // bit 12: tuning ablation (no x array)
     ZD_STAMP(2, unit, true);  // potentials in
-    if (!ZD_TUNE(S.prune & 128)) zdfft::fft_line<PL, LDS>(re, im, t, w, lds, tw);  // bit 7: tuning ablation
+    if (!ZD_TUNE(S.prune & 128)) zdfft::fft_line_tw<PL, LDS>(re, im, t, w, lds, tw, twp);  // bit 7: tuning ablation
     ZD_STAMP(3, unit, false);  // transformed
     if (ZD_TUNE(S.prune & 256) && re[0] != 123.456) return;                    // bit 8: tuning ablation (no stores)
     char *base = reinterpret_cast<char *>(ring + ((long long) (pz * 3 + a) * N) * ring_pitch);
@@ -1690,13 +1763,16 @@ __global__ __launch_bounds__(ROWS *NA *N / E, (ROWS * NA * N / E == 512 ? 4 : 1)
     const int pl = plane0 + blockIdx.y;  // local plane index inside the store
     const cplx *src = data + row_offset(S, pl, a, y);
     double re[E], im[E];
+    // the twiddles of the later passes are requested together with the row (one wait instead of three; zd_fft.h TwSet)
+    zdfft::TwSet<PL> twp;
+    zdfft::load_twiddles<PL>(twp, t, tw);
 #pragma unroll
     for (int e = 0; e < E; e++) {
         const cplx v = ld_stream(src + t + T * e, ZD_TUNE(S.nt & 4));
         re[e] = v.x;
         im[e] = v.y;
     }
-    if (!ZD_TUNE(S.prune & 32)) zdfft::fft_line<PL, LDS>(re, im, t, line, lds, tw);  // bit 5: tuning ablation
+    if (!ZD_TUNE(S.prune & 32)) zdfft::fft_line_tw<PL, LDS>(re, im, t, line, lds, tw, twp);  // bit 5: tuning ablation
     if (ZD_TUNE(S.prune & 64) && re[0] != 123.456) return;                           // bit 6: tuning ablation (no epilogue)
 
     // ---- WriteParticlesSlab (src/output.cpp:86-203) ----
@@ -2365,9 +2441,16 @@ template <int N, int E, int W, bool PERSIST = false, int MINW = 1>
 static int launch_yfft_f_t(const FieldLayout &F, const StoreLayout &S, const void *tw, const void *store, int plane0,
                            int nplanes, int ring_pitch, void *ring, hipStream_t st) {
     constexpr int threads = W * N / E;
-    const size_t shmem = sizeof(double) * zdfft::ColsInner<N, W>::SIZE;
+    // the transform's exchange area + the row-block table (8 B per block of FIELD_RB row slots)
+    const size_t shmem = sizeof(double) * (zdfft::ColsInner<N, W>::SIZE + (size_t) ((S.Hq + FIELD_RB - 1) / FIELD_RB));
+    // (the attribute is set once per device: for the largest table, one rank's)
+    const size_t shmem_max = std::min<size_t>(160 * 1024, sizeof(double) * (zdfft::ColsInner<N, W>::SIZE + (size_t) (N / 2 + FIELD_RB - 1) / FIELD_RB));
+    if (shmem > 160 * 1024) {
+        fprintf(stderr, "zeldovich_hip: y stage of the field store needs %zu B of LDS at PPD %d\n", shmem, N);
+        return 2;
+    }
     if constexpr (PERSIST) {
-        set_dyn_lds<k_yfft_fp<N, E, W, MINW>>(shmem);
+        set_dyn_lds<k_yfft_fp<N, E, W, MINW>>(shmem_max);
         int dev = 0, ncu = 256;
         hipGetDevice(&dev);
         hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -2376,7 +2459,7 @@ static int launch_yfft_f_t(const FieldLayout &F, const StoreLayout &S, const voi
         hipLaunchKernelGGL((k_yfft_fp<N, E, W, MINW>), grid, block, shmem, st, F, S, (const cplx *) tw, (const cplx *) store, plane0,
                            ring_pitch, (cplx *) ring, nplanes);
     } else {
-        set_dyn_lds<k_yfft_f<N, E, W, MINW>>(shmem);
+        set_dyn_lds<k_yfft_f<N, E, W, MINW>>(shmem_max);
         dim3 grid(3 * (N / W), 1, nplanes), block(threads);
         hipLaunchKernelGGL((k_yfft_f<N, E, W, MINW>), grid, block, shmem, st, F, S, (const cplx *) tw, (const cplx *) store, plane0,
                            ring_pitch, (cplx *) ring);

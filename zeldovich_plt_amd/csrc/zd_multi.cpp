@@ -678,22 +678,32 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
         fprintf(stderr, "zeldovich_hip: ZD_NumGPU = %d but only %d GPU(s) are visible\n", G, ndev);
         return 1;
     }
+    // How the GPUs share the job (zd_choose_pass_groups): `groups` independent groups of gsz ranks.  Group j runs the residue
+    // passes j, j + groups, ...; the rows / planes of a pass are sharded over the gsz ranks of a group with the exchange of
+    // run_pass_impl.  gsz = 1: no exchange at all.
     zd_params p = *p_in;
-    if (p.stream_factor <= 0) {
+    int groups = 1;
+    {
         size_t free_b = 0, total_b = 0;
         MHIP(hipMemGetInfo(&free_b, &total_b));
         const int ranks_per_dev = (G + ndev - 1) / ndev;
         // (ZD_f_NL: every rank also keeps PhiK of its rows, N^3 / (2 G) complex)
         const int64_t phik_b = p.f_NL != 0. ? (p.ppd / 2 / G) * p.ppd * p.ppd * 16 : 0;
-        const int R = zd_choose_stream_factor(&p, G, ((int64_t) free_b - ((int64_t) 16 << 30)) / ranks_per_dev - phik_b);
-        if (R < 0) {
+        int32_t g = 1, R = 0;
+        if (zd_choose_pass_groups(&p, G, ((int64_t) free_b - ((int64_t) 16 << 30)) / ranks_per_dev - phik_b, &g, &R)) {
             fprintf(stderr, "zeldovich_hip: PPD %lld does not fit %d GPU(s)\n", (long long) p.ppd, G);
             return 1;
         }
+        groups          = g;
         p.stream_factor = R;
     }
+    const int gsz = G / groups;
+    if (transport == 2 && groups > 1) {
+        fprintf(stderr, "zeldovich_hip: the test transport runs one group of ranks\n");
+        return 1;
+    }
     std::vector<RankCtx> ctx(G);
-    LocalGroup grp;
+    std::vector<LocalGroup> grps(groups);  // rendezvous of the local transport, one per group
     std::vector<ncclComm_t> nccls(G, nullptr);
 #ifdef ZD_TESTING
     std::vector<LoopComm> loops(G);
@@ -721,18 +731,22 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
         return 1;
 #endif
     } else if (transport == 1) {
-        grp.n = G;
-        grp.send_base.assign(G, nullptr);
-        grp.ring_base.assign(G, nullptr);
-    } else {
+        for (LocalGroup &grp : grps) {
+            grp.n = gsz;
+            grp.send_base.assign(gsz, nullptr);
+            grp.ring_base.assign(gsz, nullptr);
+        }
+    } else if (gsz > 1) {  // one communicator per group (ranks j * gsz ... of the devices in order)
         RcclApi *R = rccl();
         if (!R) {
             fprintf(stderr, "zeldovich_hip: librccl.so not found\n");
             return 1;
         }
-        std::vector<int> devs(G);
-        for (int g = 0; g < G; g++) devs[g] = g;
-        MNCCL(R->CommInitAll(nccls.data(), G, devs.data()));
+        for (int j = 0; j < groups; j++) {
+            std::vector<int> devs(gsz);
+            for (int i = 0; i < gsz; i++) devs[i] = j * gsz + i;
+            MNCCL(R->CommInitAll(nccls.data() + (size_t) j * gsz, gsz, devs.data()));
+        }
     }
     Delivery dl;
     dl.cb   = cb;
@@ -745,7 +759,7 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
     bool aborted = false;
     auto abort_all = [&]() {
         job_failed.store(1, std::memory_order_release);
-        grp.fail();
+        for (LocalGroup &grp : grps) grp.fail();
         std::lock_guard<std::mutex> lk(abort_mu);
         if (aborted || transport != 0) return;
         aborted = true;
@@ -774,11 +788,12 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
             do {
                 if (hipSetDevice(me.device) != hipSuccess) break;
                 if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
-                c->rank   = g;
-                c->nranks = G;
+                const int grp_id = g / gsz, rk = g % gsz;  // group, rank inside it
+                c->rank   = rk;
+                c->nranks = gsz;
                 c->kind   = transport == 2 ? 0 : transport;  // the loopback emulation runs the RCCL branch
                 c->nccl   = nccls[g];
-                c->grp    = &grp;
+                c->grp    = &grps[grp_id];
                 c->failed = &job_failed;
                 if (comm_prepare(c)) break;
                 if (p.f_NL != 0.) {  // the phi round first (its own plan, store and ring), then the main plan reads PhiK
@@ -786,7 +801,7 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
                     void *d_phi = nullptr;
                     bool ok     = false;
                     do {
-                        if (zd_plan_create_phi(&p, pk, g, G, &ph)) break;
+                        if (zd_plan_create_phi(&p, pk, rk, gsz, &ph)) break;
                         if (hipMalloc(&d_phi, (size_t) zd_plan_exchange_bytes(ph)) != hipSuccess
                             || hipMalloc(&d_phik, (size_t) ph->Hq * ph->N * ph->N * 16) != hipSuccess) {
                             fprintf(stderr, "zeldovich_hip: rank %d: f_NL needs %.1f GB of HBM for the phi field\n", g,
@@ -800,8 +815,8 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
                     hipFree(d_phi);
                     if (ph) zd_plan_destroy(ph);
                     if (!ok) break;
-                    if (zd_plan_create_phik(&p, pk, eig, eig_ppd, g, G, d_phik, &pl)) break;
-                } else if (zd_plan_create(&p, pk, eig, eig_ppd, g, G, &pl)) {
+                    if (zd_plan_create_phik(&p, pk, eig, eig_ppd, rk, gsz, d_phik, &pl)) break;
+                } else if (zd_plan_create(&p, pk, eig, eig_ppd, rk, gsz, &pl)) {
                     break;
                 }
                 const int ps = pl->pstep;
@@ -819,8 +834,15 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
                 if (want_rec && cb && hipHostMalloc((void **) &h_rec, plane_rec_b * (size_t) rec_planes) != hipSuccess) break;
                 if (want_dens && hipMalloc((void **) &d_dens, nn * 4 * (size_t) rec_planes) != hipSuccess) break;
                 if (want_dens && cb && hipHostMalloc((void **) &h_dens, nn * 4 * (size_t) rec_planes) != hipSuccess) break;
+                if (pl->npass % groups) {
+                    fprintf(stderr, "zeldovich_hip: %d passes do not deal out over %d pass groups\n", pl->npass, groups);
+                    break;
+                }
+                // sum |D|^2 of the packed stores comes from the generator, once per run and rank: every group sees every
+                // mode, so only group 0 accumulates it (its ranks cover all rows between them)
+                if (grp_id != 0) pl->var_pending = false;
                 bool fail = false;
-                for (int pass = 0; pass < pl->npass && !fail; pass++) {
+                for (int pass = grp_id; pass < pl->npass && !fail; pass += groups) {
                     GroupSink sink{pl, pass, &dl, h_rec, plane_rec_b, cb ? d_dens : nullptr, h_dens, -1, &job_failed};
                     if (run_pass_impl(pl, c, pass, d_store, d_rec, d_dens, rec_planes, sink_cb, &sink, st)) fail = true;
                 }

@@ -8,6 +8,10 @@ The reference is single-process; its y<->z "transpose" is StoreBlock/LoadBlock o
 exchange runs in PLANE GROUPS into a two-slot ring — group j+1 travels while the y and x stages of group j run —
 and no second full-size store exists.  No other collective is on the data path.
 
+The residue passes of the z streaming are independent partitions of the output, so the ranks may also work as several
+GROUPS (`split_ranks`, zd_choose_pass_groups): group j runs the passes j, j + groups, ... and nothing travels between groups;
+with one rank per group there is no exchange at all.
+
 On a GPU the whole pass (Z stage, exchange over RCCL/xGMI, XY stages) runs inside the library
 (`zd_plan_run_pass`, csrc/zd_multi.cpp); `SlabPipeline` then only owns the buffers.  The same pipeline written against
 an abstract `engine` (anything with the staged interface of include/zeldovich_hip.h) and torch.distributed
@@ -17,6 +21,14 @@ point-to-point operations is what the CPU tests drive with gloo and a numpy stan
     engine.stage_x_group(residue, buf, chunk_planes, plane0, gplane0, nplanes, out), engine.plane_z(residue, local_plane)
 """
 import torch
+
+
+def split_ranks(rank, world, groups):
+    """(group, rank inside the group, ranks per group) of global rank `rank` when `world` ranks work as `groups` groups of
+    consecutive ranks (the split zd_generate_multi uses for its host threads)"""
+    assert world % groups == 0
+    gsz = world // groups
+    return rank // gsz, rank % gsz, gsz
 
 
 class HipEngine:
@@ -51,13 +63,18 @@ class HipEngine:
 class SlabPipeline:
     """Runs residue passes: Z stage -> exchange of plane groups -> y FFT -> x FFT + epilogue per group."""
 
-    def __init__(self, engine, ppd, world=1, dist=None, device="cpu", chunk_bytes=8 << 30, group_bytes=4 << 30):
+    def __init__(self, engine, ppd, world=1, dist=None, device="cpu", chunk_bytes=8 << 30, group_bytes=4 << 30, rank_base=0,
+                 process_group=None):
+        # world = ranks of THIS group (they exchange); rank_base = global rank of the group's rank 0, process_group = its
+        # torch.distributed group (stand-in path only; None: the default group)
         # chunk_bytes: size of the record ring = planes finished per x-stage launch.  At PPD=4096 one plane of RVZel
         # records is 537 MB; launches of a single store plane (4096 workgroups, 16 per CU) lose 13 % to launch tails.
         self.e = engine
         self.ppd = ppd
         self.world = world
         self.dist = dist
+        self.rank_base = rank_base
+        self.pg = process_group
         self.native = bool(getattr(engine, "native", False))
         if world > 1 and dist is None and not self.native:
             raise ValueError("world > 1 needs torch.distributed")
@@ -84,7 +101,7 @@ class SlabPipeline:
         npl = min(gp, self.Zq - p0)
         slot = self.recv[(j & 1) * w * gp * cpe:((j & 1) + 1) * w * gp * cpe].view(w, gp * cpe)
         sv = self.send.view(w, self.Zq * cpe)
-        me = self.dist.get_rank()
+        me = self.dist.get_rank() - self.rank_base
         ops = []
         for d in range(w):
             src = sv[d, p0 * cpe:(p0 + npl) * cpe]          # what rank d will finish
@@ -92,8 +109,8 @@ class SlabPipeline:
             if d == me:
                 dst.copy_(src)
             else:
-                ops.append(self.dist.P2POp(self.dist.isend, src, d))
-                ops.append(self.dist.P2POp(self.dist.irecv, dst, d))
+                ops.append(self.dist.P2POp(self.dist.isend, src, self.rank_base + d))
+                ops.append(self.dist.P2POp(self.dist.irecv, dst, self.rank_base + d))
         return (self.dist.batch_isend_irecv(ops) if ops else []), slot, npl
 
     def run_pass(self, residue, consume=None):
@@ -135,8 +152,9 @@ class SlabPipeline:
                 if consume is not None:
                     consume([e.plane_z(residue, g0 + i) for i in range(n)], self.ring)
         # every peer has taken its planes before the next Z stage overwrites the send store
-        self.dist.barrier()
+        self.dist.barrier(group=self.pg)
 
-    def run(self, consume=None):
-        for r in range(getattr(self.e, "passes", self.e.R)):
+    def run(self, consume=None, pass_first=0, pass_step=1):
+        """all passes, or (several groups of ranks) the passes pass_first, pass_first + pass_step, ... of this group"""
+        for r in range(pass_first, getattr(self.e, "passes", self.e.R), pass_step):
             self.run_pass(r, consume)
