@@ -12,6 +12,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <algorithm>
+#include <type_traits>
 #include <stdlib.h>
 
 #include "zd_device.h"
@@ -1030,8 +1031,16 @@ __device__ __forceinline__ double genf_tile_mirror(const GenConst &g, const GenJ
         double aAr[NACC], aAi[NACC], aBr[NACC], aBi[NACC];
 #pragma unroll
         for (int j = 0; j < NACC; j++) aAr[j] = aAi[j] = aBr[j] = aBi[j] = 0.0;
+        // One fold term k1 of this k2.  ZA2 kinds (two residues r and r + R/2 per pass): the second residue's fold twiddle is
+        // (-1)^k1 times the first one's, so E(r0) = Ee + Eo, E(r1) = Ee - Eo with Ee / Eo the sums over the even / odd terms
+        // (likewise Z): a mode updates ONE pair of sums (4 FMAs instead of 8); the loop is unrolled by two so that the parity
+        // is a compile-time index, and the sums are combined after it.  Slots: [0] Ee, [1] Ze, [2] Eo, [3] Zo.
+        constexpr int NPAR = ZA2 ? 2 : 1;  // (ZA2: R is a power of two >= 2)
 #pragma unroll 1
-        for (int k1 = 0; k1 < R; k1++) {
+        for (int k10 = 0; k10 < R; k10 += NPAR) {
+#pragma unroll
+        for (int PAR = 0; PAR < NPAR; PAR++) {
+            const int k1 = k10 + PAR;
             const int z  = k2 + L * k1;
             const int kz = z > half ? z - N : z;
             const int k2i = kxy2 + kz * kz;
@@ -1060,8 +1069,7 @@ __device__ __forceinline__ double genf_tile_mirror(const GenConst &g, const GenJ
             const double k2v = (double) k2i * g.fundamental2;
             const double P   = genf_power<PLAW>(g, T, k2v);
             const double q   = g.fundamental * frcp(k2v);
-            // W_R^{k1 r}.  The second residue of a pass is r + R/2 (zd_plan_stage_z; checked by the launcher), so its
-            // twiddle is W_R^{k1 r} (-1)^{k1}: the same products with a sign.
+            // W_R^{k1 r}
             double wr = 1.0, wi = 0.0;
             if (R > 1) {
                 const cplx w = twN[modn(N, k1 * residue * L)];
@@ -1069,7 +1077,7 @@ __device__ __forceinline__ double genf_tile_mirror(const GenConst &g, const GenJ
                 wi = w.y;
             }
             const double dkz = (double) kz;
-            const double sg2 = (k1 & 1) ? -1.0 : 1.0, dkz2 = (k1 & 1) ? -dkz : dkz;
+            const double qwr = q * wr, qwi = q * wi;  // ZA2: fundamental / k^2 folded into the twiddle (shared by the two modes)
             auto one = [&](uint64_t r1, uint64_t r2, double (&ar)[NACC], double (&ai)[NACC]) {
                 // cgauss<2> (power_spectrum.cpp:338-359); zeroed lanes of a live wave ride along with amplitude 0
                 const uint64_t m1 = r1 + 1ULL;
@@ -1080,29 +1088,40 @@ __device__ __forceinline__ double genf_tile_mirror(const GenConst &g, const GenJ
                 double sn, cs;
                 sincos_u01(u64_to_double(r2 + 1ULL), T, sn, cs);
                 const double d0r = amp * cs, d0i = amp * sn;
-                vsum += v;  // |D|^2 = amp^2 (cos^2 + sin^2)
-                const double dr = d0r * wr - d0i * wi, di = d0r * wi + d0i * wr;
-                if constexpr (KIND == GENF_DENS) {
-                    ar[0] += dr;
-                    ai[0] += di;
-                } else if constexpr (KIND == GENF_ZA) {
-                    ar[0] += dr;
-                    ai[0] += di;
-                    const double er = q * dr, ei = q * di;
-                    ar[1] += er;
-                    ai[1] += ei;
-                    cmac(ar[2], ai[2], dkz, er, ei);
+                if (g.accum_var) vsum += v;  // |D|^2 = amp^2 (cos^2 + sin^2); wanted by the first pass of a run only
+                if constexpr (ZA2) {
+                    const double er = d0r * qwr - d0i * qwi, ei = d0r * qwi + d0i * qwr;
+                    ar[2 * PAR] += er;
+                    ai[2 * PAR] += ei;
+                    cmac(ar[2 * PAR + 1], ai[2 * PAR + 1], dkz, er, ei);
                 } else {
-                    const double er = q * dr, ei = q * di;
-                    ar[0] += er;
-                    ai[0] += ei;
-                    cmac(ar[1], ai[1], dkz, er, ei);
-                    cmac(ar[2], ai[2], sg2, er, ei);
-                    cmac(ar[3], ai[3], dkz2, er, ei);
+                    const double dr = d0r * wr - d0i * wi, di = d0r * wi + d0i * wr;
+                    ar[0] += dr;
+                    ai[0] += di;
+                    if constexpr (KIND == GENF_ZA) {
+                        const double er = q * dr, ei = q * di;
+                        ar[1] += er;
+                        ai[1] += ei;
+                        cmac(ar[2], ai[2], dkz, er, ei);
+                    }
                 }
             };
             one(r1A, r2A, aAr, aAi);
             one(r1B, r2B, aBr, aBi);
+        }
+        }
+        if constexpr (ZA2) {
+            auto combine = [](double (&a)[NACC]) {
+                const double ee = a[0], ze = a[1], eo = a[2], zo = a[3];
+                a[0] = ee + eo;  // E(r0)
+                a[1] = ze + zo;  // Z(r0)
+                a[2] = ee - eo;  // E(r1)
+                a[3] = ze - zo;  // Z(r1)
+            };
+            combine(aAr);
+            combine(aAi);
+            combine(aBr);
+            combine(aBi);
         }
         // ---- job inputs from the field sums (genf_tile), for column xA with kx = +xh and column xB with kx = -xh ----
         double pr = 1.0, pi = 0.0, qr = 1.0, qi = 0.0;
@@ -1162,7 +1181,14 @@ __device__ __forceinline__ double genf_tile_mirror(const GenConst &g, const GenJ
 // is sized to a few workgroups per CU (zd_plan: gen_wgs_per_cu) so that the HBM-bound k_zfft of the previous
 // slab, running on the second stream, always finds registers and LDS next to the generator's waves.
 template <int ZR, int KIND, bool PLAW, bool MIRROR>
-__global__ __launch_bounds__(GEN_BX) void k_genf(GenConst g, GenJumps J, StoreLayout S, int zW, int ky0, int kyl0, int nky,
+// (PLT kinds at __launch_bounds__(GEN_BX, 4) = 128 registers, 7-16 spilled dwords, two workgroups per CU so that a 512-thread
+// z-FFT workgroup shares the CU: measured PPD=2048 PLT+rescale 558 -> 574 ms, PPD=4096 PLT 9.2 -> 10.7 s.  The PLT Z stage at
+// PPD=2048 is HBM-bound — generator writes 0.41 TB of folded inputs, the z FFT reads them and writes 0.41 TB of store: 1.23 TB
+// in 0.26 s — so overlapping the two kernels buys nothing there, and at PPD=4096 the capped generator is simply slower.)
+// The ZA kinds are held to 128 registers (three generator workgroups + one 256-thread z-FFT workgroup of 128 registers fill a
+// SIMD's 512 exactly; at 129 the allocation granule of 8 makes it 136 and the z FFT no longer fits beside them).
+__global__ __launch_bounds__(GEN_BX, (KIND == GENF_ZAF || KIND == GENF_ZAP || KIND == GENF_ZA || KIND == GENF_DENS) ? 4 : 1)
+void k_genf(GenConst g, GenJumps J, StoreLayout S, int zW, int ky0, int kyl0, int nky,
                                                  int nrows, int L, int residue, int residue2,
                                                  const cplx *__restrict__ twN, cplx *__restrict__ Y,
                                                  unsigned *__restrict__ tile_ctr) {
