@@ -976,6 +976,17 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         while (pl->Hq % rows) rows--;
         pl->slab_rows = rows;
         pl->overlap   = p->serial_z == 0 && !v1 && !any_path;  // version 1: the streams are sequential in ky
+        // PLT with a table that is interpolated (eig_ppd does not divide into PPD): the (x, y) part of the trilinear lookup is
+        // done once per column of a slab (k_eig_lines) instead of once per mode; one slab of lines, refilled on the generator's
+        // stream in front of every generator launch
+        if (g.qPLT && g.genf_tab && !v1 && eig_ppd % N != 0) {
+            const size_t nb = (size_t) (eig_ppd / 2 + 1) * rows * N * 4 * sizeof(double);
+            if (nb <= ((size_t) 1 << 30)) {
+                PLCHECK(hipMalloc((void **) &pl->d_eiglines, nb));
+                g.eig_lines = pl->d_eiglines;
+                g.eig_rows  = rows;
+            }
+        }
         if (v1) {
             pl->v1_block = (int) (N / p->numblock);
             PLCHECK(hipMalloc((void **) &pl->d_v1streams, sizeof(zd::V1Stream) * (size_t) pl->v1_block));
@@ -1051,6 +1062,7 @@ void zd_plan_destroy(zd_plan *pl) {
     hipFree(pl->d_pktab);
     hipFree(pl->d_fnlM);
     hipFree(pl->d_eig);
+    hipFree(pl->d_eiglines);
     hipFree(pl->d_rowstate);
     hipFree(pl->d_twN);
     hipFree(pl->d_twL);
@@ -1117,6 +1129,7 @@ static int any_stage_z(zd_plan *pl, int residue, void *d_send, hipStream_t st) {
                                        pl->d_v1dev + (size_t) i0 * pl->N * pl->N, pl->d_v1err, st))
                     return 1;
         // (k_genf with walks of 16 / 4 / 2 z rows where the kernel exists, else the general generator)
+        if (pl->d_eiglines && zd::launch_eig_lines(pl->g, r0, 1, nky, pl->d_eiglines, st)) return 1;
         if (zd::launch_gen(pl->g, pl->J, pl->jobs, pl->S, r0, nky, pl->L, residue, residue, pl->d_twN, pl->d_Y[0], pl->d_tilectr + slab,
                            pl->gen_max_wgs, st))
             return 1;
@@ -1155,6 +1168,7 @@ int zd_plan_stage_z(zd_plan *pl, int residue, void *d_send, void *hip_stream) {
                                            pl->d_v1dev + (size_t) i0 * pl->N * pl->N, pl->d_v1err, st))
                         return 1;
             }
+            if (pl->d_eiglines && zd::launch_eig_lines(pl->g, ky_first + G * r0, G, nky, pl->d_eiglines, st)) return 1;
             if (zd::launch_gen(pl->g, pl->J, pl->jobs, pl->S, ky_first + G * r0, nky, pl->L, residue, residue2, pl->d_twN, pl->d_Y[0],
                                pl->d_tilectr + slab, pl->gen_max_wgs, st))
                 return 1;
@@ -1179,6 +1193,7 @@ int zd_plan_stage_z(zd_plan *pl, int residue, void *d_send, void *hip_stream) {
         if (slab == 0) HIPCHECK(hipMemsetAsync(ctr, 0, sizeof(unsigned) * nslab, pl->s_gen));
         pl->g.accum_var = accum;
         tick(pl, ZD_K_GEN, pl->s_gen, true);
+        if (pl->d_eiglines && zd::launch_eig_lines(pl->g, ky_first + G * r0, G, pl->slab_rows, pl->d_eiglines, pl->s_gen)) return 1;
         if (zd::launch_gen(pl->g, pl->J, pl->jobs, pl->S, ky_first + G * r0, pl->slab_rows, pl->L, pass,
                            pl->pstep == 2 ? pass + pl->R / 2 : pass, pl->d_twN, pl->d_Y[slot], ctr + slab,
                            pl->gen_max_wgs, pl->s_gen))

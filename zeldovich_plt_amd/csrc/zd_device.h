@@ -45,6 +45,11 @@ struct GenConst {
     double f_cluster, target_f, ln_growth_ratio;  // log(a_NL/a0)
     const double *eig;
     long long eig_ppd;
+    // k_genf, interpolated lookups: the table interpolated in (x, y) for every column of the slab being generated,
+    // eig_lines[(cz * eig_rows + row of the slab) * N + x] = {e_x, e_y, e_z, lambda} at table cell cz along z (k_eig_lines);
+    // a mode then blends two entries instead of eight table corners.  NULL: the direct lookup
+    const double *eig_lines;
+    int eig_rows;
     // local primordial non-Gaussianity (zeldovich.cpp:377-400): M(k) = 2 g c^2 T(k) k^2 / (3 Omega_M H0^2)
     int gen_phi;              // 1: emit phi = D / M (first f_NL pass)
     const zdfft::cplx *phik;  // non-NULL: D = phik[ky][z][x] * M (second pass; the zero rule is bypassed)

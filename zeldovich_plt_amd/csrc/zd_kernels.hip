@@ -751,6 +751,77 @@ __device__ __forceinline__ void eigenmode_fast(const GenConst &g, int kx, int ky
     out[3] = eh[3];
 }
 
+// The (x, y) part of the trilinear lookup does not depend on kz: k_eig_lines does it once per column of a slab and pass — for
+// every table cell cz along z the four (x, y) corners blended with their weights (zero-weight corners not read, like
+// get_eigenmode_dev) — into lines[(cz * nrows + row) * N + x].  kz is wave-uniform in k_genf and consecutive lanes are
+// consecutive x, so a mode reads two fully coalesced 32-byte entries per lane instead of 8 corners x 2 loads, and blends 4
+// values with 2 weights instead of 32 FMAs with 8.  (Association differs from the single expression of zeldovich.cpp:218-225 —
+// (w_x w_y) sums first, then w_z — by a few 1e-16 of the components.)  One slab is 65 x rows x N x 32 B (128 MB at PPD = 4096).
+//   grid: (ceil(N / 256), nrows)   block: 256
+__global__ __launch_bounds__(256) void k_eig_lines(GenConst g, int ky0, int ky_stride, int nrows, double *__restrict__ lines) {
+    const int N = g.N, x = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
+    if (x >= N) return;
+    const int kx = x > g.half ? x - N : x, ky = ky0 + row * ky_stride;
+    const EigXY q = eig_xy(g, eig_axis(g, eig_index_x(g, kx)), eig_axis(g, ky));
+    const int hz = (int) g.eig_ppd / 2 + 1;
+    const double2 *E = reinterpret_cast<const double2 *>(g.eig);
+    double2 *out = reinterpret_cast<double2 *>(lines);
+    for (int cz = 0; cz < hz; cz++) {
+        double e0 = 0.0, e1 = 0.0, e2 = 0.0, e3 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            if (q.w[c] != 0) {
+                const double2 q0 = E[q.base[c] + cz * 2], q1 = E[q.base[c] + cz * 2 + 1];
+                e0 += q.w[c] * q0.x;
+                e1 += q.w[c] * q0.y;
+                e2 += q.w[c] * q1.x;
+                e3 += q.w[c] * q1.y;
+            }
+        const size_t i = (((size_t) cz * nrows + row) * N + x) * 2;
+        out[i]     = double2{e0, e1};
+        out[i + 1] = double2{e2, e3};
+    }
+}
+
+// eigenmode_fast from the slab's (x, y)-interpolated lines (k_eig_lines); `row` = row of the slab
+__device__ __forceinline__ void eigenmode_lines(const GenConst &g, int kx, int ky, int kz, int row, int x, const EigAxis &az, double (&out)[4]) {
+    const double2 *V = reinterpret_cast<const double2 *>(g.eig_lines);
+    const size_t il = (((size_t) az.l * g.eig_rows + row) * g.N + x) * 2;
+    const double wl = 1 - az.f, wh = az.f;
+    double eh[4] = {0.0, 0.0, 0.0, 0.0};
+    if (wl != 0) {
+        const double2 a0 = V[il], a1 = V[il + 1];
+        eh[0] = wl * a0.x;
+        eh[1] = wl * a0.y;
+        eh[2] = wl * a1.x;
+        eh[3] = wl * a1.y;
+    }
+    if (wh != 0) {  // wave-uniform: kz is
+        const size_t ih = (((size_t) az.h * g.eig_rows + row) * g.N + x) * 2;
+        const double2 b0 = V[ih], b1 = V[ih + 1];
+        eh[0] += wh * b0.x;
+        eh[1] += wh * b0.y;
+        eh[2] += wh * b1.x;
+        eh[3] += wh * b1.y;
+    }
+    eh[2] *= (kz < 0 ? -1.0 : 1.0);
+    const double n2 = eh[0] * eh[0] + eh[1] * eh[1] + eh[2] * eh[2];
+    double r = trans_rsq(n2);
+    r = r * fma(-0.5 * n2, r * r, 1.5);
+    r = r * fma(-0.5 * n2, r * r, 1.5);
+    eh[0] *= r;
+    eh[1] *= r;
+    eh[2] *= r;
+    const double k2  = (double) (kx * kx + ky * ky + kz * kz);
+    const double dot = kx * eh[0] + ky * eh[1] + kz * eh[2];
+    double norm = k2 * frcp(dot);
+    if (k2 == 0.0 || !isfinite(norm)) norm = 0.0;
+    out[0] = norm * eh[0];
+    out[1] = norm * eh[1];
+    out[2] = norm * eh[2];
+    out[3] = eh[3];
+}
+
 template <int ZR, int KIND, bool PLAW>
 __device__ __forceinline__ double genf_tile(const GenConst &g, const GenJumps &J, const StoreLayout &S, const double *T, int zW,
                                             int ky0, int kyl_arg, int kyl_first, int nky, int L, int residue, int residue2, int bx,
@@ -790,7 +861,9 @@ __device__ __forceinline__ double genf_tile(const GenConst &g, const GenJumps &J
     const int kxy2  = kx * kx + ky * ky;
     const bool dead = (kx < 0 ? -kx : kx) == g.kmax || ky == g.kmax;  // zeldovich.cpp:350
     EigXY exy = {};
-    if constexpr (IS_PLT) exy = eig_xy(g, eig_axis(g, eig_index_x(g, kx)), eig_axis(g, ky));
+    if constexpr (IS_PLT) {
+        if (!g.eig_lines) exy = eig_xy(g, eig_axis(g, eig_index_x(g, kx)), eig_axis(g, ky));
+    }
     u128 s;
     {  // state one step ahead of the first mode's counter
         const int kz0 = k20 > half ? k20 - N : k20;  // k20 > N/2 only happens when R = 1
@@ -877,7 +950,10 @@ __device__ __forceinline__ double genf_tile(const GenConst &g, const GenJumps &J
             } else if constexpr (IS_PLT) {
                 constexpr int B = KIND == GENF_PLT ? 1 : 0;  // index of the X sum (PLTN, PLTF: the six sums only)
                 double e[4];
-                eigenmode_fast(g, kx, ky, kz, exy, eig_axis(g, eig_index_z(g, kz)), e);
+                if (g.eig_lines)  // (uniform) the slab's (x, y)-interpolated lines
+                    eigenmode_lines(g, kx, ky, kz, kyl, x, eig_axis(g, eig_index_z(g, kz)), e);
+                else
+                    eigenmode_fast(g, kx, ky, kz, exy, eig_axis(g, eig_index_z(g, kz)), e);
                 const double f = (sqrt_pos(1. + 24 * e[3] * g.f_cluster) - 1) * .25;
                 double rescale = 1.0;
                 if (g.qPLTrescale) rescale = fexp(g.ln_growth_ratio * (g.target_f - f), T);
@@ -2332,6 +2408,14 @@ int launch_gen(const GenConst &g, const GenJumps &J, const JobList &jobs, const 
     GCASE(6, true)
 #undef GCASE
     return 2;
+}
+
+// (x, y)-interpolated eigenmode lines of the rows ky0, ky0 + ky_stride, ... of a slab (GenConst::eig_lines)
+int launch_eig_lines(const GenConst &g, int ky0, int ky_stride, int nrows, void *lines, hipStream_t st) {
+    dim3 grid((g.N + 255) / 256, nrows), block(256);
+    hipLaunchKernelGGL(k_eig_lines, grid, block, 0, st, g, ky0, ky_stride, nrows, (double *) lines);
+    ZD_LAUNCH_CHECK();
+    return 0;
 }
 
 int launch_pk_table(const GenConst &g, int n, void *tab, hipStream_t st) {

@@ -41,6 +41,7 @@ constexpr int GEN_ZR = 16;   // z rows walked by one generator thread
 int launch_gen(const GenConst &g, const GenJumps &J, const JobList &jobs, const StoreLayout &S, int ky0, int nky, int L,
                int residue, int residue2, const void *twN, void *Y, unsigned *tile_ctr, int max_wgs, hipStream_t st);
 int launch_pk_table(const GenConst &g, int n, void *tab, hipStream_t st);
+int launch_eig_lines(const GenConst &g, int ky0, int ky_stride, int nrows, void *lines, hipStream_t st);
 int launch_test_modes(const GenConst &g, long long n, const int *kxyz, uint64_t *draws, double *D, hipStream_t st);
 int launch_test_modes_table(const GenConst &g, long long n, const int *kxyz, double *out, hipStream_t st);
 int launch_zfft(int L, const JobList &jobs, const StoreLayout &S, int ky0, int kyloc0, int nky, int Zq, const void *Y,

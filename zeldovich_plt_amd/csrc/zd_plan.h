@@ -38,6 +38,7 @@ struct zd_plan {
     double *d_pktab = nullptr;
     double *d_fnlM = nullptr;  // f_NL: M(k) by integer |k|^2
     double *d_eig = nullptr;
+    double *d_eiglines = nullptr;  // PLT with an interpolated table: (x, y)-interpolated lines of the slab being generated
     zdpcg::u128 *d_rowstate = nullptr;
     zdfft::cplx *d_twN = nullptr, *d_twL = nullptr;
     zdfft::cplx *d_twq_n = nullptr, *d_twq_l = nullptr;  // PPD = 2^a 3^b: twiddle sets of the composite transforms (lengths N, L)
