@@ -167,6 +167,13 @@ def main():
             return bytes(allr[grp_id * gsz].cpu().tolist())
         comm = zd.Comm(grank, gsz, exchange_id)
     pipe = SlabPipeline(HipEngine(plan, N, comm=comm), N, world=gsz, dist=dist, device="cuda")
+    pipelined = False
+    if comm is not None and gsz > 1 and plan.passes // groups >= 2:
+        free_now = torch.tensor([torch.cuda.mem_get_info()[0]], dtype=torch.int64, device="cuda")
+        dist.all_reduce(free_now, op=dist.ReduceOp.MIN)  # every rank of the job takes the same decision
+        if int(free_now.item()) > plan.exchange_bytes + (12 << 30):
+            pipe.alloc_second_store()  # passes pipelined: Z stage of pass p + 1 beside the exchange of pass p
+            pipelined = True
 
     def step():
         # per residue pass, inside the library (zd_plan_run_pass): Z stage -> exchange in plane groups over RCCL/xGMI,
@@ -288,7 +295,8 @@ def main():
                           "%d arrays" % plan.narray), "passes": plan.passes,
                 "block_store_GB": plan.exchange_bytes / 1e9,
                 "parallelism": ("%d group(s) of %d GPU(s): residue passes round-robin over the groups%s" % (
-                    groups, gsz, ", ky/z slabs + one RCCL exchange per pass inside a group" if gsz > 1 else ", no exchange"))},
+                    groups, gsz, (", ky/z slabs + one RCCL exchange per pass inside a group" + (", passes pipelined over two send stores" if pipelined else ""))
+                    if gsz > 1 else ", no exchange"))},
             "hbm_GBps_path": (64.0 * narray + recsize) * value / 1e9,
             "roofline_path_frac": (64.0 * narray + recsize) * value / 1e9 / (HBM_PEAK_GBS * world),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": du["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

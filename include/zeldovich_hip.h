@@ -214,6 +214,14 @@ typedef int (*zd_group_cb)(void *user, int64_t first_local_plane, int64_t nplane
 int zd_plan_run_pass(zd_plan *plan, zd_comm *comm, int pass, void *d_store, void *d_records, int64_t rec_planes,
                      zd_group_cb cb, void *user, void *hip_stream);
 
+/* The passes first, first + step, ... of this rank (step = number of pass groups, first = this rank's group) in one call.
+ * d_store2 (optional, as large as d_store): with a communicator of several ranks the passes are then PIPELINED — the Z stage of
+ * the next pass runs into the other store while the planes of the current pass are exchanged and transformed; a store is
+ * rewritten only after its sends have completed.  cb additionally receives the pass. */
+typedef int (*zd_pass_cb)(void *user, int pass, int64_t first_local_plane, int64_t nplanes, const void *d_records, void *hip_stream);
+int zd_plan_run_passes(zd_plan *plan, zd_comm *comm, int first, int step, void *d_store, void *d_store2, void *d_records,
+                       int64_t rec_planes, zd_pass_cb cb, void *user, void *hip_stream);
+
 /* Fetch + reset the device-side reductions (max_disp, density_variance) and kernel timers. Syncs. */
 int zd_plan_stats(zd_plan *plan, zd_stats *out);
 

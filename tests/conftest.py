@@ -26,3 +26,20 @@ def oracle():
 @pytest.fixture(scope="session")
 def wmap_path():
     return WMAP
+
+
+class OneGroupApi:
+    """zeldovich_plt_amd.api for the multi-rank parity tests written before pass groups existed: `ngpu > 1` means ONE group of
+    ranks there (rows -> exchange -> planes), so make_params pins pass_groups = 1 unless a test chooses otherwise.  (The
+    library's automatic choice — one GPU per group while there are enough passes — is tested in test_gpu_multi_rehearsal.py.)"""
+
+    def __init__(self, api):
+        self._api = api
+
+    def __getattr__(self, name):
+        return getattr(self._api, name)
+
+    def make_params(self, *a, **kw):
+        if kw.get("ngpu", 0) > 1:
+            kw.setdefault("pass_groups", 1)
+        return self._api.make_params(*a, **kw)

@@ -53,7 +53,7 @@ def test_cli_writes_reference_files(tmp_path, oracle, fmt, R, qd, ngpu):
     (out / "keep.txt").write_text("keep")
     par = tmp_path / "t.par"
     par.write_text(PAR % dict(cpd=cpd, fmt=fmt, out=out, np=n ** 3, pk=WMAP, qd=qd, R=R)
-                   + ("ZD_NumGPU = %d\nZD_ExchangePlanes = 3\n" % ngpu if ngpu > 1 else ""))
+                   + ("ZD_NumGPU = %d\nZD_ExchangePlanes = 3\nZD_PassGroups = 1\n" % ngpu if ngpu > 1 else ""))
     r = subprocess.run([EXE, str(par)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert "Mpart/sec" in r.stderr and "maximum component-wise displacements" in r.stderr

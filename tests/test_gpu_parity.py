@@ -20,8 +20,9 @@ def _rel(a, b):
 @pytest.fixture(scope="module")
 def zd():
     import zeldovich_plt_amd.api as api
+    from conftest import OneGroupApi
     api.load_library()
-    return api
+    return OneGroupApi(api)
 
 
 @pytest.fixture(scope="module")

@@ -71,6 +71,7 @@ class ZdParamStrings(C.Structure):
 
 SLAB_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p)
 GROUP_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p)
+PASS_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p)
 
 # every symbol include/zeldovich_hip.h declares (checked by tests/test_capi_symbols.py)
 EXPORTED_SYMBOLS = [
@@ -78,7 +79,7 @@ EXPORTED_SYMBOLS = [
     "zd_plan_stream_factor", "zd_plan_passes", "zd_plan_plane_step", "zd_plan_record_size", "zd_plan_exchange_bytes", "zd_plan_local_planes",
     "zd_plan_plane_z", "zd_plan_stage_z", "zd_plan_stage_y", "zd_plan_stage_x", "zd_plan_stats", "zd_comm_unique_id", "zd_comm_create", "zd_comm_destroy", "zd_plan_ring_bytes", "zd_plan_run_pass",
     "zd_params_from_file", "zd_pk_create_from_file", "zd_pk_create_powerlaw", "zd_pk_power",
-    "zd_pk_sigmaR", "zd_pk_destroy", "zd_load_eigmodes", "zd_free", "zd_comm_abort", "zd_comm_traffic", "zd_choose_pass_groups",
+    "zd_pk_sigmaR", "zd_pk_destroy", "zd_load_eigmodes", "zd_free", "zd_comm_abort", "zd_comm_traffic", "zd_choose_pass_groups", "zd_plan_run_passes",
 ]
 # test scaffolding: exists only in the -DZD_TESTING library (csrc/zd_testing.h, `make testing`), never in the product
 TESTING_SYMBOLS = ["zd_test_draws", "zd_test_modes", "zd_test_modes_table", "zd_test_v1_words", "zd_test_generate_loopback",
@@ -156,6 +157,7 @@ def _load(path, testing):
     L.zd_plan_ring_bytes.argtypes = [vp, C.POINTER(i32)]
     L.zd_plan_ring_bytes.restype = i64
     L.zd_plan_run_pass.argtypes = [vp, vp, C.c_int, vp, vp, i64, GROUP_CB, vp, vp]
+    L.zd_plan_run_passes.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp, i64, PASS_CB, vp, vp]
     L.zd_params_from_file.argtypes = [C.c_char_p, C.POINTER(ZdParams), C.POINTER(ZdParamStrings)]
     L.zd_pk_create_from_file.argtypes = [C.c_char_p, dbl, dbl, dbl, dbl, dbl, C.c_int, dbl, C.POINTER(vp), C.POINTER(ZdPk)]
     L.zd_pk_create_powerlaw.argtypes = [dbl, dbl, dbl, dbl, dbl, C.c_int, dbl, C.POINTER(vp), C.POINTER(ZdPk)]
@@ -399,6 +401,16 @@ class Plan:
             cb = GROUP_CB(lambda user, first, n, recp, st: int(consume(int(first), int(n), recp, st) or 0))
         if self.L.zd_plan_run_pass(self.h, comm.h if comm is not None else None, residue, d_store, d_records, rec_planes, cb, None, stream):
             raise RuntimeError("zd_plan_run_pass failed")
+
+    def run_passes(self, first, step, d_store, d_store2, d_records, rec_planes, comm=None, consume=None, stream=0):
+        """the passes first, first + step, ... in one call (zd_plan_run_passes); with a second store d_store2 and several ranks
+        the passes are pipelined; consume(pass, first_local_plane, nplanes, d_records_ptr, stream)"""
+        cb = PASS_CB()
+        if consume is not None:
+            cb = PASS_CB(lambda user, ps, first_, n, recp, st: int(consume(int(ps), int(first_), int(n), recp, st) or 0))
+        if self.L.zd_plan_run_passes(self.h, comm.h if comm is not None else None, first, step, d_store, d_store2, d_records, rec_planes,
+                                     cb, None, stream):
+            raise RuntimeError("zd_plan_run_passes failed")
 
     def stats(self):
         st = ZdStats()

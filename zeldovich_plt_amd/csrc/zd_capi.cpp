@@ -422,6 +422,11 @@ int zd_choose_pass_groups(const zd_params *p, int ngpu, int64_t budget_bytes, in
     const int gsz = ngpu / g;
     int R = p->stream_factor > 0 ? p->stream_factor : zd_choose_stream_factor(p, gsz, budget_bytes);
     if (R < 0) return 1;
+    // Ranks that exchange pipeline their passes (zd_plan_run_passes: Z stage of pass p+1 beside the exchange of pass p, two
+    // send stores): give every group at least four passes when the stream factor is free.  A larger factor always fits —
+    // the stores shrink — and costs (passes / ranks per group) generations per rank, hidden behind the exchange.
+    if (gsz > 1 && p->stream_factor <= 0 && is_pow2(p->ppd))
+        while ((R / plan_plane_step(p, R, gsz)) < 4 * g && p->ppd % (2 * R) == 0 && p->ppd / (2 * R) >= 256 && (p->ppd / (2 * R)) % gsz == 0) R *= 2;
     // the passes must deal out evenly over the groups: a larger stream factor (smaller stores) always fits
     while ((R / plan_plane_step(p, R, gsz)) % g) {
         if (p->stream_factor > 0) {
@@ -1143,15 +1148,34 @@ static int any_stage_z(zd_plan *pl, int residue, void *d_send, hipStream_t st) {
     return 0;
 }
 
+static int stage_z_impl(zd_plan *pl, int residue, void *d_send, hipStream_t st, bool detached, hipEvent_t wait_ev, hipEvent_t done_ev);
+
 int zd_plan_stage_z(zd_plan *pl, int residue, void *d_send, void *hip_stream) {
-    hipStream_t st = (hipStream_t) hip_stream;
+    return stage_z_impl(pl, residue, d_send, (hipStream_t) hip_stream, false, nullptr, nullptr);
+}
+
+// The Z stage detached from the caller's stream (zd_multi.cpp pipelines passes with it): the z FFT — the only part that
+// writes d_send — starts after `wait_ev` (NULL: at once) instead of after everything queued on `st`, nothing joins `st`, and
+// `done_ev` is recorded behind the last z FFT.  Plans without the two worker streams (ZD_Version = 1, convolution PPDs,
+// serial_z) run the stage on `st` as usual and record done_ev there.
+int zd_plan_stage_z_detached(zd_plan *pl, int residue, void *d_send, void *hip_stream, void *wait_event, void *done_event) {
+    return stage_z_impl(pl, residue, d_send, (hipStream_t) hip_stream, true, (hipEvent_t) wait_event, (hipEvent_t) done_event);
+}
+
+static int stage_z_impl(zd_plan *pl, int residue, void *d_send, hipStream_t st, bool detached, hipEvent_t wait_ev, hipEvent_t done_ev) {
     if (residue < 0 || residue >= pl->npass) return 1;
+    if (detached && (pl->any || !pl->overlap)) {  // no worker streams: in stream order on st
+        if (wait_ev) HIPCHECK(hipStreamWaitEvent(st, wait_ev, 0));
+        if (stage_z_impl(pl, residue, d_send, st, false, nullptr, nullptr)) return 1;
+        if (done_ev) HIPCHECK(hipEventRecord(done_ev, st));
+        return 0;
+    }
     if (pl->any) return any_stage_z(pl, residue, d_send, st);
     const int residue2 = pl->pstep == 2 ? residue + pl->R / 2 : residue;
     pl->g.accum_var = (pl->pack != zd::PACK_NONE && pl->var_pending) ? 1 : 0;  // once per run: every pass sees every mode
     pl->var_pending = false;
     const int ky_first = pl->rank, G = pl->nranks;  // this rank's half-space rows: rank, rank + G, ... (cyclic)
-    const int zspan = span_begin(pl, ZD_K_ZSTAGE, st);
+    const int zspan = span_begin(pl, ZD_K_ZSTAGE, detached ? pl->s_gen : st);
     if (!pl->overlap) {
         HIPCHECK(hipMemsetAsync(pl->d_tilectr, 0, sizeof(unsigned) * pl->n_tilectr, st));
         // ZD_Version = 1: every pass replays the streams from their seeds; rows that share a stream (block/G apart in
@@ -1183,8 +1207,12 @@ int zd_plan_stage_z(zd_plan *pl, int residue, void *d_send, void *hip_stream) {
     // Two worker streams.  s_fft (k_zfft, writes the store) starts after everything already queued on the caller's
     // stream; s_gen (generator, writes ring slots only) is ordered by the ring alone and may be a pass ahead.
     const int K = (int) pl->d_Y.size(), nslab = pl->Hq / pl->slab_rows;
-    HIPCHECK(hipEventRecord(pl->ev_fork, st));
-    HIPCHECK(hipStreamWaitEvent(pl->s_fft, pl->ev_fork, 0));
+    if (!detached) {
+        HIPCHECK(hipEventRecord(pl->ev_fork, st));
+        HIPCHECK(hipStreamWaitEvent(pl->s_fft, pl->ev_fork, 0));
+    } else if (wait_ev) {
+        HIPCHECK(hipStreamWaitEvent(pl->s_fft, wait_ev, 0));
+    }
     auto issue_gen = [&](int pass, int slab, long long gno, int accum) -> int {
         const int slot = (int) (gno % K), r0 = slab * pl->slab_rows;
         // the slot is free once the k_zfft that read its previous content (slab gno - K) has finished
@@ -1230,6 +1258,11 @@ int zd_plan_stage_z(zd_plan *pl, int residue, void *d_send, void *hip_stream) {
         for (int slab = 0; slab < n; slab++)
             if (issue_gen(residue + 1, slab, pl->next_g++, 0)) return 1;
         pl->ahead_n = n;
+    }
+    if (detached) {  // nothing joins the caller's stream: whoever needs the store waits for done_ev
+        if (done_ev) HIPCHECK(hipEventRecord(done_ev, pl->s_fft));
+        span_end(pl, zspan, pl->s_fft);
+        return 0;
     }
     // join: the caller's stream continues after the last k_zfft of this pass
     HIPCHECK(hipEventRecord(pl->ev_fork, pl->s_fft));

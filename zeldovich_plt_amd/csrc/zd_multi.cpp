@@ -250,6 +250,9 @@ struct zd_comm {
     std::atomic<int> own_failed{0};
     // per-rank accounting of the exchange (zd_comm_stats)
     int64_t bytes_sent = 0, bytes_received = 0;
+    // pipelined passes (zd_plan_run_passes with two send stores): Z stage of a store complete / its sends complete
+    hipEvent_t ev_zd[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+    bool slot_used[2] = {false, false};  // an XY stage has been recorded on ev_x[slot] since the ring was (re)allocated
 };
 
 namespace {
@@ -260,6 +263,8 @@ int comm_prepare(zd_comm *c) {
     for (int i = 0; i < 2; i++) {
         MHIP(hipEventCreateWithFlags(&c->ev_x[i], hipEventDisableTiming));
         MHIP(hipEventCreateWithFlags(&c->ev_r[i], hipEventDisableTiming));
+        MHIP(hipEventCreateWithFlags(&c->ev_zd[i], hipEventDisableTiming));
+        MHIP(hipEventCreateWithFlags(&c->ev_free[i], hipEventDisableTiming));
     }
     return 0;
 }
@@ -284,6 +289,7 @@ int comm_ring(zd_comm *c, int64_t ring_b, int gp, hipStream_t st) {
         c->ring_bytes = 0;
     }
     MHIP(hipMalloc((void **) &c->ring, (size_t) ring_b));
+    c->slot_used[0] = c->slot_used[1] = false;
     c->ring_bytes   = ring_b;
     c->slot_bytes   = ring_b / 2;
     c->group_planes = gp;
@@ -359,6 +365,8 @@ void zd_comm_destroy(zd_comm *c) {
     for (int i = 0; i < 2; i++) {
         if (c->ev_x[i]) hipEventDestroy(c->ev_x[i]);
         if (c->ev_r[i]) hipEventDestroy(c->ev_r[i]);
+        if (c->ev_zd[i]) hipEventDestroy(c->ev_zd[i]);
+        if (c->ev_free[i]) hipEventDestroy(c->ev_free[i]);
     }
     hipFree(c->ring);
     delete c;
@@ -386,6 +394,8 @@ int64_t zd_plan_ring_bytes(const zd_plan *pl, int32_t *group_planes) {
 //              still queued on `stream` — the consumer orders itself after it (or syncs); cb may be NULL (benchmark sink)
 typedef int (*zd_group_cb)(void *user, int64_t first_local_plane, int64_t nplanes, const void *d_records, void *hip_stream);
 
+static int run_passes_impl(zd_plan *pl, zd_comm *c, int first, int step, void *d_store, void *d_store2, void *d_records, float *d_density,
+                           int64_t rec_planes, zd_pass_cb cb, void *user, void *hip_stream);
 // d_density: room for rec_planes planes of float32 (stores with a density field only) or NULL
 static int run_pass_impl(zd_plan *pl, zd_comm *c, int pass, void *d_store, void *d_records, float *d_density, int64_t rec_planes,
                          zd_group_cb cb, void *user, void *hip_stream);
@@ -395,8 +405,11 @@ int zd_plan_run_pass(zd_plan *pl, zd_comm *c, int pass, void *d_store, void *d_r
     return run_pass_impl(pl, c, pass, d_store, d_records, nullptr, rec_planes, cb, user, hip_stream);
 }
 
+// z_done: NULL = run the Z stage here, joined to the stream (one store); else the Z stage of this pass has been issued
+// detached (zd_plan_stage_z_detached) and z_done is recorded behind it.  sends_done (with z_done): recorded on the
+// communication stream behind the last send of the pass instead of holding the compute stream back.
 static int run_pass_body(zd_plan *pl, zd_comm *c, int pass, void *d_store, void *d_records, float *d_density, int64_t rec_planes,
-                         zd_group_cb cb, void *user, void *hip_stream);
+                         zd_group_cb cb, void *user, void *hip_stream, hipEvent_t z_done = nullptr, hipEvent_t sends_done = nullptr);
 
 // A rank that fails (allocation, launch, RCCL error, consumer returning non-zero) must not leave its peers spinning in the
 // send / receive kernels they have already queued for it: the failure is published (zd_comm::failed) and this rank's
@@ -414,7 +427,7 @@ static int run_pass_impl(zd_plan *pl, zd_comm *c, int pass, void *d_store, void 
 }
 
 static int run_pass_body(zd_plan *pl, zd_comm *c, int pass, void *d_store, void *d_records, float *d_density, int64_t rec_planes,
-                         zd_group_cb cb, void *user, void *hip_stream) {
+                         zd_group_cb cb, void *user, void *hip_stream, hipEvent_t z_done, hipEvent_t sends_done) {
     hipStream_t st = (hipStream_t) hip_stream;
     const int ps = pl->pstep;
     const int64_t Pp = zd_plan_local_planes(pl);
@@ -422,8 +435,9 @@ static int run_pass_body(zd_plan *pl, zd_comm *c, int pass, void *d_store, void 
         fprintf(stderr, "zeldovich_hip: record buffer of %lld planes (multiples of %d needed)\n", (long long) rec_planes, ps);
         return 1;
     }
-    if (zd_plan_stage_z(pl, pass, d_store, st)) return 1;
+    if (!z_done && zd_plan_stage_z(pl, pass, d_store, st)) return 1;
     if (!c || pl->nranks <= 1) {
+        if (z_done) MHIP(hipStreamWaitEvent(st, z_done, 0));
         if (zd_plan_stage_y(pl, d_store, st)) return 1;
         for (int64_t q0 = 0; q0 < Pp; q0 += rec_planes) {
             const int64_t n = std::min<int64_t>(rec_planes, Pp - q0);
@@ -445,8 +459,12 @@ static int run_pass_body(zd_plan *pl, zd_comm *c, int pass, void *d_store, void 
     const int64_t cpb = chunk_plane_bytes(pl), chunk_b = cpb * pl->Zq;
     const int ngroups = (pl->Zq + gp - 1) / gp;
     // the Z stage must be complete before anything leaves the send store
-    MHIP(hipEventRecord(c->ev_z, st));
-    MHIP(hipStreamWaitEvent(c->s_comm, c->ev_z, 0));
+    if (z_done) {
+        MHIP(hipStreamWaitEvent(c->s_comm, z_done, 0));
+    } else {
+        MHIP(hipEventRecord(c->ev_z, st));
+        MHIP(hipStreamWaitEvent(c->s_comm, c->ev_z, 0));
+    }
     if (c->kind == 1) {  // local: every rank's send store must be complete before anybody pulls from it
         MHIP(hipStreamSynchronize(st));
         c->grp->send_base[me] = (const char *) d_store;
@@ -457,7 +475,9 @@ static int run_pass_body(zd_plan *pl, zd_comm *c, int pass, void *d_store, void 
         const int64_t p0 = (int64_t) j * gp, np = std::min<int64_t>(gp, pl->Zq - p0);
         const size_t nb = (size_t) (cpb * np);
         char *dst = c->ring + (size_t) slot * c->slot_bytes;
-        if (j >= 2) MHIP(hipStreamWaitEvent(c->s_comm, c->ev_x[slot], 0));  // the XY stages of group j-2 have left the slot
+        // the XY stages of the group that used the slot before (group j-2, or the last groups of the previous pass when the
+        // passes are pipelined and the communication stream no longer waits for the compute stream in between) have left it
+        if (j >= 2 || c->slot_used[slot]) MHIP(hipStreamWaitEvent(c->s_comm, c->ev_x[slot], 0));
         if (c->kind == 1) {
             for (int s = 0; s < G; s++)  // pull: chunk <me> of rank s's send store, planes of the group
                 MHIP(hipMemcpyAsync(dst + (size_t) s * cpb * gp, c->grp->send_base[s] + (size_t) me * chunk_b + (size_t) p0 * cpb, nb,
@@ -501,17 +521,82 @@ static int run_pass_body(zd_plan *pl, zd_comm *c, int pass, void *d_store, void 
             if (cb && cb(user, p0 * ps + q0, n, d_records, st)) return 1;
         }
         MHIP(hipEventRecord(c->ev_x[slot], st));
+        c->slot_used[slot] = true;
     }
     if (c->kind == 1) {  // nobody may start the next Z stage (overwriting its send store) while a peer still pulls
         MHIP(hipStreamSynchronize(c->s_comm));
         MHIP(hipStreamSynchronize(st));
         if (c->grp->wait()) return 1;
+    } else if (sends_done) {
+        MHIP(hipEventRecord(sends_done, c->s_comm));  // (pipelined: the Z stage that reuses this store waits for it)
     } else {
         // the sends of this pass must have left d_store before the caller's next Z stage overwrites it
         MHIP(hipEventRecord(c->ev_z, c->s_comm));
         MHIP(hipStreamWaitEvent(st, c->ev_z, 0));
     }
     return 0;
+}
+
+// Passes first, first + step, ... of this rank.  With a second send store (d_store2, same size), several ranks and the RCCL
+// transport the passes are PIPELINED: the Z stage of the next pass is issued detached from the compute stream into the other
+// store before this pass's planes are exchanged and transformed, so generator and z FFT of pass p+1 run while the exchange
+// of pass p occupies the links (the reference's per-block StoreBlock inside the generation loop, src/zeldovich.cpp:558-587,
+// in units of passes); a store is rewritten only after its sends have completed.  Otherwise the passes run one after the
+// other on d_store.
+int zd_plan_run_passes(zd_plan *pl, zd_comm *c, int first, int step, void *d_store, void *d_store2, void *d_records, int64_t rec_planes,
+                       zd_pass_cb cb, void *user, void *hip_stream) {
+    return run_passes_impl(pl, c, first, step, d_store, d_store2, d_records, nullptr, rec_planes, cb, user, hip_stream);
+}
+
+namespace {
+struct PassCb {
+    zd_pass_cb cb;
+    void *user;
+    int pass;
+};
+int pass_cb_adaptor(void *u, int64_t first_local_plane, int64_t nplanes, const void *d_records, void *hip_stream) {
+    PassCb *p = (PassCb *) u;
+    return p->cb ? p->cb(p->user, p->pass, first_local_plane, nplanes, d_records, hip_stream) : 0;
+}
+}  // namespace
+
+static int run_passes_impl(zd_plan *pl, zd_comm *c, int first, int step, void *d_store, void *d_store2, void *d_records, float *d_density,
+                           int64_t rec_planes, zd_pass_cb cb, void *user, void *hip_stream) {
+    hipStream_t st = (hipStream_t) hip_stream;
+    if (first < 0 || step < 1) return 1;
+    PassCb pc{cb, user, 0};
+    const bool pipelined = c && pl->nranks > 1 && c->kind == 0 && d_store2 != nullptr && first + step < pl->npass;
+    if (!pipelined) {
+        for (int pass = first; pass < pl->npass; pass += step) {
+            pc.pass = pass;
+            if (run_pass_impl(pl, c, pass, d_store, d_records, d_density, rec_planes, pass_cb_adaptor, &pc, st)) return 1;
+        }
+        return 0;
+    }
+    if (comm_failed(c)) return 1;
+    void *stores[2] = {d_store, d_store2};
+    int rc = 0, i = 0;
+    do {
+        // the first Z stage starts after whatever the caller queued on its stream (the stores' previous users)
+        MHIP(hipEventRecord(c->ev_z, st));
+        if ((rc = zd_plan_stage_z_detached(pl, first, stores[0], st, c->ev_z, c->ev_zd[0]))) break;
+        for (int pass = first; pass < pl->npass && !rc; pass += step, i++) {
+            const int b = i & 1, nxt = pass + step;
+            if (nxt < pl->npass)  // store 1-b was last read by the sends of pass i-1 (ev_free); the very first use is free
+                if ((rc = zd_plan_stage_z_detached(pl, nxt, stores[1 - b], st, i >= 1 ? c->ev_free[1 - b] : c->ev_z, c->ev_zd[1 - b]))) break;
+            pc.pass = pass;
+            rc = run_pass_body(pl, c, pass, stores[b], d_records, d_density, rec_planes, pass_cb_adaptor, &pc, st, c->ev_zd[b], c->ev_free[b]);
+        }
+        if (rc) break;
+        // the caller's stream ends behind the last sends (the stores may be freed or rewritten by the caller afterwards)
+        MHIP(hipEventRecord(c->ev_z, c->s_comm));
+        MHIP(hipStreamWaitEvent(st, c->ev_z, 0));
+    } while (0);
+    if (rc) {
+        if (c->failed) c->failed->store(1, std::memory_order_release);
+        zd_comm_abort(c);
+    }
+    return rc;
 }
 
 // The phi round of ZD_f_NL on several ranks (zeldovich.cpp:945-960: ZeldovichZ(gen_phi) + ZeldovichXY_Phi, then the forward z
@@ -633,10 +718,12 @@ struct GroupSink {
     float *h_dens;
     int64_t only_z;       // ZD_qoneslab: deliver just this z (-1: every plane)
     const std::atomic<int> *failed = nullptr;  // the job's failure flag
+    std::atomic<int> *failed_w = nullptr;      // (the same, to set it when this rank's consumer fails)
 };
 
-int sink_cb(void *user, int64_t first_local_plane, int64_t nplanes, const void *d_records, void *hip_stream) {
+int sink_cb(void *user, int pass, int64_t first_local_plane, int64_t nplanes, const void *d_records, void *hip_stream) {
     GroupSink *s = (GroupSink *) user;
+    s->pass = pass;
     if (!s->dl->cb) return 0;
     hipStream_t st = (hipStream_t) hip_stream;
     const size_t nn = (size_t) s->pl->N * s->pl->N;
@@ -648,9 +735,13 @@ int sink_cb(void *user, int64_t first_local_plane, int64_t nplanes, const void *
     for (int64_t i = 0; i < nplanes; i++) {
         const int64_t z = zd_plan_plane_z(s->pl, s->pass, first_local_plane + i);
         if (s->only_z >= 0 && z != s->only_z) continue;
+        if (s->failed && s->failed->load(std::memory_order_acquire)) return 1;  // (another rank's consumer failed meanwhile)
         if (s->dl->cb(s->dl->user, z, (int64_t) nn, s->plane_rec_b ? s->h_rec + (size_t) i * s->plane_rec_b : nullptr,
                       s->d_dens ? s->h_dens + (size_t) i * nn : nullptr))
+        {
+            if (s->failed_w) s->failed_w->store(1, std::memory_order_release);  // published before the mutex is released
             return 1;
+        }
     }
     return 0;
 }
@@ -779,7 +870,7 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
             RankCtx &me = ctx[g];
             me.rc       = 1;
             zd_plan *pl = nullptr;
-            void *d_store = nullptr, *d_rec = nullptr;
+            void *d_store = nullptr, *d_store2 = nullptr, *d_rec = nullptr;
             float *d_dens = nullptr, *h_dens = nullptr;
             void *d_phik = nullptr;
             char *h_rec = nullptr;
@@ -841,12 +932,16 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
                 // sum |D|^2 of the packed stores comes from the generator, once per run and rank: every group sees every
                 // mode, so only group 0 accumulates it (its ranks cover all rows between them)
                 if (grp_id != 0) pl->var_pending = false;
-                bool fail = false;
-                for (int pass = grp_id; pass < pl->npass && !fail; pass += groups) {
-                    GroupSink sink{pl, pass, &dl, h_rec, plane_rec_b, cb ? d_dens : nullptr, h_dens, -1, &job_failed};
-                    if (run_pass_impl(pl, c, pass, d_store, d_rec, d_dens, rec_planes, sink_cb, &sink, st)) fail = true;
+                // a second send store (several ranks exchanging over RCCL, more than one pass for this group, memory to spare):
+                // the passes are pipelined — Z stage of pass p+1 beside the exchange of pass p (run_passes_impl)
+                if (gsz > 1 && c->kind == 0 && grp_id + groups < pl->npass) {
+                    size_t free_b = 0, total_b = 0;
+                    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess
+                        && free_b > (size_t) zd_plan_exchange_bytes(pl) * ((G + ndev - 1) / ndev) + ((size_t) 12 << 30))
+                        if (hipMalloc(&d_store2, (size_t) zd_plan_exchange_bytes(pl)) != hipSuccess) d_store2 = nullptr;
                 }
-                if (fail) break;
+                GroupSink sink{pl, grp_id, &dl, h_rec, plane_rec_b, cb ? d_dens : nullptr, h_dens, -1, &job_failed, &job_failed};
+                if (run_passes_impl(pl, c, grp_id, groups, d_store, d_store2, d_rec, d_dens, rec_planes, sink_cb, &sink, st)) break;
                 if (zd_plan_stats(pl, &me.stats)) break;
                 if (job_failed.load(std::memory_order_acquire)) break;  // a peer failed: this rank's planes are not a result
                 me.rc = 0;
@@ -854,6 +949,7 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
             if (me.rc) abort_all();
             if (st) hipStreamDestroy(st);
             hipFree(d_store);
+            hipFree(d_store2);
             hipFree(d_rec);
             hipFree(d_dens);
             hipFree(d_phik);

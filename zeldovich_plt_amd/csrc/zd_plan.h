@@ -94,6 +94,7 @@ int zd_plan_phi_zfwd(zd_plan *pl, void *d_store, void *d_phik, void *hip_stream)
 // hipEvent pair around something on `hip_stream` that is not a kernel of this file (zd_multi.cpp: the wait for an exchanged
 // plane group); summed into kernel_ms[kind] by zd_plan_stats when the plan profiles
 void zd_plan_tick(zd_plan *pl, int kind, void *hip_stream, int begin);
+int zd_plan_stage_z_detached(zd_plan *pl, int residue, void *d_send, void *hip_stream, void *wait_event, void *done_event);
 }
 int zd_generate_multi(const zd_params *p, const zd_pk *pk, const double *eig, int64_t eig_ppd, zd_slab_cb cb, void *user,
                       zd_stats *out, int transport);

@@ -60,6 +60,11 @@ class HipEngine:
                            stream=self._stream())
 
 
+def _hip_run_passes(engine, first, step, store, store2, ring, rec_planes, consume=None):
+    engine.plan.run_passes(first, step, store.data_ptr(), None if store2 is None else store2.data_ptr(), ring.data_ptr(), rec_planes,
+                           comm=engine.comm, consume=consume, stream=engine._stream())
+
+
 class SlabPipeline:
     """Runs residue passes: Z stage -> exchange of plane groups -> y FFT -> x FFT + epilogue per group."""
 
@@ -82,6 +87,7 @@ class SlabPipeline:
         nel = engine.exchange_bytes // 8
         # float64 elements: a dtype every backend moves natively
         self.send = torch.empty(nel, dtype=torch.float64, device=device)
+        self.send2 = None  # second send store: pipelined passes of ranks that exchange (alloc_second_store)
         plane_b = ppd * ppd * max(engine.record_size, 1)
         step = getattr(engine, "plane_step", 1)  # a store plane may deliver two z planes (packed ZA stores)
         self.chunk = int(max(step, min(engine.local_planes, chunk_bytes // plane_b) // step * step))
@@ -154,7 +160,16 @@ class SlabPipeline:
         # every peer has taken its planes before the next Z stage overwrites the send store
         self.dist.barrier(group=self.pg)
 
+    def alloc_second_store(self):
+        """native path, several ranks per group: a second send store lets the library pipeline the passes (Z stage of pass
+        p + 1 beside the exchange of pass p, zd_plan_run_passes)"""
+        if self.native and self.send2 is None:
+            self.send2 = torch.empty_like(self.send)
+
     def run(self, consume=None, pass_first=0, pass_step=1):
         """all passes, or (several groups of ranks) the passes pass_first, pass_first + pass_step, ... of this group"""
+        if self.native and consume is None:
+            _hip_run_passes(self.e, pass_first, pass_step, self.send, self.send2, self.ring, self.chunk)
+            return
         for r in range(pass_first, getattr(self.e, "passes", self.e.R), pass_step):
             self.run_pass(r, consume)
