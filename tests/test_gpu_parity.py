@@ -763,6 +763,61 @@ def test_non_power_of_two_ppd_plt_vs_oracle(zd, oracle, ps, opk, n, kw):
     assert sorted(got["planes_seen"]) == list(range(n))
 
 
+@pytest.mark.parametrize("n", [40, 200, 1000, 80, 160, 1280, 5120, 240, 960, 400, 3200, 720, 2400, 2000, 4000])
+@pytest.mark.parametrize("kind", [0, 1])
+def test_fft_lines_radix5_lengths(zd, n, kind):
+    """lengths 2^a 3^b 5^c (round 3): Q = 5, 15, 25, 45, 75, 125 decimated sub-lines through the power-of-two register engine + a
+    mixed radix-3 / radix-5 outer transform (csrc/zd_fft_q.h outer_stages), both LDS layouts, vs numpy"""
+    rng = np.random.default_rng(n + kind)
+    lines = 8
+    x = rng.standard_normal((lines, n)) + 1j * rng.standard_normal((lines, n))
+    got = zd.test_fft(x, kind)
+    ref = np.fft.ifft(x, axis=1) * n
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    assert err < 2e-14, err
+
+
+@pytest.mark.parametrize("n,kw", [
+    (160, dict(stream_factor=2)),                                       # 160 = 32 * 5, z lines of 80 = 16 * 5
+    (160, dict(stream_factor=2, k_cutoff=2.0, fmt="RVZel")),
+    (160, dict(stream_factor=2, plt=32)),                                # PLT + rescale, interpolated 32^3 table
+    (320, dict(stream_factor=4, fmt="ZelSimple")),                       # 320 = 64 * 5, z lines of 80
+])
+def test_radix5_ppd_vs_oracle(zd, oracle, ps, opk, n, kw):
+    """PPD = 2^a 5 on the composite-transform kernels (field stores) against the oracle, whose non-power-of-two path is a plain DFT"""
+    kw = dict(kw)
+    fmt = kw.pop("fmt", "RVdoubleZel")
+    eig = None
+    if "plt" in kw:
+        eig = oracle.synthetic_eigenmodes(kw.pop("plt"))
+        kw.update(qPLT=1, qPLTrescale=1, PLT_target_z=5.0, f_cluster=0.97)
+    plan = zd.Plan(zd.make_params(n, icformat=fmt, **kw), ps, eig=eig)
+    assert plan.store_mode == "fields"
+    plan.close()
+    got, _ = _compare(zd, oracle, ps, opk, n, fmt=fmt, eig=eig, **kw)
+    assert sorted(got["planes_seen"]) == list(range(n))
+
+
+def test_radix5_oversampling_and_stream_invariance(zd, ps):
+    """5-smooth grids beyond the oracle's reach: 1600 (= 64 * 25, k_cutoff = 2) <-> 800 (= 32 * 25) and 960 (= 64 * 15) <-> 480 through
+    the oversampling invariant on sample planes; R-invariance of the reductions at 1280 (= 256 * 5).  (4000 = 32 * 125 against 2000 on
+    the convolution kernels: test_oversampled_planes_exact_at_full_size.)"""
+    for n, Rlo, Rhi in ((800, 2, 4), (480, 2, 4)):
+        zs = (1, n // 2 + 1, n - 1)
+        lo, hi = {}, {}
+        zd.generate_planes(zd.make_params(n, icformat="Zeldovich", stream_factor=Rlo), ps,
+                           lambda z, rec: lo.__setitem__(z, rec["d"].copy()) if z in zs else None)
+        zd.generate_planes(zd.make_params(2 * n, icformat="Zeldovich", k_cutoff=2.0, stream_factor=Rhi), ps,
+                           lambda z, rec: hi.__setitem__(z // 2, rec["d"][::2, ::2].copy()) if (z % 2 == 0 and z // 2 in zs) else None)
+        assert sorted(lo) == sorted(hi) == sorted(zs)
+        for z in zs:
+            assert np.abs(hi[z] - lo[z]).max() < 1e-12 * np.abs(lo[z]).max() + 1e-15, (n, z)
+    a = zd.generate(zd.make_params(1280, icformat="RVZel", stream_factor=2), ps, collect=False)
+    b = zd.generate(zd.make_params(1280, icformat="RVZel", stream_factor=8), ps, collect=False)
+    assert abs(a["density_variance"] - b["density_variance"]) <= 1e-11 * a["density_variance"]
+    assert np.abs(a["max_disp"] - b["max_disp"]).max() <= 1e-11 * np.abs(a["max_disp"]).max()
+
+
 def test_non_power_of_two_oversampling_invariance(zd, ps):
     """PPD = 2N with k_cutoff = 2 at even sites == PPD = N (README), across the composite sizes: 192 <-> 96, 576 <-> 288,
     1728 <-> 864 (27 * 64 / 27 * 32), on sample planes (a full PPD = 1728 record array would be 290 GB of host memory);

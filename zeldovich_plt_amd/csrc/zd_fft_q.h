@@ -1,13 +1,16 @@
-// zd_fft_q.h — line lengths N = P * Q with P a power of two and Q = 3, 9, 27 (PPD = 2^a 3^b: e.g. 6912 = 256 * 27), on
+// zd_fft_q.h — line lengths N = P * Q with P a power of two and Q = 3^a 5^b (3, 9, 27, 5, 25, 125, 15, 45, 75; PPD = 6912 = 256 * 27,
+// 4000 = 32 * 125, ...), on
 // top of the register-resident power-of-two engine of zd_fft.h.
 //
 // The reference plans any length with FFTW (src/zeldovich.cpp:61-66).  Here a line is split into its Q decimated
 // sub-sequences x[Q n1 + n2] (n2 < Q), each of length P:
 //     X[k1 + P k2] = sum_{n2 < Q}  ( W_N^{n2 k1}  F_{n2}[k1] )  W_Q^{n2 k2},      F_{n2} = DFT_P of sub-sequence n2
 // The Q sub-transforms are just Q more "columns" for the existing engine (threads (t, n2) hold 16 elements each, radix-16
-// butterflies in registers, exchanges through LDS); the outer Q-point transforms are log3(Q) radix-3 stages on an LDS
+// butterflies in registers, exchanges through LDS); the outer Q-point transforms are a + b radix-3 / radix-5 stages on an LDS
 // staging buffer (the power-of-two sizes never come here).  Thread (t, w, n2) enters with elements  x[Q (t + T e) + n2]  of line w and leaves with  X[(t + T e) + P n2].
 #pragma once
+#include <type_traits>
+
 #include "zd_fft.h"
 
 namespace zdfft {
@@ -21,7 +24,58 @@ struct pick<false, A, B> {
     using type = B;
 };
 
+// Q = 3^a 5^b: digit j of an index below Q has radix 3 for j < a and 5 above
+template <int Q>
+struct QFactors {
+    static constexpr int count(int q, int r) { return q % r == 0 ? 1 + count(q / r, r) : 0; }
+    static constexpr int A = count(Q, 3), B = count(Q, 5), S = A + B;
+    static constexpr int ipow(int b, int e) { return e == 0 ? 1 : b * ipow(b, e - 1); }
+    static_assert(ipow(3, A) * ipow(5, B) == Q && S >= 1 && S <= 4, "Q = 3^a 5^b with 1 <= a + b <= 4");
+    static constexpr int radix(int j) { return j < A ? 3 : 5; }
+    static constexpr int stride(int j) { return j == 0 ? 1 : stride(j - 1) * radix(j - 1); }  // S_j
+};
+
 #if defined(__HIPCC__)
+// the stages of the outer transform over the digits J, J - 1, ..., 0 (see LineQ::run)
+template <class QF, int J, int E, int CH, int T, int W, int Q>
+__device__ __forceinline__ void outer_stages(int k, int t, int w, int e0, cplx *stage, const cplx *__restrict__ twQ, double (&re)[E],
+                                             double (&im)[E]) {
+    constexpr int R = QF::radix(J), Sj = QF::stride(J), Mj = Q / Sj, Mn = Mj / R;
+    const int low = k / Mj, kap = k % Mj, kapn = k % Mn;  // (Mn = 1 at the first stage: kapn = 0)
+    const int rd = low + Sj * R * kapn;                  // + Sj * r: the R inputs of this stage
+    cplx wq[R];
+#pragma unroll
+    for (int r = 1; r < R; r++) wq[r] = twQ[(r * kap * Sj) % Q];
+    __syncthreads();
+    double vr[CH], vi[CH];
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const cplx *g = stage + ((c * T + t) * W + w) * Q + rd;
+        const cplx a0 = g[0];
+        double ar = a0.x, ai = a0.y;
+#pragma unroll
+        for (int r = 1; r < R; r++) {
+            const cplx b = g[r * Sj];
+            ar += b.x * wq[r].x - b.y * wq[r].y;
+            ai += b.x * wq[r].y + b.y * wq[r].x;
+        }
+        vr[c] = ar;
+        vi[c] = ai;
+    }
+    if constexpr (J > 0) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CH; c++) stage[((c * T + t) * W + w) * Q + low + Sj * kap] = cplx{vr[c], vi[c]};
+        outer_stages<QF, J - 1, E, CH, T, W, Q>(k, t, w, e0, stage, twQ, re, im);
+    } else {
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            re[e0 + c] = vr[c];
+            im[e0 + c] = vi[c];
+        }
+    }
+}
+
 // W lines per workgroup, column of the sub-engine = w + W * n2 (w fastest: global accesses coalesce along w);
 // LINE = true: LineInner layout (contiguous lines, x pass), column = line index.
 //   twP: exp(2 pi i k / P), k < P;  twN: exp(2 pi i k / (P Q)), k < P Q;  twQ: exp(2 pi i k / Q), k < Q
@@ -48,58 +102,24 @@ struct LineQ {
             re[e] = a;
             im[e] = b;
         }
-        // outer Q-point transforms (Q = 3^S) as S radix-3 stages on an LDS staging buffer, CH elements per round.
-        // Position p = d_0 + 3 d_1 + 9 d_2 of a group holds, before stage s, the partial transform whose digits d_j with
-        // j > S-1-s are already output digits; stage s sums over digit j = S-1-s:
-        //     out(d) = sum_r in(d with d_j = r) w_{3^(s+1)}^{r e_s},   e_s = n2 mod 3^(s+1)
-        // with the thread's own digits taken from n2 = d_{S-1} + 3 d_{S-2} + ... (reversed), so that after the last stage
-        // the thread holds exactly output k2 = n2 and nothing has to be exchanged again.
-        constexpr int S = Q == 3 ? 1 : (Q == 9 ? 2 : 3);
-        static_assert(Q == 3 || Q == 9 || Q == 27, "Q = 3, 9, 27");
-        int pos = 0;  // the thread's position p
-        {
-            int r = n2, w3 = Q / 3;
-#pragma unroll
-            for (int j = 0; j < S; j++) {
-                pos += (r % 3) * w3;
-                r /= 3;
-                w3 /= 3;
-            }
-        }
+        // Outer Q-point transforms, Q = 3^a 5^b, as a + b stages of radix 3 / 5 on an LDS staging buffer, CH elements per round.
+        // Input index n = d_0 + r_0 (d_1 + r_1 (d_2 + ...)) (digit j has radix r_j and weight S_j = r_0 ... r_{j-1}), so
+        //     X[k] = sum_{d_0} W_Q^{d_0 k}  sum_{d_1} W_{Q/S_1}^{d_1 k}  ...  sum_{d_{S-1}} W_{r_{S-1}}^{d_{S-1} k}
+        // and stage s sums over the digit j = S-1-s (the innermost sum first) with the twiddle W_{M_j}^{d_j k}, M_j = Q / S_j,
+        // which depends on k mod M_j only.  After it the partial result is a function of (d_0 .. d_{j-1}, k mod M_j) and is kept
+        // at position (d_0 .. d_{j-1} as a number below S_j) + S_j (k mod M_j).  The thread with n2 = k computes, at every stage,
+        // the entry whose low digits are the number k / M_j: (k / M_j, k mod M_j) is a one-to-one image of k, and at the last
+        // stage (j = 0, M_0 = Q) the thread is left with exactly X[k] — nothing has to be exchanged again.
+        using QF = QFactors<Q>;
+        constexpr int S = QF::S;
+        const int k = n2;
         cplx *stage = reinterpret_cast<cplx *>(lds);
 #pragma unroll
         for (int e0 = 0; e0 < E; e0 += CH) {
             __syncthreads();
 #pragma unroll
             for (int c = 0; c < CH; c++) stage[(((c * T + t) * W + w) * Q) + n2] = cplx{re[e0 + c], im[e0 + c]};
-#pragma unroll
-            for (int s = 0; s < S; s++) {
-                constexpr int P3[4] = {1, 3, 9, 27};
-                const int stride = Q / P3[s + 1];                  // 3^j, j = S-1-s
-                const int base   = pos - ((pos / stride) % 3) * stride;
-                const int es     = n2 % P3[s + 1];
-                const cplx w1 = twQ[(es * stride) % Q], w2 = twQ[(2 * es * stride) % Q];
-                __syncthreads();
-                double vr[CH], vi[CH];
-#pragma unroll
-                for (int c = 0; c < CH; c++) {
-                    const cplx *g = stage + ((c * T + t) * W + w) * Q + base;
-                    const cplx a = g[0], b = g[stride], d = g[2 * stride];
-                    vr[c] = a.x + (b.x * w1.x - b.y * w1.y) + (d.x * w2.x - d.y * w2.y);
-                    vi[c] = a.y + (b.x * w1.y + b.y * w1.x) + (d.x * w2.y + d.y * w2.x);
-                }
-                if (s + 1 < S) {
-                    __syncthreads();
-#pragma unroll
-                    for (int c = 0; c < CH; c++) stage[((c * T + t) * W + w) * Q + pos] = cplx{vr[c], vi[c]};
-                } else {
-#pragma unroll
-                    for (int c = 0; c < CH; c++) {
-                        re[e0 + c] = vr[c];
-                        im[e0 + c] = vi[c];
-                    }
-                }
-            }
+            outer_stages<QF, S - 1, E, CH, T, W, Q>(k, t, w, e0, stage, twQ, re, im);
         }
         __syncthreads();
     }

@@ -382,16 +382,30 @@ int launch_zfft_fields_np2(int L, const FieldLayout &F, const StoreLayout &S, in
     ZC(16, 3, 4) ZC(32, 3, 4) ZC(64, 3, 4) ZC(128, 3, 2) ZC(256, 3, 1) ZC(512, 3, 1)
     ZC(16, 9, 4) ZC(32, 9, 2) ZC(64, 9, 1) ZC(128, 9, 1)
     ZC(16, 27, 2) ZC(32, 27, 1) ZC(64, 27, 1)
+    // radix 5 (round 3): 5-smooth PPDs such as 1280, 2560, 3200, 3840, 4000, 4800, 5120, 5760, 6400
+    ZC(16, 5, 4) ZC(32, 5, 4) ZC(64, 5, 2) ZC(128, 5, 1) ZC(256, 5, 1)
+    ZC(16, 15, 4) ZC(32, 15, 2) ZC(64, 15, 1) ZC(128, 15, 1)
+    ZC(16, 25, 2) ZC(32, 25, 1) ZC(64, 25, 1)
+    ZC(16, 45, 1) ZC(32, 45, 1)
+    ZC(16, 75, 1)
+    ZC(16, 125, 1)
 #undef ZC
-    // 108 = 4 * 27: four elements per thread, one thread per sub-line (PPD = 6912 at R = 64 — the whole grid on ONE GPU)
+    // 4 * Q: four elements per thread, one thread per sub-line — the short z lines of large stream factors (108 = 4 * 27: PPD = 6912
+    // at R = 64, the whole grid on ONE GPU; 500 = 4 * 125: PPD = 4000 at R = 8)
     if (L == 108) return launch_zfft_fq_t<4, 4, 27, 2>(F, S, ky0, kyloc0, nky, Y, (const cplx *) tw, out, st);
-    fprintf(stderr, "zeldovich_hip: no z transform of length %d (16*2^k * {3, 9, 27} up to 1728)\n", L);
+    if (L == 500) return launch_zfft_fq_t<4, 4, 125, 1>(F, S, ky0, kyloc0, nky, Y, (const cplx *) tw, out, st);
+    if (L == 300) return launch_zfft_fq_t<4, 4, 75, 1>(F, S, ky0, kyloc0, nky, Y, (const cplx *) tw, out, st);
+    if (L == 180) return launch_zfft_fq_t<4, 4, 45, 2>(F, S, ky0, kyloc0, nky, Y, (const cplx *) tw, out, st);
+    if (L == 100) return launch_zfft_fq_t<4, 4, 25, 4>(F, S, ky0, kyloc0, nky, Y, (const cplx *) tw, out, st);
+    if (L == 60) return launch_zfft_fq_t<4, 4, 15, 4>(F, S, ky0, kyloc0, nky, Y, (const cplx *) tw, out, st);
+    fprintf(stderr, "zeldovich_hip: no z transform of length %d (16*2^k * {3, 9, 27, 5, 15, 25, 45, 75, 125})\n", L);
     return 2;
 }
+// columns per z-FFT workgroup (the generator prunes by it) = the NC of the table above
 int zfft_fields_np2_columns(int L) {
     switch (L) {
-        case 48: case 96: case 192: case 144: return 4;
-        case 384: case 288: case 432: case 108: return 2;
+        case 48: case 96: case 192: case 144: case 80: case 160: case 240: case 100: case 60: return 4;
+        case 384: case 288: case 432: case 108: case 320: case 480: case 400: case 180: return 2;
         default: return 1;
     }
 }
@@ -443,7 +457,14 @@ static int launch_xfft_q_t(const EpiConst &ec, const cplx *tw, const void *ring,
 // the PPDs with a y / x transform: N = P*Q
 #define NP2_SIZES(X)                                                                                                   \
     X(32, 3, 16) X(64, 3, 16) X(128, 3, 16) X(256, 3, 8) X(512, 3, 8) X(1024, 3, 4) X(32, 9, 16) X(64, 9, 16) X(128, 9, 8) \
-    X(256, 9, 4) X(512, 9, 2) X(32, 27, 8) X(64, 27, 8) X(128, 27, 4) X(256, 27, 2)
+    X(256, 9, 4) X(512, 9, 2) X(32, 27, 8) X(64, 27, 8) X(128, 27, 4) X(256, 27, 2)                                       \
+    /* radix 5 (round 3): 160 ... 5120, 480 ... 7680, 800 ... 6400, 1440 ... 5760, 2400, 4800, 4000, 8000 */               \
+    X(32, 5, 16) X(64, 5, 16) X(128, 5, 16) X(256, 5, 8) X(512, 5, 4) X(1024, 5, 2)                                        \
+    X(32, 15, 16) X(64, 15, 16) X(128, 15, 8) X(256, 15, 4) X(512, 15, 2)                                                  \
+    X(32, 25, 16) X(64, 25, 8) X(128, 25, 4) X(256, 25, 2)                                                                 \
+    X(32, 45, 8) X(64, 45, 4) X(128, 45, 2)                                                                                \
+    X(32, 75, 4) X(64, 75, 2)                                                                                              \
+    X(32, 125, 4) X(64, 125, 2)
 int launch_yfft_fields_np2(const FieldLayout &F, const StoreLayout &S, const void *tw, const void *store, int plane0, int nplanes,
                            int ring_pitch, void *ring, hipStream_t st) {
 #define YC(p, q, w) \
@@ -474,9 +495,10 @@ bool np2_supported_ppd(int N) {
 }
 bool np2_supported_zlen(int L) {
     int P, Q;
-    if (L == 108) return true;  // 4 * 27 (launch_zfft_fields_np2)
+    if (L == 108 || L == 500 || L == 300 || L == 180 || L == 100 || L == 60) return true;  // 4 * Q (launch_zfft_fields_np2)
     if (!np2_split(L, &P, &Q) || P < 16) return false;
-    return (Q == 3 && P <= 512) || (Q == 9 && P <= 128) || (Q == 27 && P <= 64);
+    return (Q == 3 && P <= 512) || (Q == 9 && P <= 128) || (Q == 27 && P <= 64) || (Q == 5 && P <= 256) || (Q == 15 && P <= 128)
+           || (Q == 25 && P <= 64) || (Q == 45 && P <= 32) || (Q == 75 && P <= 16) || (Q == 125 && P <= 16);
 }
 
 #ifdef ZD_TESTING
@@ -509,7 +531,12 @@ bool np2_split(int n, int *P, int *Q) {
         p /= 3;
         q *= 3;
     }
-    if (q == 1 || q > 27 || p < 4 || (p & (p - 1)) != 0) return false;
+    while (p % 5 == 0) {
+        p /= 5;
+        q *= 5;
+    }
+    const bool known = q == 3 || q == 9 || q == 27 || q == 5 || q == 15 || q == 25 || q == 45 || q == 75 || q == 125;
+    if (!known || p < 4 || (p & (p - 1)) != 0) return false;
     *P = p;
     *Q = q;
     return true;
@@ -532,6 +559,9 @@ int launch_test_fftq(int n, int kind, const void *twP, const void *twN, const vo
     TC(128, 16, 3, 4) TC(128, 16, 9, 4) TC(128, 16, 27, 4)
     TC(256, 16, 3, 4) TC(256, 16, 9, 4) TC(256, 16, 27, 2)
     TC(512, 16, 3, 4) TC(512, 16, 9, 2)
+    TC(16, 16, 5, 4) TC(32, 16, 5, 4) TC(256, 16, 5, 4) TC(1024, 16, 5, 2)
+    TC(16, 16, 15, 4) TC(64, 16, 15, 4) TC(16, 16, 25, 4) TC(128, 16, 25, 4) TC(16, 16, 45, 4) TC(32, 16, 75, 4) TC(16, 16, 125, 4) TC(32, 16, 125, 4)
+    TC(8, 8, 5, 4) TC(8, 8, 25, 4) TC(8, 8, 125, 4)
     TC(1024, 16, 3, 4)
 #undef TC
     fprintf(stderr, "zeldovich_hip: no composite FFT for length %d\n", n);
