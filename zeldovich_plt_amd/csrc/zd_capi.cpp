@@ -923,6 +923,8 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
     pl->ec.vnorm    = p->qPLT ? 1.0 : (sqrt(1. + 24 * p->f_cluster) - 1) * .25;  // output.cpp:78-82
     pl->ec.pack     = pl->pack == zd::PACK_PLTFIELD ? zd::PACK_PLT3 : pl->pack;  // the y stage builds the PLT3 arrays in the ring
     pl->ec.z_pair   = R / 2;
+    pl->ec.xdead_lo = 1;  // (none; set below for the field stores' ring)
+    pl->ec.xdead_hi = 0;
     pl->store_bytes_ = (int64_t) S.chunk_rows * S.pitch * nranks * 16;
     if (zd::pack_is_fields(pl->pack)) {
         std::vector<zd::FieldRow> rows;
@@ -959,6 +961,16 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         Q.kb_rows    = Q.zb_rows * pl->ring_planes;
         Q.chunk_rows = Q.kb_rows;
         PLCHECK(hipMalloc((void **) &pl->d_ring, (size_t) Q.chunk_rows * Q.pitch * 16));
+        if (S.prune & 4) {  // columns of the ring no row of which survives the zero rule (column_is_zero with ky = 0)
+            int lo = 0;
+            while (lo < pl->half && !zd::column_is_zero(S, lo, 0)) lo++;
+            bool all = true;  // the rule is an interval in |kx| for every ky: check it rather than assume it
+            for (int kx = lo; kx <= pl->half && all; kx++) all = zd::column_is_zero(S, kx, 0) && zd::column_is_zero(S, -kx, 0);
+            if (all && lo >= 1) {
+                pl->ec.xdead_lo = lo;
+                pl->ec.xdead_hi = pl->N - lo;
+            }
+        }
     }
     g.var_slots     = pl->d_red->sumsq;
 
@@ -1791,7 +1803,10 @@ static int test_fft_any(int32_t n, int64_t lines, int32_t axis_kind, const doubl
 int zd_test_fft(int32_t n, int64_t lines, int32_t axis_kind, const double *in, double *out) {
     if (!is_pow2(n)) {
         int P = 0, Q = 0;
-        if (zd::np2_split(n, &P, &Q) && zd::test_fftq_tile_width(n) > 0 && P >= 8) return test_fft_composite(n, lines, axis_kind, in, out);
+        // composite-length kernels where they exist and the batch is whole tiles; else the convolution kernels (any length,
+        // ragged batches)
+        if (zd::np2_split(n, &P, &Q) && zd::test_fftq_tile_width(n) > 0 && P >= 8 && lines % zd::test_fftq_tile_width(n) == 0)
+            return test_fft_composite(n, lines, axis_kind, in, out);
         return test_fft_any(n, lines, axis_kind, in, out);
     }
     const int W = zd::test_fft_tile_width(n);

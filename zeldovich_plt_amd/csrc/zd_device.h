@@ -241,7 +241,12 @@ struct EpiConst {
     int z_pair;    // PACK_ZAPAIR: z distance between the two planes a store plane carries (R/2)
     int qPLT, qdensity;
     double vnorm;  // (sqrt(1+24 f_cluster)-1)/4 without PLT, 1 with   output.cpp:78-82
+    // Field-store ring: the columns xdead_lo <= x <= xdead_hi are identically zero for every row (no (kx, ky) column with that kx
+    // survives the zero rule of zeldovich.cpp:350-353: 1 column at k_cutoff = 1, half of them at k_cutoff = 2).  The y stage does
+    // not transform or write tiles that lie wholly inside, the x stage takes zeros instead of reading them.  lo > hi: none
+    int xdead_lo, xdead_hi;
 };
+ZD_HD bool x_is_dead(const EpiConst &ec, int x) { return x >= ec.xdead_lo && x <= ec.xdead_hi; }
 
 // any even PPD (zd_kernels_any.hip): a length-n transform as a convolution of length M = 2^m >= 2n - 1 (Bluestein)
 struct AnyTab {

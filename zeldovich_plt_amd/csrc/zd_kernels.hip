@@ -1611,6 +1611,9 @@ __device__ __forceinline__ void yfft_f_unit_t(const FieldLayout &F, const StoreL
 #endif
     ZD_STAMP(0, unit, false);
     const int kx = x > N / 2 ? x - N : x;
+    // a tile none of whose columns has a live row (k_cutoff = 2: half of the tiles) is neither transformed nor written: the x
+    // stage takes zeros for those columns (EpiConst::xdead_lo / hi, the same rule)
+    if ((S.prune & 4) && __syncthreads_and(column_is_zero(S, kx, 0))) return;
     // potentials this array is made of.  ZA: E_a alone (a < 2), or (Z_0, Z_1).  PLT: the pairs (X, fX), (Y, Z), (fY, fZ) of
     // the fields X, Y, Z, fX, fY, fZ — every array is i P - Q like the ZA one of two
     const bool plt = F.nfield == 6;
@@ -1870,9 +1873,12 @@ __global__ __launch_bounds__(ROWS *NA *N / E, (ROWS * NA * N / E == 512 ? 4 : 1)
     zdfft::load_twiddles<PL>(twp, t, tw);
 #pragma unroll
     for (int e = 0; e < E; e++) {
-        const cplx v = ld_stream(src + t + T * e, ZD_TUNE(S.nt & 4));
-        re[e] = v.x;
-        im[e] = v.y;
+        // (dead columns of the field stores' ring are not even written: read element 0 of the row instead — one line for the
+        // whole wave — and take zero; branch-free, like the y stage's skipped rows)
+        const bool dead = x_is_dead(ec, t + T * e);
+        const cplx v = ld_stream(src + (dead ? 0 : t + T * e), ZD_TUNE(S.nt & 4));
+        re[e] = dead ? 0.0 : v.x;
+        im[e] = dead ? 0.0 : v.y;
     }
     if (!ZD_TUNE(S.prune & 32)) zdfft::fft_line_tw<PL, LDS>(re, im, t, line, lds, tw, twp);  // bit 5: tuning ablation
     if (ZD_TUNE(S.prune & 64) && re[0] != 123.456) return;                           // bit 6: tuning ablation (no epilogue)
@@ -1960,10 +1966,15 @@ __global__ __launch_bounds__(N / E) void k_xfft_seq(StoreLayout S, EpiConst ec, 
         const cplx *src = data + row_offset(S, pl, a, y);
 #pragma unroll
         for (int e = 0; e < E; e++) {
-            const cplx v = src[t + T * e];
+            const cplx v = src[x_is_dead(ec, t + T * e) ? 0 : t + T * e];  // (see k_xfft)
             re[e] = v.x;
             im[e] = v.y;
         }
+        int t3 = t;
+        asm volatile("" : "+v"(t3));  // the dead flags are recomputed behind the loads rather than kept beside them (registers)
+#pragma unroll
+        for (int e = 0; e < E; e++)
+            if (x_is_dead(ec, t3 + T * e)) re[e] = im[e] = 0.0;
         zdfft::fft_line<PL, LDS>(re, im, t, 0, lds, tw);
     };
     double cr[E], ci[E];
@@ -2035,9 +2046,10 @@ __global__ __launch_bounds__(N / E) void k_xfft_two(StoreLayout S, EpiConst ec, 
     double re[E], im[E];
 #pragma unroll
     for (int e = 0; e < E; e++) {
-        const cplx v = self[t + T * e];
-        re[e] = v.x;
-        im[e] = v.y;
+        const bool dead = x_is_dead(ec, t + T * e);  // (see k_xfft)
+        const cplx v = self[dead ? 0 : t + T * e];
+        re[e] = dead ? 0.0 : v.x;
+        im[e] = dead ? 0.0 : v.y;
     }
     zdfft::fft_line<PL, LDS>(re, im, t, 0, lds, tw);
     int t2 = t;

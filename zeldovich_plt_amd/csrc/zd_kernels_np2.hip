@@ -126,6 +126,7 @@ __global__ __launch_bounds__(W *Q *P / E) void k_yfft_fq(FieldLayout F, StoreLay
     const int x = tile * W + w, xm = x ? N - x : 0;
     const int zl = plane0 + blockIdx.z;
     const int kx = x > N / 2 ? x - N : x;
+    if ((S.prune & 4) && __syncthreads_and(column_is_zero(S, kx, 0))) return;  // a tile without a live row: see k_yfft_f
     // ZA: E_a alone (a < 2) or (Z_0, Z_1); PLT: the pairs (X, fX), (Y, Z), (fY, fZ) of the six sums — see k_yfft_f
     const bool plt = F.nfield == 6, two = plt || a == 2;
     const int f0 = plt ? (a == 0 ? 0 : (a == 1 ? 1 : 4)) : (a == 2 ? 1 : 2 * a);
@@ -208,7 +209,10 @@ __global__ __launch_bounds__(3 * Q *P / E) void k_xfft_q3(EpiConst ec, const cpl
     double re[E], im[E];
 #pragma unroll
     for (int e = 0; e < E; e++) {
-        const cplx v = src[Q * (t + T * e) + n2];
+        const int xi = Q * (t + T * e) + n2;
+        const bool dead = x_is_dead(ec, xi);  // (columns of the ring the y stage does not write: zd_device.h EpiConst)
+        cplx v = src[dead ? 0 : xi];
+        if (dead) v = cplx{0.0, 0.0};
         re[e] = v.x;
         im[e] = v.y;
     }
@@ -305,7 +309,10 @@ __global__ __launch_bounds__(Q *P / E) void k_xfft_seq_q(EpiConst ec, const cplx
     double re[E], im[E];
 #pragma unroll
     for (int e = 0; e < E; e++) {
-        const cplx v = src[Q * (t + T * e) + n2];
+        const int xi = Q * (t + T * e) + n2;
+        const bool dead = x_is_dead(ec, xi);  // (columns of the ring the y stage does not write: zd_device.h EpiConst)
+        cplx v = src[dead ? 0 : xi];
+        if (dead) v = cplx{0.0, 0.0};
         re[e] = v.x;
         im[e] = v.y;
     }
