@@ -961,15 +961,19 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         Q.kb_rows    = Q.zb_rows * pl->ring_planes;
         Q.chunk_rows = Q.kb_rows;
         PLCHECK(hipMalloc((void **) &pl->d_ring, (size_t) Q.chunk_rows * Q.pitch * 16));
-        if (S.prune & 4) {  // columns of the ring no row of which survives the zero rule (column_is_zero with ky = 0)
-            int lo = 0;
-            while (lo < pl->half && !zd::column_is_zero(S, lo, 0)) lo++;
-            bool all = true;  // the rule is an interval in |kx| for every ky: check it rather than assume it
-            for (int kx = lo; kx <= pl->half && all; kx++) all = zd::column_is_zero(S, kx, 0) && zd::column_is_zero(S, -kx, 0);
-            if (all && lo >= 1) {
-                pl->ec.xdead_lo = lo;
-                pl->ec.xdead_hi = pl->N - lo;
-            }
+
+    }
+    // columns no row of which survives the zero rule (column_is_zero with ky = 0): never written by the z stage, skipped by the
+    // y stage (whole tiles) and taken as zero by the x stage — power-of-two and composite kernels, every store; not the
+    // convolution path (it transforms everything) and not the f_NL passes (prune = 0)
+    if ((S.prune & 4) && !any_path && phi_mode == 0 && phik == nullptr) {
+        int lo = 0;
+        while (lo < pl->half && !zd::column_is_zero(S, lo, 0)) lo++;
+        bool all = true;  // the rule is an interval in |kx| for every ky: check it rather than assume it
+        for (int kx = lo; kx <= pl->half && all; kx++) all = zd::column_is_zero(S, kx, 0) && zd::column_is_zero(S, -kx, 0);
+        if (all && lo >= 1) {
+            pl->ec.xdead_lo = lo;
+            pl->ec.xdead_hi = pl->N - lo;
         }
     }
     g.var_slots     = pl->d_red->sumsq;

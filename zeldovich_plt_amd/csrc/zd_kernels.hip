@@ -1443,6 +1443,9 @@ __global__ __launch_bounds__(W *N / E, MINW) void k_yfft(StoreLayout S, const cp
     const int x = tile * W + w;
     const int zl = blockIdx.z, a = blockIdx.y;
     const int kxs = x > N / 2 ? x - N : x;
+    // a tile none of whose columns has a live row: the z stage wrote nothing there and the x stage takes zeros for those
+    // columns (EpiConst::xdead_lo / hi) — nothing to transform
+    if ((S.prune & 4) && __syncthreads_and(column_is_zero(S, kxs, 0))) return;
     double re[E], im[E];
     if constexpr (ONEBLOCK) {
         // single rank, all 2*Hq row slots of a (plane, array) contiguous: one 64-bit scalar base per
