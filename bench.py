@@ -100,7 +100,8 @@ def main():
     ap.add_argument("--stream", type=int, default=0, help="z-residue stream factor R (0 = auto)")
     ap.add_argument("--groups", type=int, default=0,
                     help="N > 1: independent groups of GPUs, residue passes dealt round-robin over them (0 = the library's choice: "
-                         "one GPU per group while there are at least N passes, else one group with the all-to-all exchange)")
+                         "one GPU per group while the passes, after at most one doubling of the stream factor, deal out over the N GPUs; else "
+                         "one group with the all-to-all exchange)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist", action="store_true",
                     help="take the N > 1 code path (torch.distributed RCCL group, zd.Comm id broadcast, per-rank gathers) whatever "

@@ -106,19 +106,26 @@ def test_trans_hazard_checker_detects_back_to_back_use():
 
 
 def test_choose_pass_groups_policy():
-    """PPD = 4096 ZA on 288 GB GPUs: 4 passes on one rank -> 2 and 4 GPUs run one GPU per group (no exchange); 8 GPUs run as ONE
-    group (the all-to-all of BASELINE config 4) unless ZD_PassGroups asks otherwise"""
+    """PPD = 4096 ZA on 288 GB GPUs: 4 passes on one rank -> 2 and 4 GPUs run one GPU per group (no exchange); 8 GPUs double the
+    stream factor (8 passes, one per GPU: still no exchange); ZD_PassGroups = 1 asks for ONE group (the all-to-all of BASELINE
+    config 4), which then gets at least four passes to pipeline.  One doubling at most: PPD = 2048 ZA (one pass) on 8 GPUs
+    exchanges."""
     import ctypes as C
     import zeldovich_plt_amd.api as zd
     L = zd.load_library()
     budget = (288 - 32) << 30
-    for ngpu, want_g in ((1, 1), (2, 2), (4, 4), (8, 1)):
-        p = zd.make_params(4096, icformat="RVZel", numblock=64)
+
+    def choose(ppd, ngpu, **kw):
+        p = zd.make_params(ppd, icformat="RVZel", numblock=64, **kw)
         g, R = C.c_int32(), C.c_int32()
         assert L.zd_choose_pass_groups(C.byref(p), ngpu, budget, C.byref(g), C.byref(R)) == 0
-        assert g.value == want_g, (ngpu, g.value, R.value)
-        assert (R.value // 2) % g.value == 0
-    p = zd.make_params(4096, icformat="RVZel", numblock=64, pass_groups=8)
-    g, R = C.c_int32(), C.c_int32()
-    assert L.zd_choose_pass_groups(C.byref(p), 8, budget, C.byref(g), C.byref(R)) == 0
-    assert g.value == 8 and R.value == 16  # eight passes, one per GPU
+        return g.value, R.value
+
+    for ngpu, want in ((1, (1, 8)), (2, (2, 8)), (4, (4, 8)), (8, (8, 16))):
+        assert choose(4096, ngpu) == want, ngpu
+    g, R = choose(4096, 8, pass_groups=1)
+    assert g == 1 and (R // 2) >= 4
+    assert choose(4096, 8, pass_groups=8) == (8, 16)
+    assert choose(4096, 8, stream_factor=8)[0] == 1      # a given stream factor is kept: 4 passes -> one group
+    assert choose(2048, 8)[0] == 1 and choose(2048, 2) == (2, 4)  # (two GPUs would exchange over a single link)
+    assert choose(4096, 8, qPLT=1, qPLTrescale=1) == (8, 16)  # 16 passes, two per GPU
