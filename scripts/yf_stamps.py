@@ -1,5 +1,5 @@
-"""In-kernel phase stamps of the field-store y stage (tuning library, zdk_set_stamps): where a workgroup's time goes.
-   ZD_LIB_PATH=.../libzeldovich_hip_tuning.so python scripts/yf_stamps.py"""
+"""In-kernel phase stamps of the field-store y stage (`make stamps` library, zdk_set_stamps): where a workgroup's time goes.
+   ZD_LIB_PATH=.../libzeldovich_hip_stamps.so python scripts/yf_stamps.py"""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

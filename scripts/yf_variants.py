@@ -12,10 +12,14 @@ p = zd.make_params(N, icformat="RVZel", profile=1, stream_factor=int(os.environ.
 nplanes = int(os.environ.get("PLANES", "32"))
 store = None
 ref = None
-VARS = [("default", {}), ("same row order", {"ZD_PRUNE": str(7 | 2048)}), ("W/2", {"ZD_YW": str(2 if N == 4096 else 4)}),
-        ("persistent", {"ZD_YPERSIST": "1"}), ("default", {}), ("same row order", {"ZD_PRUNE": str(7 | 2048)})]
+VARS = [("default", {}), ("nt ring stores", {"ZD_NT": "32"}), ("nt ring stores + x loads", {"ZD_NT": str(32 | 4)}),
+        ("nt record stores", {"ZD_NT": "128"}), ("nt ring st + x ld + rec st", {"ZD_NT": str(32 | 4 | 128)}),
+        ("nt E loads", {"ZD_NT": "64"}), ("default", {})]
+if os.environ.get("OLDVARS"):
+    VARS = [("default", {}), ("same row order", {"ZD_PRUNE": str(7 | 2048)}), ("W/2", {"ZD_YW": str(2 if N == 4096 else 4)}),
+            ("persistent", {"ZD_YPERSIST": "1"}), ("default", {}), ("same row order", {"ZD_PRUNE": str(7 | 2048)})]
 for name, env in VARS:
-    for k in ("ZD_YW", "ZD_YPERSIST", "ZD_PRUNE"):
+    for k in ("ZD_YW", "ZD_YPERSIST", "ZD_PRUNE", "ZD_NT"):
         os.environ.pop(k, None)
     os.environ.update(env)
     plan = zd.Plan(p, ps)
@@ -39,7 +43,7 @@ for name, env in VARS:
     else:
         CH = 1 << 28
         same = all(bool(torch.equal(ref[i:i + CH], out[i:i + CH])) for i in range(0, out.numel(), CH))
-    print("%-16s yfft %.1f ms (%.0f ms/step)   xfft %.1f ms (%.0f ms/step)  records==default: %s" % (
+    print("%-28s yfft %.1f ms (%.0f ms/step)   xfft %.1f ms (%.0f ms/step)  records==default: %s" % (
         name, ms["k_yfft"], ms["k_yfft"] * scale, ms["k_xfft"], ms["k_xfft"] * scale, same), flush=True)
     plan.close()
     del out

@@ -115,7 +115,7 @@ struct StoreLayout {
     // identically zero after the z FFT; it is neither written by the z stage nor read by the y stage
     int prune, kmax;
     double fund2, k2_cutoff;
-    int nt;  // tuning (ZD_NT): non-temporal accesses, bit 0 y loads, 1 y stores, 2 x loads, 3 z stores, 4 z loads
+    int nt;  // tuning (ZD_NT): non-temporal accesses, bit 0 y loads, 1 y stores, 2 x loads, 3 z stores, 4 z loads, 5 ring stores / 6 first-potential loads of k_yfft_f, 7 record stores
 };
 
 // true iff every mode of column (kx, ky) (signed wavenumbers) is zero for all kz

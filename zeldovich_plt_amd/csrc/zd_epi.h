@@ -13,7 +13,7 @@ __device__ __forceinline__ unsigned long long dbits(double v) { return (unsigned
 // one particle record (include/output.h:19-49; WriteParticlesSlab output.cpp:128-141: i = z, j = y, k = x,
 // displ = (qz, qy, qx), vel = (vz, vy, vx)); pos/vel are in this code's x, y, z order
 __device__ __forceinline__ void emit_record(char *__restrict__ records, long long pidx, const EpiConst &ec, int z, int yy,
-                                            int xx, const double (&pos)[3], const double (&vel)[3]) {
+                                            int xx, const double (&pos)[3], const double (&vel)[3], bool nt = false) {
     char *rec = records + pidx * ec.recsize;
     const unsigned int ij = ((unsigned int) z & 0xffffu) | (((unsigned int) yy & 0xffffu) << 16);
     const unsigned int k0 = ((unsigned int) xx & 0xffffu);
@@ -27,8 +27,15 @@ __device__ __forceinline__ void emit_record(char *__restrict__ records, long lon
         q1.y = __float_as_uint((float) vel[2]);
         q1.z = __float_as_uint((float) vel[1]);
         q1.w = __float_as_uint((float) vel[0]);
-        reinterpret_cast<uint4 *>(rec)[0] = q0;
-        reinterpret_cast<uint4 *>(rec)[1] = q1;
+        if (nt) {  // tuning knob (ZD_NT bit 7): streaming stores
+            typedef unsigned int zd_u4v __attribute__((ext_vector_type(4)));
+            zd_u4v a = {q0.x, q0.y, q0.z, q0.w}, b = {q1.x, q1.y, q1.z, q1.w};
+            __builtin_nontemporal_store(a, reinterpret_cast<zd_u4v *>(rec));
+            __builtin_nontemporal_store(b, reinterpret_cast<zd_u4v *>(rec) + 1);
+        } else {
+            reinterpret_cast<uint4 *>(rec)[0] = q0;
+            reinterpret_cast<uint4 *>(rec)[1] = q1;
+        }
     } else if (ec.icformat == 2) {  // RVdoubleZel: 56 B
         unsigned long long *r8 = reinterpret_cast<unsigned long long *>(rec);
         r8[0] = (unsigned long long) ij | ((unsigned long long) k0 << 32);

@@ -44,8 +44,18 @@ __device__ __forceinline__ void st_stream(cplx *p, cplx v, bool nt) {
         *p = v;
 }
 
-#ifdef ZD_TUNING
-// Diagnostic stamps (tuning library only): wave 0 of every workgroup of the y stage records shader-clock times of its phases,
+// ZD_NTBIT(S, b): bit b of the ZD_NT knob — from the environment in the tuning library, or fixed at compile time
+// (-DZD_NT_FORCE=bits on otherwise product flags: `make nt32`, ... for clean A/B timings; the tuning library's ablation branches
+// cost the y kernel 65 spilled registers)
+#ifdef ZD_NT_FORCE
+#define ZD_NTBIT(S, b) (((ZD_NT_FORCE) & (b)) != 0)
+#else
+#define ZD_NTBIT(S, b) ZD_TUNE((S).nt & (b))
+#endif
+
+#ifdef ZD_STAMPS
+// Diagnostic stamps (`make stamps`: the tuning library + -DZD_STAMPS — the stamps cost the y kernel 87 spilled registers, so the
+// plain tuning library, whose timings are compared, leaves them out): wave 0 of every workgroup of the y stage records shader-clock times of its phases,
 // the 100 MHz real-time clock at its start and the hardware id of its CU into zd_stamps[unit * 8 ...] (scripts/yf_stamps.py).
 __device__ unsigned long long *zd_stamps = nullptr;
 extern "C" int zdk_set_stamps(unsigned long long *buf) { return (int) hipMemcpyToSymbol(HIP_SYMBOL(zd_stamps), &buf, sizeof(buf)); }
@@ -1605,7 +1615,7 @@ __device__ __forceinline__ void yfft_f_unit_t(const FieldLayout &F, const StoreL
     constexpr int T = PL::T;
     const int x = tile * W + w, xm = (N - x) & (N - 1);
     const int zl = plane0 + pz;
-#ifdef ZD_TUNING
+#ifdef ZD_STAMPS
     if (zd_stamps && threadIdx.x == 0) {
         zd_stamps[(size_t) unit * 8 + 6] = __builtin_amdgcn_s_memrealtime();
         zd_stamps[(size_t) unit * 8 + 7] = (unsigned long long) __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11))  /* HW_ID */
@@ -1685,7 +1695,7 @@ __device__ __forceinline__ void yfft_f_unit_t(const FieldLayout &F, const StoreL
         asm volatile("" : "+v"(ta));
 #pragma unroll
         for (int e = 0; e < E; e++) {
-            const cplx u = p0[locate(ta, e)];
+            const cplx u = ld_stream(p0 + locate(ta, e), ZD_NTBIT(S, 64));
             re[e] = u.x;
             im[e] = u.y;
         }
@@ -1745,7 +1755,7 @@ __device__ __forceinline__ void yfft_f_unit_t(const FieldLayout &F, const StoreL
         if constexpr (N > 8192)  // one array plane of the ring exceeds 4 GB
             *reinterpret_cast<cplx *>(base + ((size_t) slot * pb + xb)) = cplx{re[e], im[e]};
         else
-            *reinterpret_cast<cplx *>(base + (slot * pb + xb)) = cplx{re[e], im[e]};
+            st_stream(reinterpret_cast<cplx *>(base + (slot * pb + xb)), cplx{re[e], im[e]}, ZD_NTBIT(S, 32));
     }
     ZD_STAMP(4, unit, false);  // stores issued
     ZD_STAMP(5, unit, true);   // stores acknowledged (wave 0's)
@@ -1879,7 +1889,7 @@ __global__ __launch_bounds__(ROWS *NA *N / E, (ROWS * NA * N / E == 512 ? 4 : 1)
         // (dead columns of the field stores' ring are not even written: read element 0 of the row instead — one line for the
         // whole wave — and take zero; branch-free, like the y stage's skipped rows)
         const bool dead = x_is_dead(ec, t + T * e);
-        const cplx v = ld_stream(src + (dead ? 0 : t + T * e), ZD_TUNE(S.nt & 4));
+        const cplx v = ld_stream(src + (dead ? 0 : t + T * e), ZD_NTBIT(S, 4));
         re[e] = dead ? 0.0 : v.x;
         im[e] = dead ? 0.0 : v.y;
     }
@@ -1918,7 +1928,7 @@ __global__ __launch_bounds__(ROWS *NA *N / E, (ROWS * NA * N / E == 512 ? 4 : 1)
                     }
                     if (records)
                         emit_record(records, 2 * plane_rec0 + (long long) a * N * N + (long long) y * N + xx, ec, z + a * ec.z_pair, y, xx,
-                                    pos, vel);
+                                    pos, vel, ZD_NTBIT(S, 128));
                 }
             }
             __syncthreads();
