@@ -1592,9 +1592,15 @@ __device__ __forceinline__ void yfft_f_unit(const FieldLayout &F, const StoreLay
         const int xcd = id & 7, s = id >> 3;  // s: position in this XCD's stream
         // (groups interleaved over the XCDs; giving each XCD a contiguous range of groups measured 12 % slower)
         const int g = (s / GS) * 8 + xcd, m = s % GS;  // group of 2*TPL tiles, member
-        const int q = m % (2 * TPL);
-        a    = m / (2 * TPL);
-        tile = q >= TPL ? NT - 1 - (TPL * g + (q - TPL)) : TPL * g + q;
+        // Order inside a group: the direct tiles (three arrays x the TPL tiles of a line, the two halves of a ring line next to
+        // each other) first, their mirror tiles 3*TPL positions later.  A tile and its mirror tile read the same potential
+        // lines; requests for a line that is still on its way are not merged by the L2, they fetch it again, so the second
+        // reader should arrive a few microseconds after the first (a workgroup starts every ~1 us on an XCD) and before the
+        // line is evicted.  y stage at PPD = 4096, distance in positions: 1 (tile, mirror, tile, mirror) 733 ms, 2 (round 2's
+        // order) 713, 6 (this) 683-688, 12 693, 24 720, 48 742.
+        const int side = m / (3 * TPL), mm = m % (3 * TPL);
+        a    = mm / TPL;
+        tile = side ? NT - 1 - (TPL * g + mm % TPL) : TPL * g + mm % TPL;
     } else {
         tile = id % NT;
         a    = id / NT;
