@@ -268,6 +268,32 @@ struct Reduce {
     unsigned long long maxneg[3][NSLOT];  // bit pattern of max(-v)
 };
 
+// y stage of the field stores: workgroup index -> (column tile of W columns, array a of 3).  Workgroups go to the 8 XCDs round-robin
+// by their linear index and every XCD has its own L2, so the workgroups that read or write the same lines are made neighbours ON
+// ONE XCD: the TPL tiles of a 128-byte ring line (W < 8), their mirror images (rows y > N/2 are read at column N - x: a tile's
+// mirrored reads are its mirror tile's direct reads, off by one column), for each of the three arrays.
+template <int NT, int W>
+__device__ __forceinline__ void ytile_of(int id, int &tile, int &a) {
+    constexpr int TPL = W >= 8 ? 1 : 8 / W, GS = 6 * TPL;
+    if constexpr (NT % (16 * TPL) == 0) {
+        const int xcd = id & 7, s = id >> 3;  // s: position in this XCD's stream
+        // (groups interleaved over the XCDs; giving each XCD a contiguous range of groups measured 12 % slower)
+        const int g = (s / GS) * 8 + xcd, m = s % GS;  // group of 2*TPL tiles, member
+        // Order inside a group: the direct tiles (three arrays x the TPL tiles of a line, the two halves of a ring line next to
+        // each other) first, their mirror tiles 3*TPL positions later.  A tile and its mirror tile read the same potential
+        // lines; requests for a line that is still on its way are not merged by the L2, they fetch it again, so the second
+        // reader should arrive a few microseconds after the first (a workgroup starts every ~1 us on an XCD) and before the
+        // line is evicted.  y stage at PPD = 4096, distance in positions: 1 (tile, mirror, tile, mirror) 733 ms, 2 (round 2's
+        // order) 713, 6 (this) 683-688, 12 693, 24 720, 48 742.
+        const int side = m / (3 * TPL), mm = m % (3 * TPL);
+        a    = mm / TPL;
+        tile = side ? NT - 1 - (TPL * g + mm % TPL) : TPL * g + mm % TPL;
+    } else {
+        tile = id % NT;
+        a    = id / NT;
+    }
+}
+
 #if defined(__HIPCC__)
 // zero rule of LoadPlane (src/zeldovich.cpp:350-356)
 __device__ __forceinline__ bool mode_is_zero(const GenConst &g, int kx, int ky, int kz, double k2) {

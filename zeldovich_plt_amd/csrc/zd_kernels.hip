@@ -1582,29 +1582,8 @@ __device__ __forceinline__ void yfft_f_unit(const FieldLayout &F, const StoreLay
     using LDS = zdfft::ColsInner<N, W>;
     constexpr int T = PL::T;
     constexpr int NT = N / W;
-    // Workgroup -> (column tile, array).  Workgroups go to the 8 XCDs round-robin by their linear index and every XCD has
-    // its own L2, so the workgroups that read or write the same lines are made consecutive ON ONE XCD: the TPL tiles of a
-    // 128-byte ring line (W < 8), their mirror images (rows y > N/2 are read at column N - x: a tile's mirrored reads are
-    // its mirror tile's direct reads, off by one column), for each of the three arrays.
-    constexpr int TPL = W >= 8 ? 1 : 8 / W, GS = 6 * TPL;
     int tile, a;
-    if constexpr (NT % (16 * TPL) == 0) {
-        const int xcd = id & 7, s = id >> 3;  // s: position in this XCD's stream
-        // (groups interleaved over the XCDs; giving each XCD a contiguous range of groups measured 12 % slower)
-        const int g = (s / GS) * 8 + xcd, m = s % GS;  // group of 2*TPL tiles, member
-        // Order inside a group: the direct tiles (three arrays x the TPL tiles of a line, the two halves of a ring line next to
-        // each other) first, their mirror tiles 3*TPL positions later.  A tile and its mirror tile read the same potential
-        // lines; requests for a line that is still on its way are not merged by the L2, they fetch it again, so the second
-        // reader should arrive a few microseconds after the first (a workgroup starts every ~1 us on an XCD) and before the
-        // line is evicted.  y stage at PPD = 4096, distance in positions: 1 (tile, mirror, tile, mirror) 733 ms, 2 (round 2's
-        // order) 713, 6 (this) 683-688, 12 693, 24 720, 48 742.
-        const int side = m / (3 * TPL), mm = m % (3 * TPL);
-        a    = mm / TPL;
-        tile = side ? NT - 1 - (TPL * g + mm % TPL) : TPL * g + mm % TPL;
-    } else {
-        tile = id % NT;
-        a    = id / NT;
-    }
+    ytile_of<NT, W>(id, tile, a);
     const int unit = pz * 3 * NT + id;
     if (F.nfield == 6 || a == 2)  // workgroup-uniform
         yfft_f_unit_t<N, E, W, true>(F, S, tw, store, plane0, ring_pitch, ring, tile, a, pz, unit, t, w, lds);

@@ -122,7 +122,8 @@ __global__ __launch_bounds__(W *Q *P / E) void k_yfft_fq(FieldLayout F, StoreLay
     constexpr int T = LQ::T;
     const int c = threadIdx.x % (W * Q), t = threadIdx.x / (W * Q);
     const int w = c % W, n2 = c / W;
-    const int tile = blockIdx.x % NT, a = blockIdx.x / NT;
+    int tile, a;
+    ytile_of<NT, W>((int) blockIdx.x, tile, a);  // XCD-aware order (zd_device.h)
     const int x = tile * W + w, xm = x ? N - x : 0;
     const int zl = plane0 + blockIdx.z;
     const int kx = x > N / 2 ? x - N : x;
