@@ -281,10 +281,11 @@ __device__ __forceinline__ void ytile_of(int id, int &tile, int &a) {
         const int g = (s / GS) * 8 + xcd, m = s % GS;  // group of 2*TPL tiles, member
         // Order inside a group: the direct tiles (three arrays x the TPL tiles of a line, the two halves of a ring line next to
         // each other) first, their mirror tiles 3*TPL positions later.  A tile and its mirror tile read the same potential
-        // lines; requests for a line that is still on its way are not merged by the L2, they fetch it again, so the second
-        // reader should arrive a few microseconds after the first (a workgroup starts every ~1 us on an XCD) and before the
-        // line is evicted.  y stage at PPD = 4096, distance in positions: 1 (tile, mirror, tile, mirror) 733 ms, 2 (round 2's
-        // order) 713, 6 (this) 683-688, 12 693, 24 720, 48 742.
+        // lines; a workgroup starts every ~1 us on an XCD, and the two do best a few microseconds apart — close enough for the
+        // L2 to still hold what the first one fetched, not so close that both ask for a line while it is on its way (measured:
+        // asking at the same moment is the worst case).  y stage at PPD = 4096, distance in positions: 1 (tile, mirror, tile,
+        // mirror) 733 ms, 2 (round 2's order) 713, 6 (this) 683-688, 12 693, 24 720, 48 742.  FETCH_SIZE is the same 1.4 TB per
+        // step at distance 2 and 6 (profiles/r03a, r03b): the bytes fetched did not change, the time the requests take did.
         const int side = m / (3 * TPL), mm = m % (3 * TPL);
         a    = mm / TPL;
         tile = side ? NT - 1 - (TPL * g + mm % TPL) : TPL * g + mm % TPL;
