@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of non-temporal access bits (zd_kernels.hip ZD_NTBIT) on product flags: build each variant first, e.g.
-#   (cd zeldovich_plt_amd/csrc && make ntforce NT=32 && mv build/libzeldovich_hip_ntforce.so build/libzeldovich_hip_nt32.so && rm -rf build/ntforce)
+#   (cd zeldovich_plt_amd/csrc && make variant NAME=nt32 FLAGS=-DZD_NT_FORCE=32)
 # then on the GPU box:  bash scripts/nt_ab.sh "" _nt32 _nt128 ""
 for v in "$@"; do
   echo "== lib$v" >> gpurun_out/ntab.log

@@ -996,6 +996,9 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         const int64_t row_b = y_bytes_per_row(pl);
         int64_t slab_b = (int64_t) 3 << 29;  // ~1.5 GB per buffer
         if (const char *env = tune_env("ZD_SLAB_MB")) slab_b = (int64_t) atoll(env) << 20;
+#ifdef ZD_SLAB_MB_FORCE  // experiment (make variant)
+        slab_b = (int64_t) ZD_SLAB_MB_FORCE << 20;
+#endif
         int rows = (int) std::max<int64_t>(1, slab_b / row_b);
         rows     = std::min(rows, pl->Hq);
         if (zd::pack_is_fields(pl->pack)) {  // whole row blocks

@@ -2254,7 +2254,11 @@ int zfft_fields_tile_columns(int L);
 
 // z rows walked by one generator thread: 16; 4 for the short composite z lines (L = 108 = 4 * 27: PPD = 6912 on ONE GPU);
 // 4, 2 or 1 for the arbitrary lengths of the any-PPD path (zd_kernels_any.hip)
+#ifdef ZD_GEN_ZR_FORCE  // experiment (make variant): a shorter walk = smaller generator tiles
+static int gen_zr(int L) { return L % ZD_GEN_ZR_FORCE == 0 ? ZD_GEN_ZR_FORCE : (L % 2 == 0 ? 2 : 1); }
+#else
 static int gen_zr(int L) { return L % GEN_ZR == 0 ? GEN_ZR : (L % 4 == 0 ? 4 : (L % 2 == 0 ? 2 : 1)); }
+#endif
 
 template <int ZR, int NJ, bool PLT, bool PLAW>
 static int launch_gen_z(const GenConst &g, const GenJumps &J, const JobList &jobs, const StoreLayout &S, int ky0, int nky,
