@@ -767,30 +767,29 @@ __device__ __forceinline__ void eigenmode_fast(const GenConst &g, int kx, int ky
 // consecutive x, so a mode reads two fully coalesced 32-byte entries per lane instead of 8 corners x 2 loads, and blends 4
 // values with 2 weights instead of 32 FMAs with 8.  (Association differs from the single expression of zeldovich.cpp:218-225 —
 // (w_x w_y) sums first, then w_z — by a few 1e-16 of the components.)  One slab is 65 x rows x N x 32 B (128 MB at PPD = 4096).
-//   grid: (ceil(N / 256), nrows)   block: 256
+//   grid: (ceil(N / 256), nrows, eig_ppd / 2 + 1)   block: 256
+// (one table cell cz per workgroup: with the cells in a loop the launch was 128 workgroups of 65 dependent table reads, 165 us in
+// front of every generator launch — 42 ms per step at PPD=2048, 0.7 s at PPD=4096)
 __global__ __launch_bounds__(256) void k_eig_lines(GenConst g, int ky0, int ky_stride, int nrows, double *__restrict__ lines) {
-    const int N = g.N, x = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
+    const int N = g.N, x = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y, cz = blockIdx.z;
     if (x >= N) return;
     const int kx = x > g.half ? x - N : x, ky = ky0 + row * ky_stride;
     const EigXY q = eig_xy(g, eig_axis(g, eig_index_x(g, kx)), eig_axis(g, ky));
-    const int hz = (int) g.eig_ppd / 2 + 1;
     const double2 *E = reinterpret_cast<const double2 *>(g.eig);
     double2 *out = reinterpret_cast<double2 *>(lines);
-    for (int cz = 0; cz < hz; cz++) {
-        double e0 = 0.0, e1 = 0.0, e2 = 0.0, e3 = 0.0;
+    double e0 = 0.0, e1 = 0.0, e2 = 0.0, e3 = 0.0;
 #pragma unroll
-        for (int c = 0; c < 4; c++)
-            if (q.w[c] != 0) {
-                const double2 q0 = E[q.base[c] + cz * 2], q1 = E[q.base[c] + cz * 2 + 1];
-                e0 += q.w[c] * q0.x;
-                e1 += q.w[c] * q0.y;
-                e2 += q.w[c] * q1.x;
-                e3 += q.w[c] * q1.y;
-            }
-        const size_t i = (((size_t) cz * nrows + row) * N + x) * 2;
-        out[i]     = double2{e0, e1};
-        out[i + 1] = double2{e2, e3};
-    }
+    for (int c = 0; c < 4; c++)
+        if (q.w[c] != 0) {
+            const double2 q0 = E[q.base[c] + cz * 2], q1 = E[q.base[c] + cz * 2 + 1];
+            e0 += q.w[c] * q0.x;
+            e1 += q.w[c] * q0.y;
+            e2 += q.w[c] * q1.x;
+            e3 += q.w[c] * q1.y;
+        }
+    const size_t i = (((size_t) cz * nrows + row) * N + x) * 2;
+    out[i]     = double2{e0, e1};
+    out[i + 1] = double2{e2, e3};
 }
 
 // eigenmode_fast from the slab's (x, y)-interpolated lines (k_eig_lines); `row` = row of the slab
@@ -2426,7 +2425,7 @@ int launch_gen(const GenConst &g, const GenJumps &J, const JobList &jobs, const 
 
 // (x, y)-interpolated eigenmode lines of the rows ky0, ky0 + ky_stride, ... of a slab (GenConst::eig_lines)
 int launch_eig_lines(const GenConst &g, int ky0, int ky_stride, int nrows, void *lines, hipStream_t st) {
-    dim3 grid((g.N + 255) / 256, nrows), block(256);
+    dim3 grid((g.N + 255) / 256, nrows, (unsigned) g.eig_ppd / 2 + 1), block(256);
     hipLaunchKernelGGL(k_eig_lines, grid, block, 0, st, g, ky0, ky_stride, nrows, (double *) lines);
     ZD_LAUNCH_CHECK();
     return 0;
