@@ -9,7 +9,8 @@ TAG=${TAG:-r02a}
 ARGS=${ARGS:-}
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-isolated $ARGS > $R/gpurun_out/prof_${TAG}_bench.log 2>&1 || { tail -5 $R/gpurun_out/prof_${TAG}_bench.log; exit 1; }
-tail -1 $R/gpurun_out/prof_${TAG}_bench.log | cut -c1-300
+grep '^{"metric"' $R/gpurun_out/prof_${TAG}_bench.log | tail -1 > $R/gpurun_out/${TAG}_bench_under_rocprof.json
+cut -c1-300 $R/gpurun_out/${TAG}_bench_under_rocprof.json
 for c in FETCH_SIZE WRITE_SIZE; do
 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${TAG}_$c -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-isolated $ARGS > $R/gpurun_out/pmc_${TAG}_$c.log 2>&1 || { tail -5 $R/gpurun_out/pmc_${TAG}_$c.log; exit 1; }
 done
