@@ -1974,44 +1974,42 @@ __global__ __launch_bounds__(N / E) void k_xfft_seq(StoreLayout S, EpiConst ec, 
             if (x_is_dead(ec, t3 + T * e)) re[e] = im[e] = 0.0;
         zdfft::fft_line<PL, LDS>(re, im, t, 0, lds, tw);
     };
-    double cr[E], ci[E];
-    load_fft(2, cr, ci);
-    constexpr int NH = XFFT_SEQ_NH(N, 2, LDS::SIZE);  // three real fields per pass of N/NH columns (2*2 >= 3)
-    constexpr int NXH = N / NH, EH = E / NH;
-    static_assert(EH >= 1 && 3 * NXH <= LDS::SIZE, "epilogue staging must fit the FFT's LDS");
+    // array 2 = qz_r0 + i qz_r1: the real part (plane r0, written first) stays in registers, the imaginary part waits in LDS
+    // behind the transform's area — with both in registers next to a second array's 64 the kernel spilled 32-78 registers
+    double *czi = lds + LDS::SIZE;
+    double cr[E];
+    {
+        double ci[E];
+        load_fft(2, cr, ci);
+#pragma unroll
+        for (int e = 0; e < E; e++) czi[t + T * e] = ci[e];
+    }
     const int z = z_first + z_step * (int) blockIdx.y;
     double mp[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
     const long long plane_rec0 = 2 * (long long) blockIdx.y * N * N;
-    double *fld = lds;
 #pragma unroll
     for (int w2 = 0; w2 < 2; w2++) {
         double ar[E], ai[E];
         __syncthreads();
         load_fft(w2, ar, ai);
+        // records straight from the registers (element e of thread t is x = t + T e; adjacent lanes write adjacent records),
+        // as in k_xfft's field-store branch: no staging through LDS, no barriers
+        int t2 = t;
+        asm volatile("" : "+v"(t2));
 #pragma unroll
-        for (int h = 0; h < NH; h++) {
-            __syncthreads();
+        for (int e = 0; e < E; e++) {
+            const int xx = t2 + T * e;
+            const double pos[3] = {ar[e], ai[e], w2 ? czi[xx] : cr[e]};  // (a thread reads back what it wrote itself)
+            const double vel[3] = {pos[0] * ec.vnorm, pos[1] * ec.vnorm, pos[2] * ec.vnorm};
 #pragma unroll
-            for (int e2 = 0; e2 < EH; e2++) {
-                const int e = h * EH + e2, xl = t + T * e - h * NXH;
-                fld[xl]           = ar[e];
-                fld[NXH + xl]     = ai[e];
-                fld[2 * NXH + xl] = w2 ? ci[e] : cr[e];
+            for (int j = 0; j < 3; j++) {
+                mp[j] = fmax(mp[j], pos[j]);
+                mn[j] = fmax(mn[j], -pos[j]);
             }
-            __syncthreads();
-            for (int i = threadIdx.x; i < NXH; i += NT) {
-                const int xx = i + h * NXH;
-                const double pos[3] = {fld[i], fld[NXH + i], fld[2 * NXH + i]};
-                const double vel[3] = {pos[0] * ec.vnorm, pos[1] * ec.vnorm, pos[2] * ec.vnorm};
-#pragma unroll
-                for (int j = 0; j < 3; j++) {
-                    mp[j] = fmax(mp[j], pos[j]);
-                    mn[j] = fmax(mn[j], -pos[j]);
-                }
-                if (records) emit_record(records, plane_rec0 + (long long) w2 * N * N + (long long) y * N + xx, ec, z + w2 * ec.z_pair, y, xx, pos, vel);
-            }
+            if (records) emit_record(records, plane_rec0 + (long long) w2 * N * N + (long long) y * N + xx, ec, z + w2 * ec.z_pair, y, xx, pos, vel);
         }
     }
+    __syncthreads();
     xfft_reduce<NT, 3>(lds, red, 0.0, mp, mn);
 }
 
@@ -2665,7 +2663,7 @@ static int launch_xfft_t(const StoreLayout &S, const EpiConst &ec, const void *t
 template <int N, int E>
 static int launch_xfft_seq_t(const StoreLayout &S, const EpiConst &ec, const void *tw, const void *data, int plane0,
                              int nplanes, int z_first, int z_step, void *records, Reduce *red, hipStream_t st) {
-    const size_t shmem = sizeof(double) * zdfft::LineInner<N, 1>::SIZE;
+    const size_t shmem = sizeof(double) * (zdfft::LineInner<N, 1>::SIZE + N);  // + Im of array 2 (k_xfft_seq)
     set_dyn_lds<k_xfft_seq<N, E>>(shmem);
     dim3 grid(N, nplanes), block(N / E);
     hipLaunchKernelGGL((k_xfft_seq<N, E>), grid, block, shmem, st, S, ec, (const cplx *) tw, (const cplx *) data, plane0, z_first,
