@@ -291,7 +291,7 @@ __global__ __launch_bounds__(3 * Q *P / E) void k_xfft_q3(EpiConst ec, const cpl
 // results in registers: that cost 240-450 spilled dwords in every single-launch form tried).
 //   block: Q*P/E
 template <int P, int E, int Q, bool PLT>
-__global__ __launch_bounds__(Q *P / E) void k_xfft_seq_q(EpiConst ec, const cplx *__restrict__ twP, const cplx *__restrict__ twN,
+__global__ __launch_bounds__(Q *P / E, 4) void k_xfft_seq_q(EpiConst ec, const cplx *__restrict__ twP, const cplx *__restrict__ twN,
                                                        const cplx *__restrict__ twQ, cplx *ring, int emit,
                                                        int ring_pitch, int z_first, int z_step, char *__restrict__ records,
                                                        Reduce *__restrict__ red) {
@@ -346,6 +346,90 @@ __global__ __launch_bounds__(Q *P / E) void k_xfft_seq_q(EpiConst ec, const cplx
             mn[j] = fmax(mn[j], -pos[j]);
         }
         if (records) emit_record(records, rec0 + xx, ec, z, y, xx, pos, vel);
+    }
+    // workgroup reduction through LDS (the workgroup is N/16 threads: not a whole number of waves, so no wave shuffles)
+    __syncthreads();
+    for (int j = 0; j < 3; j++) {
+        lds[threadIdx.x * 6 + j]     = mp[j];
+        lds[threadIdx.x * 6 + 3 + j] = mn[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {  // thread j reduces one of the six quantities
+        double m = 0;
+        for (int i = 0; i < NT; i++) m = fmax(m, lds[i * 6 + threadIdx.x]);
+        const int slot = (blockIdx.x + blockIdx.y * 7) % NSLOT;
+        if (threadIdx.x < 3)
+            atomicMax(&red->maxpos[threadIdx.x][slot], dbits(fabs(m)));
+        else
+            atomicMax(&red->maxneg[threadIdx.x - 3][slot], dbits(fabs(m)));
+    }
+}
+
+// The ZA ring in ONE launch where three lines do not fit a workgroup (the form k_xfft_seq has for PPD = 8192): Q*P/E threads own
+// a row and transform its arrays one after the other.  Array 2 = qz_r0 + i qz_r1 goes first: its real part (plane r0, written
+// first) stays in registers, its imaginary part waits in LDS behind the transform's area; then each of (qx + i qy)_r is
+// transformed and its plane's records leave straight from the registers.  Against the two-launch form: no round trip of array 2
+// through the ring (32 of 88 bytes per particle at PPD = 6912).
+//   grid: (N, planes)   block: Q*P/E
+template <int P, int E, int Q>
+__global__ __launch_bounds__(Q *P / E) void k_xfft_seq1_q(EpiConst ec, const cplx *__restrict__ twP, const cplx *__restrict__ twN,
+                                                        const cplx *__restrict__ twQ, const cplx *__restrict__ ring, int ring_pitch,
+                                                        int z_first, int z_step, char *__restrict__ records,
+                                                        Reduce *__restrict__ red) {
+    constexpr int N = P * Q;
+    using LQ = zdfft::LineQ<P, E, Q, 1, true>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int T = LQ::T, NT = T * Q;
+    const int t = threadIdx.x % T, n2 = threadIdx.x / T;
+    const int y = blockIdx.x, pl = blockIdx.y;
+    double *czi = lds + LQ::LDS_DOUBLES;  // [x]: Im of array 2; a thread reads back only what it wrote itself
+    double cr[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) cr[e] = 0.0;
+    const int z = z_first + z_step * (int) blockIdx.y;
+    double mp[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
+    // ONE copy of the transform in a rolled loop over the arrays 2, 0, 1 (three inlined copies spilled 350-760 registers)
+#pragma unroll 1
+    for (int it = 0; it < 3; it++) {
+        const int a = it == 0 ? 2 : it - 1;
+        const cplx *src = ring + ((long long) (pl * 3 + a) * N + y) * ring_pitch;
+        double re[E], im[E];
+        int ta = t;
+        asm volatile("" : "+v"(ta));
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int xi = Q * (ta + T * e) + n2;
+            const bool dead = x_is_dead(ec, xi);  // (columns of the ring the y stage does not write: zd_device.h EpiConst)
+            cplx v = src[dead ? 0 : xi];
+            if (dead) v = cplx{0.0, 0.0};
+            re[e] = v.x;
+            im[e] = v.y;
+        }
+        __syncthreads();  // the previous transform's last LDS reads are done
+        LQ::run(re, im, t, 0, n2, lds, twP, twN, twQ);
+        int t2 = t;
+        asm volatile("" : "+v"(t2));
+        if (it == 0) {
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                cr[e] = re[e];
+                czi[(t2 + T * e) + P * n2] = im[e];
+            }
+            continue;
+        }
+        const long long rec0 = 2 * (long long) blockIdx.y * N * N + (long long) a * N * N + (long long) y * N;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int xx = (t2 + T * e) + P * n2;
+            const double pos[3] = {re[e], im[e], a ? czi[xx] : cr[e]};
+            const double vel[3] = {pos[0] * ec.vnorm, pos[1] * ec.vnorm, pos[2] * ec.vnorm};
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                mp[j] = fmax(mp[j], pos[j]);
+                mn[j] = fmax(mn[j], -pos[j]);
+            }
+            if (records) emit_record(records, rec0 + xx, ec, z + a * ec.z_pair, y, xx, pos, vel);
+        }
     }
     // workgroup reduction through LDS (the workgroup is N/16 threads: not a whole number of waves, so no wave shuffles)
     __syncthreads();
@@ -451,6 +535,16 @@ static int launch_xfft_q_t(const EpiConst &ec, const cplx *tw, const void *ring,
     }
     using LQ = zdfft::LineQ<P, E, Q, 1, true>;
     const size_t need = sizeof(double) * (size_t) LQ::LDS_DOUBLES, red_b = sizeof(double) * 6 * threads;
+    if constexpr (!PLT) {  // ZA ring: one launch, Im of array 2 parked behind the transform's area
+        const size_t need1 = need + sizeof(double) * N, shmem1 = need1 > red_b ? need1 : red_b;
+        if (shmem1 <= 160 * 1024) {
+            set_dyn_lds<k_xfft_seq1_q<P, E, Q>>(shmem1);
+            hipLaunchKernelGGL((k_xfft_seq1_q<P, E, Q>), dim3(N, nplanes), dim3(threads), shmem1, st, ec, tw, tw + P, tw + P + N,
+                               (const cplx *) ring, ring_pitch, z_first, z_step, (char *) records, red);
+            ZD_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     const size_t shmem = need > red_b ? need : red_b;
     if (shmem > 160 * 1024) return 2;
     set_dyn_lds<k_xfft_seq_q<P, E, Q, PLT>>(shmem);
