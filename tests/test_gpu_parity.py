@@ -730,6 +730,7 @@ def test_fft_lines_composite_lengths(zd, n, kind):
     (192, dict(stream_factor=4, k_cutoff=2.0)),
     (288, dict(stream_factor=2)),                              # 288 = 32 * 9
     (96, dict(stream_factor=2, fmt="Zeldovich", k_cutoff=1.5)),
+    (288, dict(stream_factor=6)),                              # a stream factor that is not a power of two: z lines of 48, 3 passes
     (288, dict(stream_factor=2, k_cutoff=2.0, fmt="ZelSimple")),  # (Q = 27 sizes start at 864: beyond the oracle's O(N^4) plain DFT;
                                                                   # covered by test_non_power_of_two_oversampling_invariance and test_non_power_of_two_short_z_lines)
 ])
@@ -863,6 +864,44 @@ def test_non_power_of_two_short_z_lines(zd, oracle, ps):
                        lambda z, rec: hi.__setitem__(z // 2, rec["d"][::2, ::2].copy()) if (z % 2 == 0 and z // 2 in zs) else None)
     for z in zs:
         assert np.abs(hi[z] - lo[z]).max() < 1e-12 * np.abs(lo[z]).max(), z
+
+
+@pytest.mark.parametrize("n,Rs,plt", [(864, (6, 18), False), (864, (6,), True), (960, (10, 12, 20), False)])
+def test_stream_factors_that_are_not_powers_of_two(zd, oracle, ps, n, Rs, plt):
+    """composite PPDs take any even stream factor whose z lines have a composite transform (PPD = 6912 on one GPU: R = 36, 18 passes,
+    where the powers of two offer R = 64, 32 passes): sample planes equal to the R = 2 run's, ZA (two residues r, r + R/2 per pass)
+    and PLT; the automatic choice picks such a factor when it is the smallest that fits"""
+    zs = (1, n // 2 + 7, n - 2)
+    kw = dict(icformat="Zeldovich")
+    eig = None
+    if plt:
+        kw = dict(icformat="RVdoubleZel", qPLT=1, qPLTrescale=1, PLT_target_z=5.0, f_cluster=0.97)
+        eig = oracle.synthetic_eigenmodes(32)
+    ref = {}
+    zd.generate_planes(zd.make_params(n, stream_factor=2, **kw), ps, lambda z, rec: ref.__setitem__(z, rec.copy()) if z in zs else None, eig=eig)
+    for R in Rs:
+        got, seen = {}, []
+
+        def take(z, rec):
+            seen.append(z)
+            if z in zs:
+                got[z] = rec.copy()
+
+        st = zd.generate_planes(zd.make_params(n, stream_factor=R, **kw), ps, take, eig=eig)
+        assert st["stream_factor"] == R and sorted(seen) == list(range(n))
+        for z in zs:
+            for f in ("d", "v"):
+                if f in ref[z].dtype.names:
+                    assert np.abs(got[z][f] - ref[z][f]).max() <= 1e-12 * np.abs(ref[z][f]).max(), (R, z, f)
+
+
+def test_stream_factor_choice_on_composite_grids(zd):
+    """PPD = 6912 on a 288 GB GPU: the smallest even factor whose store fits and whose z lines (192 = 64 * 3) have a transform"""
+    import ctypes as C
+    L = zd.load_library()
+    p = zd.make_params(6912, icformat="RVZel", numblock=64)
+    R = L.zd_choose_stream_factor(C.byref(p), 1, (288 - 32) << 30)
+    assert R % 2 == 0 and 6912 % R == 0 and R < 64, R
 
 
 # ---- ZD_Version = 1: legacy mt19937 streams with rejection sampling (SURVEY §8 f4) ----

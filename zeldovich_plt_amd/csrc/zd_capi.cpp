@@ -351,6 +351,13 @@ static int field_ring_planes(int64_t N, int64_t Zq) {
     return (int) std::max<int64_t>(1, std::min<int64_t>(Zq, ((int64_t) 6 << 30) / plane_b));
 }
 
+// stream factors the composite (2^a 3^b 5^c) kernels take: any EVEN divisor of PPD (two residues r, r + R/2 share a ZA pass) — or
+// 1 — whose z lines have a composite transform.  R = 36 gives PPD = 6912 z lines of 192 = 64 * 3 and 18 passes where the powers of two
+// offer 64 (z lines of 108) and 32 passes: the store of a pass must fit, and between 128 GB and 260 GB there was nothing.
+static bool np2_stream_factor_ok(int64_t N, int R) {
+    return R >= 1 && (R == 1 || R % 2 == 0) && N % R == 0 && zd::np2_supported_zlen((int) (N / R));
+}
+
 int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes) {
     const int64_t N = p->ppd;
     // ZA without density: two residues share a pass, so R = 2 is preferred over R = 1 whenever the z FFT is long enough
@@ -367,14 +374,13 @@ int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes
         return -1;
     };
     if (np2 && (!zd::pack_is_fields(pack_mode(p, 2)) || !zd::np2_supported_ppd((int) N) || (N / 2) % (nranks * zd::FIELD_RB))) return any_factor();
-    for (int R = R0; N / R >= 32 && N % R == 0; R *= 2) {
-        if ((N / R) % nranks) break;
+    for (int R = R0; np2 ? N / R >= 12 : (N / R >= 32 && N % R == 0); R = np2 ? (R == 1 ? 2 : R + 2) : R * 2) {
+        if (np2) {  // any even divisor whose z lines have a composite transform (np2_stream_factor_ok)
+            if (!np2_stream_factor_ok(N, R) || (N / R) % nranks) continue;
+        } else if ((N / R) % nranks)
+            break;
         if (N / R > 4096) continue;  // z-FFT kernels exist up to length 4096
         if (N > 4096 && N / R > 2048) continue;  // the field store's z FFT stops at 2048 and PPD > 4096 has no other store worth using
-        if (np2 && !zd::np2_supported_zlen((int) (N / R))) {
-            if (N / R < 48) break;
-            continue;
-        }
         int64_t store = store_bytes(p, R, nranks);
         if (nranks > 1) store += std::min<int64_t>(store, (int64_t) 9 << 30);  // + the two-slot exchange ring (zd_multi.cpp), not a second store
         if (zd::pack_is_fields(pack_mode(p, R)))
@@ -388,7 +394,7 @@ int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes
 static int plan_plane_step(const zd_params *p, int R, int nranks) {
     const int64_t N = p->ppd;
     if (!is_pow2(N)) {  // composite kernels (field stores) or the convolution path (reference arrays)
-        const bool comp = zd::np2_supported_ppd((int) N) && p->f_NL == 0. && is_pow2(R) && N % R == 0 && zd::np2_supported_zlen((int) (N / R))
+        const bool comp = zd::np2_supported_ppd((int) N) && p->f_NL == 0. && np2_stream_factor_ok(N, R)
                           && zd::pack_is_fields(pack_mode(p, R)) && (N / 2) % (nranks * zd::FIELD_RB) == 0;
         if (!comp) return 1;
     }
@@ -420,10 +426,12 @@ int zd_choose_pass_groups(const zd_params *p, int ngpu, int64_t budget_bytes, in
             // one pass per GPU, 0.36-0.38 s predicted against 0.30-0.33 s for the all-to-all — within the
             // uncertainty of the link rate, and independent of it.  More than one doubling is not worth the generations.
             const int Rmax = q.stream_factor > 0 ? R1 : 2 * R1;
-            for (int R2 = R1; R2 <= Rmax; R2 *= 2) {
-                const bool len_ok = p->ppd % R2 == 0 && p->ppd / R2 >= 32
-                                    && (is_pow2(p->ppd) || zd::np2_supported_zlen((int) (p->ppd / R2)));
-                if (!len_ok) break;
+            for (int R2 = R1; R2 <= Rmax; R2 = is_pow2(p->ppd) ? R2 * 2 : R2 + 2) {
+                const bool len_ok = is_pow2(p->ppd) ? (p->ppd % R2 == 0 && p->ppd / R2 >= 32) : np2_stream_factor_ok(p->ppd, R2);
+                if (!len_ok) {
+                    if (is_pow2(p->ppd)) break;
+                    continue;
+                }
                 const int npass = R2 / plan_plane_step(&q, R2, 1);
                 if (npass >= ngpu && npass % ngpu == 0) {
                     g = ngpu;
@@ -447,8 +455,14 @@ int zd_choose_pass_groups(const zd_params *p, int ngpu, int64_t budget_bytes, in
                     R / plan_plane_step(p, R, gsz), g);
             return 1;
         }
-        R *= 2;
-        if (p->ppd % R || p->ppd / R < 32 || (p->ppd / R) % gsz) return 1;
+        if (is_pow2(p->ppd)) {
+            R *= 2;
+            if (p->ppd % R || p->ppd / R < 32 || (p->ppd / R) % gsz) return 1;
+        } else {  // composite PPD: the next even factor the composite kernels take
+            do R += 2;
+            while (p->ppd / R >= 12 && !(np2_stream_factor_ok(p->ppd, R) && (p->ppd / R) % gsz == 0));
+            if (p->ppd / R < 12) return 1;
+        }
     }
     *groups        = g;
     *stream_factor = R;
@@ -571,14 +585,14 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
     if (!pow2) {
         int Rg = p->stream_factor > 0 ? p->stream_factor : 2;
         if (p->stream_factor <= 0)  // no factor given: the first one whose z lines the composite kernels have
-            for (int r = 2; N % r == 0 && N / r >= 48; r *= 2)
-                if (zd::np2_supported_zlen((int) (N / r))) {
+            for (int r = 2; N / r >= 12; r += 2)
+                if (np2_stream_factor_ok(N, r)) {
                     Rg = r;
                     break;
                 }
         np2_R = Rg;
-        const bool comp_ok = zd::np2_supported_ppd((int) N) && phi_mode == 0 && phik == nullptr && is_pow2(Rg) && N % Rg == 0
-                             && zd::np2_supported_zlen((int) (N / Rg)) && zd::pack_is_fields(pack_mode(p, Rg))
+        const bool comp_ok = zd::np2_supported_ppd((int) N) && phi_mode == 0 && phik == nullptr && np2_stream_factor_ok(N, Rg)
+                             && zd::pack_is_fields(pack_mode(p, Rg))
                              && (N / 2) % (nranks * zd::FIELD_RB) == 0;
         any_path = !comp_ok;
     }
@@ -600,7 +614,7 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
                     (long long) N, R);
             return 1;
         }
-    } else if (!is_pow2(R) || N % R || N / R < 32 || N / R > 4096 || (np2 && !zd::np2_supported_zlen((int) (N / R)))) {
+    } else if (np2 ? !np2_stream_factor_ok(N, R) : (!is_pow2(R) || N % R || N / R < 32 || N / R > 4096)) {
         fprintf(stderr, "zeldovich_hip: stream factor %d invalid for PPD %lld\n", R, (long long) N);
         return 1;
     }
