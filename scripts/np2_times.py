@@ -1,11 +1,16 @@
-"""Timed runs of composite PPDs (y-stage order experiments): python scripts/np2_times.py 3456 6912:2 6400:2"""
+"""Timed runs of big / composite PPDs: python scripts/np2_times.py 3456 6912:2 6400:2 6912:1:plt   (PPD[:k_cutoff[:plt]])"""
 import sys, time, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 import zeldovich_plt_amd.api as zd
 ps = zd.PowerSpectrum.from_file('tests/golden/wmap1new.pow', 720.0)
 for spec in sys.argv[1:]:
-    n, _, kc = spec.partition(":")
-    n, kc = int(n), float(kc or 1)
-    a = zd.generate(zd.make_params(n, icformat="RVZel", profile=1, k_cutoff=kc), ps, collect=False)
-    print(n, "k_cutoff", kc, "R", a["stream_factor"], "sec", round(a["seconds_total"], 2),
+    f = spec.split(":")
+    n, kc, plt = int(f[0]), float(f[1]) if len(f) > 1 and f[1] else 1.0, len(f) > 2 and f[2] == "plt"
+    kw, eig = {}, None
+    if plt:
+        import bench
+        eig = bench.synthetic_eigenmodes(128)
+        kw = dict(qPLT=1, qPLTrescale=1, PLT_target_z=5.0, z_initial=49.0)
+    a = zd.generate(zd.make_params(n, icformat="RVZel", profile=1, k_cutoff=kc, **kw), ps, eig=eig, collect=False)
+    print(n, "PLT" if plt else "ZA", "k_cutoff", kc, "R", a["stream_factor"], "sec", round(a["seconds_total"], 2),
           {k: round(v) for k, v in a["kernel_ms"].items()}, "var", repr(a["density_variance"]), flush=True)
