@@ -48,7 +48,7 @@ typedef struct zd_params {
     int32_t qPLTrescale; /* ZD_qPLT_rescale */
     int32_t icformat;    /* ZD_FMT_* */
     /* --- optional MI355X knobs (0 = let the library decide); not present in the reference --- */
-    int32_t stream_factor; /* R: number of z-residue passes (power of two) */
+    int32_t stream_factor; /* R: number of z-residue classes (a power of two; composite PPDs: any even divisor whose z lines PPD/R have a transform) */
     int32_t profile;       /* 1: bracket every kernel with hipEvents and report per-kernel ms */
     int32_t store_mode;    /* ZD_STORE_*: what the block store between the z and y passes holds (0 = best available) */
     int32_t serial_z;      /* 1: generator and z FFT on ONE stream (per-kernel timing runs); 0: two overlapped streams */
@@ -132,7 +132,7 @@ typedef int (*zd_slab_cb)(void *user, int64_t z, int64_t n_records, const void *
 int zd_generate(const zd_params *p, const zd_pk *pk, const double *eig, int64_t eig_ppd, zd_slab_cb cb,
                 void *user, zd_stats *out);
 
-/* Smallest power-of-two stream factor R whose block store of one pass (+ the y->x ring of the field store, + the exchange
+/* Smallest stream factor R (a power of two; composite PPDs: any even divisor with a supported z length) whose block store of one pass (+ the y->x ring of the field store, + the exchange
  * ring for nranks > 1) fits in budget_bytes; -1 if none. */
 int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes);
 /* How `ngpu` GPUs share the job (zd_params.pass_groups, 0 = automatic): *groups independent groups of ngpu / *groups ranks
