@@ -286,6 +286,9 @@ __device__ __forceinline__ void ytile_of(int id, int &tile, int &a) {
         // asking at the same moment is the worst case).  y stage at PPD = 4096, distance in positions: 1 (tile, mirror, tile,
         // mirror) 733 ms, 2 (round 2's order) 713, 6 (this) 683-688, 12 693, 24 720, 48 742.  FETCH_SIZE is the same 1.4 TB per
         // step at distance 2 and 6 (profiles/r03a, r03b): the bytes fetched did not change, the time the requests take did.
+        // (A tile reads its direct rows ascending, then its mirrored rows = its partner's direct rows descending; the partner runs
+        // the same code, i.e. asks for the shared lines in exactly the reverse order — last fetched, first re-read.  Giving one
+        // side the other order costs 17 %.)
         const int side = m / (3 * TPL), mm = m % (3 * TPL);
         a    = mm / TPL;
         tile = side ? NT - 1 - (TPL * g + mm % TPL) : TPL * g + mm % TPL;
