@@ -1919,6 +1919,37 @@ __global__ __launch_bounds__(ROWS *NA *N / E, (ROWS * NA * N / E == 512 ? 4 : 1)
             xfft_reduce<NT, NA>(lds, red, ssq, mp, mn);
             return;
         }
+        if (ec.pack == PACK_PLT3) {
+            // qx + i vx | qy + i qz | vy + i vz, ONE plane: the threads of line 1 hold qy, qz at their columns and write the
+            // records; lines 0 and 2 hand {qx, vx} and {vy, vz} over through LDS ([row][x] and [ROWS + row][x], 16 B each) —
+            // one exchange and one barrier instead of NH staging rounds of all six fields.
+            double2 *st = reinterpret_cast<double2 *>(lds);
+            if (a != 1) {
+#pragma unroll
+                for (int e = 0; e < E; e++) st[((a ? ROWS : 0) + row) * N + t + T * e] = double2{re[e], im[e]};
+            }
+            __syncthreads();
+            if (a == 1) {
+                int t2 = t;
+                asm volatile("" : "+v"(t2));
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    const int xx = t2 + T * e;
+                    const double2 c0 = st[row * N + xx], c2 = st[(ROWS + row) * N + xx];
+                    const double pos[3] = {c0.x, re[e], im[e]};
+                    const double vel[3] = {c0.y * ec.vnorm, c2.x * ec.vnorm, c2.y * ec.vnorm};
+#pragma unroll
+                    for (int j = 0; j < 3; j++) {
+                        mp[j] = fmax(mp[j], pos[j]);
+                        mn[j] = fmax(mn[j], -pos[j]);
+                    }
+                    if (records) emit_record(records, plane_rec0 + (long long) y * N + xx, ec, z, y, xx, pos, vel);
+                }
+            }
+            __syncthreads();
+            xfft_reduce<NT, NA>(lds, red, ssq, mp, mn);
+            return;
+        }
     }
     // The unpacked fields go through LDS in NH passes over x so that the staging area stays <= 64 KB
     // (two workgroups per CU): pass h covers x in [h*N/NH, (h+1)*N/NH) = elements e in [h*E/NH, ...).
@@ -2644,7 +2675,10 @@ static int launch_xfft_t(const StoreLayout &S, const EpiConst &ec, const void *t
                          int nplanes, int z_first, int z_step, void *records, float *density, Reduce *red, hipStream_t st) {
     constexpr int WL = ROWS * NA, threads = WL * N / E;
     constexpr size_t fft_dbl = zdfft::LineInner<N, WL>::SIZE, fld_dbl = (size_t) ROWS * 2 * NA * N / XFFT_NH(N, NA, ROWS);
-    const size_t shmem = sizeof(double) * (fft_dbl > fld_dbl ? fft_dbl : fld_dbl);
+    // PACK_PLT3: lines 0 and 2 hand their results to line 1 through LDS, 2 x 16 B per column and row (k_xfft)
+    const size_t plt_dbl = (NA == 3 && ec.pack == PACK_PLT3) ? (size_t) 4 * ROWS * N : 0;
+    const size_t base_dbl = fft_dbl > fld_dbl ? fft_dbl : fld_dbl;
+    const size_t shmem = sizeof(double) * (base_dbl > plt_dbl ? base_dbl : plt_dbl);
     if (threads > 1024) {
         fprintf(stderr, "zeldovich_hip: x pass for PPD %d with %d arrays needs %d threads per workgroup: unsupported\n", N, NA, threads);
         return 2;
