@@ -264,11 +264,13 @@ def test_ppd512_za_default_store_vs_oracle(zd, oracle):
 
 
 @pytest.mark.parametrize("n,R,modes", [
-    (6912, 64, [(-2001, 1777, 1200), (5, 3, -7)]),
+    (6912, 64, [(-2001, 1777, 1200), (5, 3, -7)]),   # R given: z lines of 108 = 4 * 27 (the only factor a power of two offers)
+    (6912, 0, [(-2001, 1777, 1200)]),                # R chosen: 36 (z lines of 192 = 64 * 3, 18 passes) on a 288 GB GPU
     (4096, 8, [(-1001, 1177, 1200), (5, 3, -7), (0, 2, 0)]),   # the bench workload: k_genf / k_zfft_f<512> / k_yfft_f<4096> / k_xfft<4096,16,3,1>
 ])
 def test_ppd6912_on_one_gpu_plane_waves(zd, oracle, n, R, modes):
-    """PPD = 6912 = 2^8 3^3 at ZD_k_cutoff = 1 — the production Abacus grid — on ONE GPU: R = 64, z lines of 108 = 4 * 27;
+    """PPD = 6912 = 2^8 3^3 at ZD_k_cutoff = 1 — the production Abacus grid — on ONE GPU: R = 64, z lines of 108 = 4 * 27, and the
+    factor the library chooses, R = 36;
     and PPD = 4096 at ZD_k_cutoff = 1 (the headline workload, R = 8) through the general one-mode generator + the
     production z / y / x kernels.
     One-mode runs against the closed form q_j(x) = -2 (k_j fund / k^2) (Re D sin t + Im D cos t), v = vnorm q, with D(k) from
@@ -284,8 +286,9 @@ def test_ppd6912_on_one_gpu_plane_waves(zd, oracle, n, R, modes):
     vnorm = (np.sqrt(1 + 24 * fc) - 1) / 4
     yy, xx = np.meshgrid(np.arange(0, n, 16), np.arange(0, n, 16), indexing="ij")
     for mode in modes:
-        got, info = _planes(zd, ps, n, [z], stride=16, fmt="RVdoubleZel", f_cluster=fc, qonemode=1, one_mode=mode)
-        assert info["R"] == R
+        got, info = _planes(zd, ps, n, [z], stride=16, fmt="RVdoubleZel", f_cluster=fc, qonemode=1, one_mode=mode,
+                            stream_factor=R if n == 6912 else 0)
+        assert info["R"] == (R if R else 36)
         r, D = (C.c_uint64 * 2)(), (C.c_double * 2)()
         L.zdo_mode_draw(C.byref(op), C.byref(opk), mode[0], mode[1], mode[2], r, D)
         k2 = sum(m * m for m in mode) * fund * fund
