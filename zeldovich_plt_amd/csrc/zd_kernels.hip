@@ -1849,7 +1849,9 @@ __device__ __forceinline__ void xfft_consume(const EpiConst &ec, const double *_
         }
 }
 
-template <int N, int E, int NA, int ROWS>
+// PLT3D: the instantiation for the PLT3 packing (records from line 1's registers); a separate kernel so that the ZA field-store
+// instantiation keeps its 138 registers (with both branches in one body: 144, and 1 % on the default bench's x stage)
+template <int N, int E, int NA, int ROWS, bool PLT3D = false>
 __global__ __launch_bounds__(ROWS *NA *N / E, (ROWS * NA * N / E == 512 ? 4 : 1)) void k_xfft(StoreLayout S, EpiConst ec, const cplx *__restrict__ tw,
                                                          const cplx *__restrict__ data, int plane0,
                                                          int z_first, int z_step, char *__restrict__ records,
@@ -1884,7 +1886,7 @@ __global__ __launch_bounds__(ROWS *NA *N / E, (ROWS * NA * N / E == 512 ? 4 : 1)
     const int z = z_first + z_step * (int) blockIdx.y;
     double ssq = 0.0, mp[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
     const long long plane_rec0 = (long long) blockIdx.y * N * N;
-    if constexpr (NA == 3) {
+    if constexpr (NA == 3 && !PLT3D) {
         if (ec.pack == PACK_ZAFIELD) {
             // Field-store ring: (qx + i qy)_r0 | (qx + i qy)_r1 | qz_r0 + i qz_r1.  The threads of lines 0 and 1 already
             // hold qx, qy of THEIR plane at their columns x = t + T*e; only the shared third array goes through LDS
@@ -1919,7 +1921,9 @@ __global__ __launch_bounds__(ROWS *NA *N / E, (ROWS * NA * N / E == 512 ? 4 : 1)
             xfft_reduce<NT, NA>(lds, red, ssq, mp, mn);
             return;
         }
-        if (ec.pack == PACK_PLT3) {
+    }
+    if constexpr (NA == 3 && PLT3D) {
+        {
             // qx + i vx | qy + i qz | vy + i vz, ONE plane: the threads of line 1 hold qy, qz at their columns and write the
             // records; lines 0 and 2 hand {qx, vx} and {vy, vz} over through LDS ([row][x] and [ROWS + row][x], 16 B each) —
             // one exchange and one barrier instead of NH staging rounds of all six fields.
@@ -2687,8 +2691,17 @@ static int launch_xfft_t(const StoreLayout &S, const EpiConst &ec, const void *t
         fprintf(stderr, "zeldovich_hip: x pass for PPD %d with %d arrays needs %zu B of LDS (> 160 KB): unsupported\n", N, NA, shmem);
         return 2;
     }
-    set_dyn_lds<k_xfft<N, E, NA, ROWS>>(shmem);
     dim3 grid(N / ROWS, nplanes), block(threads);
+    if constexpr (NA == 3) {
+        if (ec.pack == PACK_PLT3) {
+            set_dyn_lds<k_xfft<N, E, NA, ROWS, true>>(shmem);
+            hipLaunchKernelGGL((k_xfft<N, E, NA, ROWS, true>), grid, block, shmem, st, S, ec, (const cplx *) tw, (const cplx *) data, plane0,
+                               z_first, z_step, (char *) records, density, red);
+            ZD_LAUNCH_CHECK();
+            return 0;
+        }
+    }
+    set_dyn_lds<k_xfft<N, E, NA, ROWS>>(shmem);
     hipLaunchKernelGGL((k_xfft<N, E, NA, ROWS>), grid, block, shmem, st, S, ec, (const cplx *) tw, (const cplx *) data,
                        plane0, z_first, z_step, (char *) records, density, red);
     ZD_LAUNCH_CHECK();
