@@ -2743,6 +2743,11 @@ int launch_xfft(const StoreLayout &S, const EpiConst &ec, const void *tw, const 
         return launch_xfft_two_t<16384, 16, false>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, red, st);
     if (S.N == 8192 && S.narray == 3 && ec.pack == PACK_PLT3)  // the ring of the PLT field store
         return launch_xfft_two_t<8192, 16, true>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, red, st);
+    // PPD = 2048, PLT3 packing: one row per workgroup (384 threads, 64 KB of LDS: two independent workgroups per CU) instead of
+    // two (768 threads): x stage 164.6 -> 151.6 ms
+    if (S.N == 2048 && S.narray == 3 && ec.pack == PACK_PLT3)
+        return launch_xfft_t<2048, 16, 3, 1>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, density, red, st);
+    // (the ZA field ring at 2048 is indifferent: 104.2 ms with two rows, 105.7 with one)
 #define XCASE(n, e, rows1, rows2, rows4, rows3z, rows3p)                                                              \
     case n:                                                                                                           \
         if (S.narray == 1) return launch_xfft_t<n, e, 1, rows1>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, density, red, st); \
