@@ -307,7 +307,10 @@ def main():
                          "alg_bytes_per_particle": alg[dom],
                          "note": "achieved = SURVEY 8d algorithmic bytes of this unit per launch / hipEvent launch time "
                                  "(launch stream, timed region): a figure of merit against the reference's traffic, not "
-                                 "bytes moved — this implementation moves fewer (design_bytes_per_step; PMC in traffic)"},
+                                 "bytes moved — this implementation moves fewer (design_bytes_per_step; PMC in traffic)"
+                                 + ("; the Z stage = generator || z FFT on two streams is bound by their vector work (pcg64, "
+                                    "Box-Muller, P(k) per mode), not by HBM: see kernels.k_yfft / k_xfft for the HBM-bound units"
+                                    if dom == "z_stage" and not plt else "")},
             "kernels": per_kernel,
             "kernels_isolated": isolated,
         }

@@ -1978,14 +1978,15 @@ __global__ __launch_bounds__(ROWS *NA *N / E, (ROWS * NA * N / E == 512 ? 4 : 1)
     xfft_reduce<NT, NA>(lds, red, ssq, mp, mn);
 }
 
-// k_xfft_seq: the x pass of the field store for sizes where the three lines of a row do not fit a workgroup (PPD = 8192:
-// 1536 threads, 209 KB of LDS).  N/E threads own ONE row and transform its arrays one after the other.  The ring holds
+// k_xfft_seq: the x pass of the field store with ONE row per workgroup: N/E threads transform its three arrays one after the
+// other.  Built for PPD = 8192, where the three lines of a row do not fit a workgroup (1536 threads, 209 KB of LDS); since round 3
+// also the form PPD = 4096 and 2048 run, because it leaves room for two (four) independent workgroups per CU.  The ring holds
 // (qx + i qy)_r0 | (qx + i qy)_r1 | qz_r0 + i qz_r1, so the two delivered planes need {array 0, Re array 2} and
 // {array 1, Im array 2}: array 2 is transformed first and kept in registers, then each of the other two is transformed
 // and its plane's records are written at once — never more than two arrays' results are live.
 //   grid: (N, nplanes)   block: N/E
 template <int N, int E>
-__global__ __launch_bounds__(N / E) void k_xfft_seq(StoreLayout S, EpiConst ec, const cplx *__restrict__ tw,
+__global__ __launch_bounds__(N / E, 2) void k_xfft_seq(StoreLayout S, EpiConst ec, const cplx *__restrict__ tw,
                                                    const cplx *__restrict__ data, int plane0, int z_first, int z_step,
                                                    char *__restrict__ records, Reduce *__restrict__ red) {
     using PL  = zdfft::Plan<N, E>;
@@ -1994,11 +1995,26 @@ __global__ __launch_bounds__(N / E) void k_xfft_seq(StoreLayout S, EpiConst ec, 
     constexpr int T = PL::T, NT = T;
     const int t = threadIdx.x;
     const int y = blockIdx.x, pl = plane0 + blockIdx.y;
-    auto load_fft = [&](int a, double (&re)[E], double (&im)[E]) {
+    // array 2 = qz_r0 + i qz_r1 goes first: its real part (plane r0, written first) stays in registers, its imaginary part waits in
+    // LDS behind the transform's area.  ONE copy of the transform in a rolled loop over the arrays 2, 0, 1 (three inlined copies
+    // with both arrays' results live spilled 28-78 registers).
+    double *czi = lds + LDS::SIZE;
+    double cr[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) cr[e] = 0.0;
+    const int z = z_first + z_step * (int) blockIdx.y;
+    double mp[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
+    const long long plane_rec0 = 2 * (long long) blockIdx.y * N * N;
+#pragma unroll 1
+    for (int it = 0; it < 3; it++) {
+        const int a = it == 0 ? 2 : it - 1;
         const cplx *src = data + row_offset(S, pl, a, y);
+        double re[E], im[E];
+        int ta = t;
+        asm volatile("" : "+v"(ta));
 #pragma unroll
         for (int e = 0; e < E; e++) {
-            const cplx v = src[x_is_dead(ec, t + T * e) ? 0 : t + T * e];  // (see k_xfft)
+            const cplx v = src[x_is_dead(ec, ta + T * e) ? 0 : ta + T * e];  // (see k_xfft)
             re[e] = v.x;
             im[e] = v.y;
         }
@@ -2007,41 +2023,31 @@ __global__ __launch_bounds__(N / E) void k_xfft_seq(StoreLayout S, EpiConst ec, 
 #pragma unroll
         for (int e = 0; e < E; e++)
             if (x_is_dead(ec, t3 + T * e)) re[e] = im[e] = 0.0;
+        __syncthreads();  // the previous transform's last LDS reads are done
         zdfft::fft_line<PL, LDS>(re, im, t, 0, lds, tw);
-    };
-    // array 2 = qz_r0 + i qz_r1: the real part (plane r0, written first) stays in registers, the imaginary part waits in LDS
-    // behind the transform's area — with both in registers next to a second array's 64 the kernel spilled 32-78 registers
-    double *czi = lds + LDS::SIZE;
-    double cr[E];
-    {
-        double ci[E];
-        load_fft(2, cr, ci);
-#pragma unroll
-        for (int e = 0; e < E; e++) czi[t + T * e] = ci[e];
-    }
-    const int z = z_first + z_step * (int) blockIdx.y;
-    double mp[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
-    const long long plane_rec0 = 2 * (long long) blockIdx.y * N * N;
-#pragma unroll
-    for (int w2 = 0; w2 < 2; w2++) {
-        double ar[E], ai[E];
-        __syncthreads();
-        load_fft(w2, ar, ai);
-        // records straight from the registers (element e of thread t is x = t + T e; adjacent lanes write adjacent records),
-        // as in k_xfft's field-store branch: no staging through LDS, no barriers
         int t2 = t;
         asm volatile("" : "+v"(t2));
+        if (it == 0) {
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                cr[e] = re[e];
+                czi[t2 + T * e] = im[e];  // (a thread reads back only what it wrote itself)
+            }
+            continue;
+        }
+        // records straight from the registers (element e of thread t is x = t + T e; adjacent lanes write adjacent records),
+        // as in k_xfft's field-store branch: no staging through LDS, no barriers
 #pragma unroll
         for (int e = 0; e < E; e++) {
             const int xx = t2 + T * e;
-            const double pos[3] = {ar[e], ai[e], w2 ? czi[xx] : cr[e]};  // (a thread reads back what it wrote itself)
+            const double pos[3] = {re[e], im[e], a ? czi[xx] : cr[e]};
             const double vel[3] = {pos[0] * ec.vnorm, pos[1] * ec.vnorm, pos[2] * ec.vnorm};
 #pragma unroll
             for (int j = 0; j < 3; j++) {
                 mp[j] = fmax(mp[j], pos[j]);
                 mn[j] = fmax(mn[j], -pos[j]);
             }
-            if (records) emit_record(records, plane_rec0 + (long long) w2 * N * N + (long long) y * N + xx, ec, z + w2 * ec.z_pair, y, xx, pos, vel);
+            if (records) emit_record(records, plane_rec0 + (long long) a * N * N + (long long) y * N + xx, ec, z + a * ec.z_pair, y, xx, pos, vel);
         }
     }
     __syncthreads();
@@ -2739,6 +2745,13 @@ int launch_xfft(const StoreLayout &S, const EpiConst &ec, const void *tw, const 
     // workgroup, its arrays in sequence
     if (S.N == 8192 && S.narray == 3 && ec.pack == PACK_ZAFIELD)
         return launch_xfft_seq_t<8192, 16>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, red, st);
+    // PPD = 4096 too (round 3): the one-row form is 256 threads, 190 registers and 68 KB of LDS — TWO independent workgroups per
+    // CU, whose load / transform / store phases overlap — where the three-line k_xfft is one workgroup of 768 threads and 104 KB:
+    // x stage 798 -> 713 ms (3.85 TB at 5.4 TB/s)
+    if (S.N == 4096 && S.narray == 3 && ec.pack == PACK_ZAFIELD)
+        return launch_xfft_seq_t<4096, 16>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, red, st);
+    if (S.N == 2048 && S.narray == 3 && ec.pack == PACK_ZAFIELD)  // 128 threads, four workgroups per CU: 101.6 -> 89.5 ms
+        return launch_xfft_seq_t<2048, 16>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, red, st);
     if (S.N == 16384 && S.narray == 3 && ec.pack == PACK_ZAFIELD)
         return launch_xfft_two_t<16384, 16, false>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, red, st);
     if (S.N == 8192 && S.narray == 3 && ec.pack == PACK_PLT3)  // the ring of the PLT field store
