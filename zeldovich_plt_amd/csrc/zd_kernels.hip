@@ -2748,6 +2748,7 @@ int launch_xfft(const StoreLayout &S, const EpiConst &ec, const void *tw, const 
     // PPD = 4096 too (round 3): the one-row form is 256 threads, 190 registers and 68 KB of LDS — TWO independent workgroups per
     // CU, whose load / transform / store phases overlap — where the three-line k_xfft is one workgroup of 768 threads and 104 KB:
     // x stage 798 -> 713 ms (3.85 TB at 5.4 TB/s)
+    // (8 elements per thread — 512 threads at 116 registers, twice the waves in the same two workgroups — is slower: 714 vs 699 ms)
     if (S.N == 4096 && S.narray == 3 && ec.pack == PACK_ZAFIELD)
         return launch_xfft_seq_t<4096, 16>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, red, st);
     if (S.N == 2048 && S.narray == 3 && ec.pack == PACK_ZAFIELD)  // 128 threads, four workgroups per CU: 101.6 -> 89.5 ms
