@@ -41,7 +41,8 @@ for k,v in res.items():
     if not k.startswith("k_") or "FETCH_SIZE" not in v or "WRITE_SIZE" not in v: continue
     n=v["FETCH_SIZE"]["launches"]
     fetch=2*v["FETCH_SIZE"]["total_KB"]*1024; write=v["WRITE_SIZE"]["total_KB"]*1024
-    name={"k_genf":"k_gen","k_zfft_f":"k_zfft","k_yfft_f":"k_yfft"}.get(k,k)
+    k=k.split("(")[0]
+    name={"k_genf":"k_gen","k_zfft_f":"k_zfft","k_yfft_f":"k_yfft","k_xfft_seq":"k_xfft"}.get(k,k)
     out["bytes_per_launch"][name]=out["bytes_per_launch"].get(name,0)+(fetch+write)/n
     out["bytes_per_step"][name]=out["bytes_per_step"].get(name,0)+(fetch+write)
     print(k,"launches",n,"fetch GB (x2)",round(fetch/1e9,1),"write GB",round(write/1e9,1),"per launch MB",round((fetch+write)/n/1e6,1))
