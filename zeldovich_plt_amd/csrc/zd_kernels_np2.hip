@@ -520,7 +520,16 @@ template <int P, int E, int Q, bool PLT>
 static int launch_xfft_q_t(const EpiConst &ec, const cplx *tw, const void *ring, int ring_pitch, int nplanes, int z_first, int z_step,
                            void *records, Reduce *red, hipStream_t st) {
     constexpr int N = P * Q, threads = Q * P / E;
-    if constexpr (3 * threads <= 1024) {  // three lines per workgroup
+    // The one-row form (k_xfft_seq1_q) also where three lines fit a workgroup?  Measured per size, x stage in ms, three-line / one-row:
+    // 3456 (128 * 27) 883 / 634, 5120 (1024 * 5) 2978 / 2460 — taken; 2560 322 / 355, 2880 513 / 565, 3072 474 / 512, 3200 673 / 735,
+    // 4000 1371 / 1529 — left (it depends on how many workgroups of each form a CU holds: registers, LDS and thread count differ by
+    // (P, Q)).  -DZD_SEQ1_MIN=n (make variant) switches every size >= n for such measurements.
+#ifdef ZD_SEQ1_MIN
+    constexpr bool prefer_seq1 = !PLT && N >= ZD_SEQ1_MIN;
+#else
+    constexpr bool prefer_seq1 = !PLT && (N == 3456 || N == 5120);
+#endif
+    if constexpr (3 * threads <= 1024 && !prefer_seq1) {  // three lines per workgroup
         using LQ3 = zdfft::LineQ<P, E, Q, 3, true>;
         constexpr size_t stash = PLT ? 4 * N : 2 * N;  // doubles: the one (ZA) or two (PLT) lines the records read from LDS
         constexpr size_t dbl = LQ3::LDS_DOUBLES > stash ? LQ3::LDS_DOUBLES : stash;
