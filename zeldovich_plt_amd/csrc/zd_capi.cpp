@@ -1055,6 +1055,9 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
             hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
             int per_cu = pl->overlap ? 3 : 6;
             if (const char *env = tune_env("ZD_GEN_WGS")) per_cu = atoi(env);
+#ifdef ZD_GEN_WGS_FORCE  // experiment (make variant)
+            if (pl->overlap) per_cu = ZD_GEN_WGS_FORCE;
+#endif
             pl->gen_max_wgs = std::max(1, per_cu) * std::max(1, ncu);
             pl->n_tilectr   = 2 * (pl->Hq / rows) + 2;  // per pass parity: the next pass's generator may already run
             PLCHECK(hipMalloc((void **) &pl->d_tilectr, sizeof(unsigned) * pl->n_tilectr));
