@@ -71,7 +71,9 @@ __global__ __launch_bounds__(W *Q *P / E) void k_test_fftq_lines(const cplx *__r
 // z stage: lines of length L = P*Q (the folded z direction) for NC columns x the 8 rows of a row group.
 //   grid: (N/NC, row groups, nfield)   block: NC*8*Q*P/E
 template <int P, int E, int Q, int NC>
-__global__ __launch_bounds__(NC *FIELD_RB *Q *P / E) void k_zfft_fq(FieldLayout F, StoreLayout S, int ky0, int kyloc0, int nky,
+// (held to 128 registers — 11-18 spilled dwords for Q = 27 — so that two of its 7-wave workgroups fit a CU: Z stage of PPD=3456
+// 520 -> 491 ms, of PPD=6912 k_cutoff=2 1244 -> 1155)
+__global__ __launch_bounds__(NC *FIELD_RB *Q *P / E, 4) void k_zfft_fq(FieldLayout F, StoreLayout S, int ky0, int kyloc0, int nky,
                                                                   const cplx *__restrict__ Y, const cplx *__restrict__ twP,
                                                                   const cplx *__restrict__ twL, const cplx *__restrict__ twQ,
                                                                   cplx *__restrict__ out) {
