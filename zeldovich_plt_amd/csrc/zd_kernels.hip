@@ -2065,7 +2065,8 @@ __global__ __launch_bounds__(N / E, 2) void k_xfft_seq(StoreLayout S, EpiConst e
 //                  array 1 (grid z = 1), one plane
 //   grid: (N, planes, z)   block: N/E
 template <int N, int E, bool PLT>
-__global__ __launch_bounds__(N / E) void k_xfft_two(StoreLayout S, EpiConst ec, const cplx *__restrict__ tw, cplx *data, int emit,
+// (PPD = 8192: 512 threads held to 128 registers — it took 130 — so that TWO workgroups fit a CU, 70 KB of LDS each)
+__global__ __launch_bounds__(N / E, (N / E <= 512 ? 4 : 1)) void k_xfft_two(StoreLayout S, EpiConst ec, const cplx *__restrict__ tw, cplx *data, int emit,
                                                    int plane0, int z_first, int z_step, char *__restrict__ records,
                                                    Reduce *__restrict__ red) {
     using PL  = zdfft::Plan<N, E>;
