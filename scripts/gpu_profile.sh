@@ -42,7 +42,7 @@ for k,v in res.items():
     n=v["FETCH_SIZE"]["launches"]
     fetch=2*v["FETCH_SIZE"]["total_KB"]*1024; write=v["WRITE_SIZE"]["total_KB"]*1024
     k=k.split("(")[0]
-    name={"k_genf":"k_gen","k_zfft_f":"k_zfft","k_yfft_f":"k_yfft","k_xfft_seq":"k_xfft"}.get(k,k)
+    name={"k_genf":"k_gen","k_zfft_f":"k_zfft","k_yfft_f":"k_yfft","k_xfft_seq":"k_xfft","k_xfft_seq_plt":"k_xfft"}.get(k,k)
     out["bytes_per_launch"][name]=out["bytes_per_launch"].get(name,0)+(fetch+write)/n
     out["bytes_per_step"][name]=out["bytes_per_step"].get(name,0)+(fetch+write)
     print(k,"launches",n,"fetch GB (x2)",round(fetch/1e9,1),"write GB",round(write/1e9,1),"per launch MB",round((fetch+write)/n/1e6,1))

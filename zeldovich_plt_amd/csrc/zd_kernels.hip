@@ -2054,6 +2054,80 @@ __global__ __launch_bounds__(N / E, 2) void k_xfft_seq(StoreLayout S, EpiConst e
     xfft_reduce<NT, 3>(lds, red, 0.0, mp, mn);
 }
 
+// k_xfft_seq_plt: the one-row form for the PLT3 packing qx + i vx | qy + i qz | vy + i vz (ONE plane per store plane): array 0 first
+// (kept in registers), array 2 (both parts wait in LDS behind the transform's area), then array 1, whose threads write the records.
+// One rolled copy of the transform, as in k_xfft_seq.
+//   grid: (N, nplanes)   block: N/E
+template <int N, int E>
+__global__ __launch_bounds__(N / E, 2) void k_xfft_seq_plt(StoreLayout S, EpiConst ec, const cplx *__restrict__ tw,
+                                                          const cplx *__restrict__ data, int plane0, int z_first, int z_step,
+                                                          char *__restrict__ records, Reduce *__restrict__ red) {
+    using PL  = zdfft::Plan<N, E>;
+    using LDS = zdfft::LineInner<N, 1>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int T = PL::T, NT = T;
+    const int t = threadIdx.x;
+    const int y = blockIdx.x, pl = plane0 + blockIdx.y;
+    double2 *c2s = reinterpret_cast<double2 *>(lds + LDS::SIZE);  // [x] = {vy, vz}; a thread reads back only what it wrote itself
+    double c0r[E], c0i[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) c0r[e] = c0i[e] = 0.0;
+    const int z = z_first + z_step * (int) blockIdx.y;
+    double mp[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
+    const long long plane_rec0 = (long long) blockIdx.y * N * N;
+#pragma unroll 1
+    for (int it = 0; it < 3; it++) {
+        const int a = it == 0 ? 0 : (it == 1 ? 2 : 1);
+        const cplx *src = data + row_offset(S, pl, a, y);
+        double re[E], im[E];
+        int ta = t;
+        asm volatile("" : "+v"(ta));
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const cplx v = src[x_is_dead(ec, ta + T * e) ? 0 : ta + T * e];  // (see k_xfft)
+            re[e] = v.x;
+            im[e] = v.y;
+        }
+        int t3 = t;
+        asm volatile("" : "+v"(t3));
+#pragma unroll
+        for (int e = 0; e < E; e++)
+            if (x_is_dead(ec, t3 + T * e)) re[e] = im[e] = 0.0;
+        __syncthreads();  // the previous transform's last LDS reads are done
+        zdfft::fft_line<PL, LDS>(re, im, t, 0, lds, tw);
+        int t2 = t;
+        asm volatile("" : "+v"(t2));
+        if (it == 0) {
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                c0r[e] = re[e];
+                c0i[e] = im[e];
+            }
+            continue;
+        }
+        if (it == 1) {
+#pragma unroll
+            for (int e = 0; e < E; e++) c2s[t2 + T * e] = double2{re[e], im[e]};
+            continue;
+        }
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int xx = t2 + T * e;
+            const double2 c2 = c2s[xx];
+            const double pos[3] = {c0r[e], re[e], im[e]};
+            const double vel[3] = {c0i[e] * ec.vnorm, c2.x * ec.vnorm, c2.y * ec.vnorm};
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                mp[j] = fmax(mp[j], pos[j]);
+                mn[j] = fmax(mn[j], -pos[j]);
+            }
+            if (records) emit_record(records, plane_rec0 + (long long) y * N + xx, ec, z, y, xx, pos, vel);
+        }
+    }
+    __syncthreads();
+    xfft_reduce<NT, 3>(lds, red, 0.0, mp, mn);
+}
+
 // k_xfft_two: the same x pass as two launches of one line per workgroup (PPD = 16384: a line alone takes the 1024 threads
 // of a workgroup at 128 VGPRs, and holding a second line's results beside the transform spilled; PPD = 8192 with PLT: a
 // record needs all three arrays).  Launch 0 transforms the arrays the records only READ, each over its own ring row;
@@ -2726,6 +2800,18 @@ static int launch_xfft_seq_t(const StoreLayout &S, const EpiConst &ec, const voi
     return 0;
 }
 
+template <int N, int E>
+static int launch_xfft_seq_plt_t(const StoreLayout &S, const EpiConst &ec, const void *tw, const void *data, int plane0,
+                                 int nplanes, int z_first, int z_step, void *records, Reduce *red, hipStream_t st) {
+    const size_t shmem = sizeof(double) * (zdfft::LineInner<N, 1>::SIZE + 2 * N);  // + {vy, vz} of array 2 (k_xfft_seq_plt)
+    set_dyn_lds<k_xfft_seq_plt<N, E>>(shmem);
+    dim3 grid(N, nplanes), block(N / E);
+    hipLaunchKernelGGL((k_xfft_seq_plt<N, E>), grid, block, shmem, st, S, ec, (const cplx *) tw, (const cplx *) data, plane0, z_first,
+                       z_step, (char *) records, red);
+    ZD_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int N, int E, bool PLT>
 static int launch_xfft_two_t(const StoreLayout &S, const EpiConst &ec, const void *tw, const void *data, int plane0,
                              int nplanes, int z_first, int z_step, void *records, Reduce *red, hipStream_t st) {
@@ -2760,10 +2846,12 @@ int launch_xfft(const StoreLayout &S, const EpiConst &ec, const void *tw, const 
         return launch_xfft_two_t<16384, 16, false>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, red, st);
     if (S.N == 8192 && S.narray == 3 && ec.pack == PACK_PLT3)  // the ring of the PLT field store
         return launch_xfft_two_t<8192, 16, true>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, red, st);
-    // PPD = 2048, PLT3 packing: one row per workgroup (384 threads, 64 KB of LDS: two independent workgroups per CU) instead of
-    // two (768 threads): x stage 164.6 -> 151.6 ms
+    // PPD = 2048, PLT3 packing: the one-row form too (k_xfft_seq_plt: 128 threads, 204 registers, 49 KB of LDS: three workgroups
+    // per CU).  x stage: two rows per k_xfft workgroup (768 threads) 164.6 ms, one row (384 threads, two workgroups per CU) 151.3,
+    // one row per k_xfft_seq_plt workgroup 137.0.  (At PPD = 4096 the row's second array needs 64 KB of LDS beside the transform's
+    // 35 — one workgroup of 256 threads per CU: 1444 ms against k_xfft's 1338 — so 4096 stays on k_xfft.)
     if (S.N == 2048 && S.narray == 3 && ec.pack == PACK_PLT3)
-        return launch_xfft_t<2048, 16, 3, 1>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, density, red, st);
+        return launch_xfft_seq_plt_t<2048, 16>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, red, st);
     // (the ZA field ring at 2048 is indifferent: 104.2 ms with two rows, 105.7 with one)
 #define XCASE(n, e, rows1, rows2, rows4, rows3z, rows3p)                                                              \
     case n:                                                                                                           \
