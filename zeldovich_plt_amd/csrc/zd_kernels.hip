@@ -2058,7 +2058,9 @@ __global__ __launch_bounds__(N / E, 2) void k_xfft_seq(StoreLayout S, EpiConst e
 // (kept in registers), array 2 (both parts wait in LDS behind the transform's area), then array 1, whose threads write the records.
 // One rolled copy of the transform, as in k_xfft_seq.
 //   grid: (N, nplanes)   block: N/E
-template <int N, int E>
+// SPLIT2: vy stays in registers too and only vz waits in LDS (8 B per column: PPD = 4096 then needs 67 KB instead of 99, two
+// workgroups per CU)
+template <int N, int E, bool SPLIT2 = false>
 __global__ __launch_bounds__(N / E, 2) void k_xfft_seq_plt(StoreLayout S, EpiConst ec, const cplx *__restrict__ tw,
                                                           const cplx *__restrict__ data, int plane0, int z_first, int z_step,
                                                           char *__restrict__ records, Reduce *__restrict__ red) {
@@ -2069,9 +2071,12 @@ __global__ __launch_bounds__(N / E, 2) void k_xfft_seq_plt(StoreLayout S, EpiCon
     const int t = threadIdx.x;
     const int y = blockIdx.x, pl = plane0 + blockIdx.y;
     double2 *c2s = reinterpret_cast<double2 *>(lds + LDS::SIZE);  // [x] = {vy, vz}; a thread reads back only what it wrote itself
-    double c0r[E], c0i[E];
+    double *c2i = lds + LDS::SIZE;                                // SPLIT2: [x] = vz
+    double c0r[E], c0i[E], c2r[SPLIT2 ? E : 1];
 #pragma unroll
     for (int e = 0; e < E; e++) c0r[e] = c0i[e] = 0.0;
+#pragma unroll
+    for (int e = 0; e < (SPLIT2 ? E : 1); e++) c2r[e] = 0.0;
     const int z = z_first + z_step * (int) blockIdx.y;
     double mp[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
     const long long plane_rec0 = (long long) blockIdx.y * N * N;
@@ -2107,13 +2112,23 @@ __global__ __launch_bounds__(N / E, 2) void k_xfft_seq_plt(StoreLayout S, EpiCon
         }
         if (it == 1) {
 #pragma unroll
-            for (int e = 0; e < E; e++) c2s[t2 + T * e] = double2{re[e], im[e]};
+            for (int e = 0; e < E; e++) {
+                if constexpr (SPLIT2) {
+                    c2r[e] = re[e];
+                    c2i[t2 + T * e] = im[e];
+                } else
+                    c2s[t2 + T * e] = double2{re[e], im[e]};
+            }
             continue;
         }
 #pragma unroll
         for (int e = 0; e < E; e++) {
             const int xx = t2 + T * e;
-            const double2 c2 = c2s[xx];
+            double2 c2;
+            if constexpr (SPLIT2)
+                c2 = double2{c2r[e], c2i[xx]};
+            else
+                c2 = c2s[xx];
             const double pos[3] = {c0r[e], re[e], im[e]};
             const double vel[3] = {c0i[e] * ec.vnorm, c2.x * ec.vnorm, c2.y * ec.vnorm};
 #pragma unroll
@@ -2800,13 +2815,13 @@ static int launch_xfft_seq_t(const StoreLayout &S, const EpiConst &ec, const voi
     return 0;
 }
 
-template <int N, int E>
+template <int N, int E, bool SPLIT2 = false>
 static int launch_xfft_seq_plt_t(const StoreLayout &S, const EpiConst &ec, const void *tw, const void *data, int plane0,
                                  int nplanes, int z_first, int z_step, void *records, Reduce *red, hipStream_t st) {
-    const size_t shmem = sizeof(double) * (zdfft::LineInner<N, 1>::SIZE + 2 * N);  // + {vy, vz} of array 2 (k_xfft_seq_plt)
-    set_dyn_lds<k_xfft_seq_plt<N, E>>(shmem);
+    const size_t shmem = sizeof(double) * (zdfft::LineInner<N, 1>::SIZE + (SPLIT2 ? 1 : 2) * N);  // + {vy, vz} (or vz) of array 2
+    set_dyn_lds<k_xfft_seq_plt<N, E, SPLIT2>>(shmem);
     dim3 grid(N, nplanes), block(N / E);
-    hipLaunchKernelGGL((k_xfft_seq_plt<N, E>), grid, block, shmem, st, S, ec, (const cplx *) tw, (const cplx *) data, plane0, z_first,
+    hipLaunchKernelGGL((k_xfft_seq_plt<N, E, SPLIT2>), grid, block, shmem, st, S, ec, (const cplx *) tw, (const cplx *) data, plane0, z_first,
                        z_step, (char *) records, red);
     ZD_LAUNCH_CHECK();
     return 0;
@@ -2848,10 +2863,16 @@ int launch_xfft(const StoreLayout &S, const EpiConst &ec, const void *tw, const 
         return launch_xfft_two_t<8192, 16, true>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, red, st);
     // PPD = 2048, PLT3 packing: the one-row form too (k_xfft_seq_plt: 128 threads, 204 registers, 49 KB of LDS: three workgroups
     // per CU).  x stage: two rows per k_xfft workgroup (768 threads) 164.6 ms, one row (384 threads, two workgroups per CU) 151.3,
-    // one row per k_xfft_seq_plt workgroup 137.0.  (At PPD = 4096 the row's second array needs 64 KB of LDS beside the transform's
-    // 35 — one workgroup of 256 threads per CU: 1444 ms against k_xfft's 1338 — so 4096 stays on k_xfft.)
+    // one row per k_xfft_seq_plt workgroup 137.0.  (At PPD = 4096 the row's second array would need 64 KB of LDS beside the
+    // transform's 35 — one workgroup of 256 threads per CU: 1444 ms against k_xfft's 1338 — hence the SPLIT2 form above.)
+    // PPD = 4096: the same with vy kept in registers as well (240 registers, 67 KB of LDS: two workgroups of 256 threads per CU):
+    // x stage of PPD=4096 PLT 1338 -> 1067 ms
+    if (S.N == 4096 && S.narray == 3 && ec.pack == PACK_PLT3)
+        return launch_xfft_seq_plt_t<4096, 16, true>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, red, st);
+
+    // (with vy in registers as well — 240 registers, 33 KB of LDS, four workgroups per CU — 134.6 -> 127.8)
     if (S.N == 2048 && S.narray == 3 && ec.pack == PACK_PLT3)
-        return launch_xfft_seq_plt_t<2048, 16>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, red, st);
+        return launch_xfft_seq_plt_t<2048, 16, true>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, red, st);
     // (the ZA field ring at 2048 is indifferent: 104.2 ms with two rows, 105.7 with one)
 #define XCASE(n, e, rows1, rows2, rows4, rows3z, rows3p)                                                              \
     case n:                                                                                                           \
