@@ -17,6 +17,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: exactly the declarations of this header are exported */
+#pragma GCC visibility push(default)
 
 #define ZD_MAX_PPD 65536 /* include/zeldovich.h:34 — fixes the RNG addressing */
 
@@ -257,6 +259,15 @@ void zd_pk_destroy(zd_pk_handle *h);
 int zd_load_eigmodes(const char *path, double **eig, int64_t *eig_ppd);
 void zd_free(void *p);
 
+/* ---- diagnostics ------------------------------------------------------------------------------
+ * Which kernel variants this process has launched so far, and how often: one line "count<TAB>line<TAB>launcher" per launch
+ * site of the library, the launcher named with its template arguments (transform length, elements per thread, tile shape,
+ * packing).  Writes at most cap - 1 bytes + a terminating 0 into buf (may be NULL) and returns the size a complete report
+ * needs.  (The reference logs its FFTW plan sizes at start-up, src/zeldovich.cpp:39-135; here the variant depends on PPD,
+ * store and stream factor, and the test-suite uses this report to prove that every variant it ships has been exercised.) */
+int64_t zd_dispatch_report(char *buf, int64_t cap);
+
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

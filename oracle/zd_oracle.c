@@ -1222,3 +1222,132 @@ void zdo_mode_draw(const zdo_params *p, const zdo_pk *pk, int kx, int ky, int kz
     double k2  = (kx * kx + ky * ky + kz * kz) * (p->fundamental * p->fundamental);
     cgauss2(pk, sqrt(k2), &g, D);
 }
+
+/* Direct summation of the displacement / velocity / density fields at a few lattice sites, without any FFT, blocking or
+ * packing:   q_j(x) = sum_k F_j(k) e^{+2 pi i k.x / N},  F_j = I rescale e_j fundamental / k^2 D(k)   (src/zeldovich.cpp:404-452:
+ * pos[0] = Im(A) = the inverse transform of F etc.; src/output.cpp:93-141 for the velocity: PLT f F_j, else vnorm q_j),
+ * density = sum_k D(k) e^{...}.  The modes are drawn exactly as LoadPlane draws them — plane ky's stream walked in (z, x)
+ * order, zeroed modes skipped in bulk (src/zeldovich.cpp:335-363) — for the half space ky in [0, N/2); a mode and its
+ * Hermitian twin contribute 2 Re[F e^{i theta}].  In the ky = 0 plane the reference keeps the draws of z in [0, N/2) (x < N/2
+ * for z = 0) and overwrites the others with their conjugates, origin zeroed (:485-503): only those "winner" modes are summed.
+ * Requires every Nyquist-plane mode to be zeroed by the rule (no CornerModes), version 2 streams, f_NL = 0.
+ * The phases are exact: theta = 2 pi m / N with m = k.x mod N from a table of N entries.  Kahan sums, one partial sum per
+ * ky plane, added in ky order (result independent of the thread count).
+ *   sites: nsites x (z, y, x);   out: nsites x 7 = qx, qy, qz, vx, vy, vz, density  (this code's x, y, z order).
+ * A size-independent oracle check of the GPU path at the full BASELINE sizes (tests/golden/direct_sum_*.json). */
+int zdo_direct_sum(const zdo_params *param, const zdo_pk *Pk, const double *eig, int64_t eig_ppd, int nsites, const int *sites,
+                   double *out) {
+    const int64_t ppd = param->ppd, ppdhalf = ppd / 2;
+    if (param->CornerModes || param->version == 1 || param->f_NL != 0. || nsites < 1 || nsites > 64) return 1;
+    const double fundamental2 = param->fundamental * param->fundamental;
+    const double ik_cutoff    = 1.0 / param->k_cutoff;
+    const double target_f     = (sqrt(1. + 24 * param->f_cluster) - 1) / 4.;
+    const double a_NL = param->qPLTrescale ? 1. / (1 + param->PLT_target_z) : 1.0;
+    const double a0   = param->qPLTrescale ? 1. / (1 + param->z_initial) : 1.0;
+    const double k2_cutoff = param->nyquist * param->nyquist / (param->k_cutoff * param->k_cutoff);
+    const int kmax = (double) ppdhalf * ik_cutoff + .5;
+    const double vnorm = param->qPLT ? 1.0 : (sqrt(1. + 24 * param->f_cluster) - 1) * .25;
+    double *cs = (double *) malloc(sizeof(double) * 2 * (size_t) ppd);
+    for (int64_t m = 0; m < ppd; m++) {
+        long double a = 2.0L * 3.141592653589793238462643383279502884L * (long double) m / (long double) ppd;
+        cs[2 * m]     = (double) cosl(a);
+        cs[2 * m + 1] = (double) sinl(a);
+    }
+    zdo_pcg *v2rng   = make_v2rng(param);
+    const int NQ     = 7;
+    double *partial  = (double *) calloc((size_t) ppdhalf * nsites * NQ, sizeof(double));
+    int bad = 0;
+    int nthreads = param->nthreads > 0 ? param->nthreads : omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+    for (int64_t y = 0; y < ppdhalf; y++) {
+        const int ky = (int) y;
+        double sum[64 * 7], comp[64 * 7];
+        for (int i = 0; i < nsites * NQ; i++) sum[i] = comp[i] = 0.0;
+        zdo_pcg rng   = v2rng[y];
+        int64_t nskip = 0;
+        int64_t mrow[64], mstep[64];
+        for (int z = 0; z < ppd; z++) {
+            if (z == ppdhalf + 1) nskip += (ZDO_MAX_PPD - ppd) * ZDO_MAX_PPD;
+            const int kz = z > ppdhalf ? z - (int) ppd : z;
+            for (int s = 0; s < nsites; s++) {
+                /* phase index of kx = 0 in this row, and its step per unit of kx */
+                int64_t m = ((int64_t) ky * sites[3 * s + 1] + (int64_t) kz * sites[3 * s]) % ppd;
+                mrow[s]  = m < 0 ? m + ppd : m;
+                mstep[s] = sites[3 * s + 2] % ppd;
+            }
+            for (int x = 0; x < ppd; x++) {
+                if (x == ppdhalf + 1) nskip += ZDO_MAX_PPD - ppd;
+                const int kx = x > ppdhalf ? x - (int) ppd : x;
+                double k2    = (kx * kx + ky * ky + kz * kz) * fundamental2;
+                if ((abs(kx) == kmax || abs(kz) == kmax || abs(ky) == kmax) || k2 >= k2_cutoff
+                    || (param->qonemode && !(kx == param->one_mode[0] && ky == param->one_mode[1] && kz == param->one_mode[2]))) {
+                    nskip++;
+                    continue;
+                }
+                if (abs(kx) == ppdhalf || abs(kz) == ppdhalf) {  /* a live Nyquist-plane mode: not Hermitian, unsupported */
+#pragma omp atomic write
+                    bad = 1;
+                }
+                if (nskip) {
+                    zdo_pcg_advance(&rng, 0, (uint64_t) (2 * nskip));
+                    nskip = 0;
+                }
+                double D[2];
+                cgauss2(Pk, sqrt(k2), &rng, D);
+                if (ky == 0) { /* winners of the ky = 0 plane (:485-503); the origin is zeroed */
+                    const int winner = (z < ppdhalf) && (z > 0 || (x > 0 && x < ppdhalf));
+                    if (!winner) continue;
+                }
+                if (D[0] == 0. && D[1] == 0.) continue;
+                if (k2 == 0.0) k2 = 1.0;
+                const double ik2 = 1. / k2;
+                double e[4];
+                zdo_get_eigenmode(eig, eig_ppd, kx, ky, kz, ppd, param->qPLT, e);
+                double rescale = 1., f = 1.0;
+                if (param->qPLT) {
+                    f = (sqrt(1. + 24 * e[3] * param->f_cluster) - 1) * .25;
+                    if (param->qPLTrescale) rescale = pow(a_NL / a0, target_f - f);
+                }
+                double sj[3];
+                for (int j = 0; j < 3; j++) sj[j] = rescale * e[j] * param->fundamental * ik2;
+                const double fv = param->qPLT ? f : vnorm;
+                for (int s = 0; s < nsites; s++) {
+                    int64_t m = (mrow[s] + (int64_t) kx * mstep[s]) % ppd;
+                    if (m < 0) m += ppd;
+                    const double c = cs[2 * m], sn = cs[2 * m + 1];
+                    /* 2 Re[D e^{i t}] and 2 Re[i D e^{i t}] */
+                    const double dre = 2.0 * (D[0] * c - D[1] * sn);
+                    const double fim = -2.0 * (D[0] * sn + D[1] * c);
+                    double term[7];
+                    for (int j = 0; j < 3; j++) {
+                        term[j]     = sj[j] * fim;
+                        term[3 + j] = fv * (sj[j] * fim);
+                    }
+                    term[6] = dre;
+                    for (int q = 0; q < NQ; q++) { /* Kahan */
+                        double *S = &sum[s * NQ + q], *Cc = &comp[s * NQ + q];
+                        const double yv = term[q] - *Cc;
+                        const double tv = *S + yv;
+                        *Cc = (tv - *S) - yv;
+                        *S  = tv;
+                    }
+                }
+            }
+        }
+        for (int i = 0; i < nsites * NQ; i++) partial[(size_t) y * nsites * NQ + i] = sum[i];
+    }
+    for (int i = 0; i < nsites * NQ; i++) {
+        double S = 0.0, Cc = 0.0;
+        for (int64_t y = 0; y < ppdhalf; y++) {
+            const double yv = partial[(size_t) y * nsites * NQ + i] - Cc;
+            const double tv = S + yv;
+            Cc = (tv - S) - yv;
+            S  = tv;
+        }
+        out[i] = S;
+    }
+    free(partial);
+    free(v2rng);
+    free(cs);
+    return bad ? 2 : 0;
+}

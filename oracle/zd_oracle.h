@@ -125,6 +125,12 @@ void zdo_mode_draw(const zdo_params *p, const zdo_pk *pk, int kx, int ky, int kz
 void zdo_get_eigenmode(const double *eig, int64_t eig_ppd, int kx, int ky, int kz, int64_t ppd,
                        int qPLT, double out[4]);
 
+/* Direct summation q_j(x) = sum_k F_j(k) e^{2 pi i k.x/N} (no FFT / blocking / packing) at nsites <= 64 lattice sites
+ * (z, y, x), modes drawn in LoadPlane's stream order (src/zeldovich.cpp:331-503, src/output.cpp:93-141);
+ * out: nsites x {qx, qy, qz, vx, vy, vz, density}.  OpenMP over ky.  Size-independent check of the full-size GPU runs. */
+int zdo_direct_sum(const zdo_params *p, const zdo_pk *pk, const double *eig, int64_t eig_ppd, int nsites, const int *sites,
+                   double *out);
+
 /* record sizes: src/output.h:19-42 */
 int zdo_record_size(int icformat);
 int zdo_narray(const zdo_params *p); /* src/zeldovich.cpp:871-876 */

@@ -90,6 +90,7 @@ def lib():
                                     C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
         L.zdo_get_eigenmode.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64,
                                         C.c_int, C.POINTER(C.c_double)]
+        L.zdo_direct_sum.argtypes = [C.POINTER(Params), C.POINTER(Pk), C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
         L.zdo_pk_set_primordial.argtypes = [C.POINTER(Pk), C.c_double]
         L.zdo_infer_Tk.argtypes = [C.POINTER(Pk), C.c_double]
         L.zdo_infer_Tk.restype = C.c_double
@@ -231,6 +232,20 @@ def run(params, pk, eig=None, eig_ppd=0, want_planes=False, want_density=False):
     return dict(records=None if rec is None else rec.reshape(n, n, n), planes=planes,
                 density=None if dens is None else dens.reshape(n, n, n),
                 max_disp=np.array(list(st.max_disp)), density_variance=st.density_variance, stats=st)
+
+
+def direct_sum(params, pk, sites, eig=None):
+    """fields at the lattice sites [(z, y, x), ...] by direct summation over the modes (zdo_direct_sum): float64
+    [nsites, 7] = qx, qy, qz, vx, vy, vz, density"""
+    s = np.ascontiguousarray(sites, dtype=np.int32).reshape(-1, 3)
+    out = np.zeros((s.shape[0], 7), dtype=np.float64)
+    if eig is not None:
+        eig = np.ascontiguousarray(eig, dtype=np.float64)
+    rc = lib().zdo_direct_sum(C.byref(params), C.byref(pk), eig.ctypes.data if eig is not None else None,
+                              eig.shape[0] if eig is not None else 0, s.shape[0], s.ctypes.data, out.ctypes.data)
+    if rc:
+        raise RuntimeError("zdo_direct_sum failed rc=%d" % rc)
+    return out
 
 
 def mode_cube(params, pk, eig=None, eig_ppd=0):

@@ -11,6 +11,20 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 WMAP = os.path.join(GOLDEN, "wmap1new.pow")
 
 
+def source_sha():
+    """sha-256 over the native sources of the product, as zeldovich_plt_amd/csrc/Makefile records it in <library>.srcsha when it
+    links a library (`make srcsha` prints the same)"""
+    import hashlib
+    import glob
+    csrc = os.path.join(ROOT, "zeldovich_plt_amd", "csrc")
+    names = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.cpp"))
+                   + [os.path.join(ROOT, "include", "zeldovich_hip.h")])
+    h = hashlib.sha256()
+    for n in names:
+        h.update(open(n, "rb").read())
+    return h.hexdigest()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -24,6 +24,36 @@ def test_header_and_library_agree():
     assert declared == set(api.EXPORTED_SYMBOLS), declared ^ set(api.EXPORTED_SYMBOLS)
 
 
+def test_library_exports_exactly_the_header():
+    """built with -fvisibility=hidden + a version script: `nm -D` shows the declarations of include/zeldovich_hip.h and nothing
+    else (no C++ internals, no kernel host stubs); the -DZD_TESTING library adds exactly csrc/zd_testing.h"""
+    import subprocess
+    import zeldovich_plt_amd.api as api
+
+    def exported(path):
+        out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+        return {line.split()[-1] for line in out.splitlines() if line.strip()}
+
+    assert exported(api.LIB_PATH) == _declared_functions()
+    if os.path.exists(api.TESTING_LIB_PATH):
+        assert exported(api.TESTING_LIB_PATH) == _declared_functions() | set(api.TESTING_SYMBOLS)
+
+
+def test_every_build_target_has_a_recipe():
+    """every make target build() names must have a rule that produces its file on a clean tree (round 3: `nofma` had become a
+    bare .PHONY name and the A/B parity test ran a stale library)"""
+    import subprocess
+    import __graft_entry__ as ge
+    csrc = os.path.join(ROOT, "zeldovich_plt_amd", "csrc")
+    assert set(ge.MAKE_TARGETS) >= {"all", "nofma", "testing"}
+    for tgt in ge.MAKE_TARGETS:
+        # -B: as if nothing were built; -n: print only.  The link line of the target's library must appear
+        plan = subprocess.check_output(["make", "-C", csrc, "-B", "-n", tgt], text=True)
+        want = "libzeldovich_hip.so" if tgt == "all" else "libzeldovich_hip_%s.so" % tgt
+        assert ("-o build/" + want) in plan, (tgt, plan[-400:])
+        assert "-c zd_kernels.hip" in plan, tgt
+
+
 def test_struct_layouts_match_header():
     """sizes the C compiler gives the ABI structs == the ctypes mirrors"""
     import subprocess

@@ -18,7 +18,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT, WMAP
+from conftest import ROOT, WMAP, source_sha
 from test_gpu_parity import TOL, _compare, _rel
 
 pytestmark = pytest.mark.gpu
@@ -203,6 +203,7 @@ def test_ppd16384_k_cutoff4_planes_equal_ppd4096(zd):
 
 @pytest.mark.parametrize("n,kc,Ra,Rb,modes", [
     (2048, 1.0, 2, 4, [(3, 5, -7), (-401, 577, 600), (0, 2, 0)]),          # BASELINE C3: packed PLT arrays (k_genf PLTN / k_zfft / k_yfft / k_xfft)
+    (4096, 1.0, 16, 32, [(3, 5, -7), (-1001, 777, 1200), (0, 2, 0)]),    # PLT at the headline grid: k_genf PLTN + k_eig_lines at 4096 / k_zfft<256|128> / k_yfft<4096> / k_xfft_seq_plt<4096,16,true>
     (8192, 2.0, 64, 128, [(3, 5, -7), (-1001, 777, 1200), (0, 2, 0)]),   # k_xfft_two<8192, PLT>
     (6912, 4.0, 8, 16, [(3, 5, -7), (-401, 377, 500)]),                  # composite kernels, x pass in two launches
     (3456, 2.0, 4, 8, [(-3, 5, 7), (401, 377, -500)]),                   # composite kernels, three lines per workgroup
@@ -331,8 +332,11 @@ def test_plain_fma_build_passes_the_parity_suite():
     """the -DZD_NO_FMA_ASM library (plain fma() instead of the asm 3-address FMAs, `make nofma`) through a subset of the
     parity tests in a child process (ZD_LIB_PATH): generator arithmetic must not depend on the asm forms"""
     lib = os.path.join(ROOT, "zeldovich_plt_amd", "csrc", "build", "libzeldovich_hip_nofma.so")
-    if not os.path.exists(lib):
-        pytest.skip("nofma variant not built (make -C zeldovich_plt_amd/csrc nofma)")
+    # round 3 ran this against a library older than the kernels it was meant to check (the make rule had been lost): a missing
+    # or stale variant is a FAILURE.  Staleness by content, not mtime (snapshots do not keep mtimes): the Makefile records the
+    # sha-256 of the sources next to every library it links
+    assert os.path.exists(lib), "nofma variant not built (make -C zeldovich_plt_amd/csrc nofma; build() does it)"
+    assert open(lib + ".srcsha").read().split()[0] == source_sha(), "libzeldovich_hip_nofma.so is older than the kernel sources"
     env = dict(os.environ, ZD_LIB_PATH=lib, ZD_TESTING_LIB_PATH=lib)  # (the variant carries the test hooks too)
     sel = "test_za_extrapolated_pk_vs_oracle or test_plt_rescale_extrapolated_pk_vs_oracle or test_table_generator_arithmetic_vs_oracle"
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k", sel],

@@ -428,6 +428,36 @@ def test_fnl_end_to_end(zd, oracle, ps, wmap_path, n, kw):
     assert abs(got["density_variance"] - ref["density_variance"]) <= TOL * ref["density_variance"]
 
 
+@pytest.mark.parametrize("n,kw", [(128, dict(k_cutoff=2.0)), (128, dict(k_cutoff=2.0, ngpu=2)), (64, dict(k_cutoff=2.0, stream_factor=2)),
+                                  (128, dict()), (128, dict(k_cutoff=2.0, f_NL=0.0)), (64, dict(f_NL=0.0, qPLT=1))])
+def test_poisoned_buffers(zd, oracle, ps, wmap_path, n, kw):
+    """with ZD_k_cutoff = 2 half of the phi store's column tiles are dead under the zero rule; the z stage
+    never writes them and the y stage of the phi round must still deliver zeros there, because k_xphi / k_yfwd / k_zfwd read
+    every column (only the x kernels of the main pass honour xdead_lo / hi).  Run in the -DZD_TESTING library with every store /
+    ring / phi allocation pre-filled with NaN bytes (zd_test_poison): any kernel that reads what no kernel wrote turns the
+    records into NaN.  Also the main pass (f_NL = 0; field and PLT stores)."""
+    import ctypes as C
+    kw = dict(kw)
+    fnl, ns, om = kw.pop("f_NL", 2.0e4), 0.96, 0.31
+    eig = oracle.synthetic_eigenmodes(32) if kw.get("qPLT") else None
+    opk = oracle.pk_from_file(wmap_path, 720.0)
+    oracle.lib().zdo_pk_set_primordial(C.byref(opk), ns)
+    T = zd.load_testing_library()
+    T.zd_test_poison(1)
+    try:
+        got = zd.generate(zd.make_params(n, icformat="RVdoubleZel", f_NL=fnl, n_s=ns, Omega_M=om, **kw), ps, eig=eig, testing=True)
+    finally:
+        T.zd_test_poison(0)
+    okw = {k: v for k, v in kw.items() if k not in ("stream_factor", "ngpu")}
+    ref = oracle.run(oracle.make_params(n, numblock=2, icformat="RVdoubleZel", f_NL=fnl, n_s=ns, Omega_M=om, **okw), opk,
+                     eig=eig, eig_ppd=0 if eig is None else eig.shape[0])
+    for f in ("d", "v"):
+        assert np.isfinite(got["records"][f]).all(), f
+        for c in range(3):
+            assert _rel(got["records"][f][..., c], ref["records"][f][..., c]) < TOL, (f, c)
+    assert abs(got["density_variance"] - ref["density_variance"]) <= TOL * ref["density_variance"]
+
+
 @pytest.mark.parametrize("ngpu,n,kw", [(2, 64, dict()), (4, 128, dict(stream_factor=2, exchange_planes=3)), (2, 64, dict(plt=True))])
 def test_fnl_on_several_ranks(zd, oracle, ps, wmap_path, ngpu, n, kw):
     """ZD_f_NL with ZD_NumGPU > 1: the phi round travels to the XY ranks in plane groups, is transformed there (inverse y, x with

@@ -516,3 +516,35 @@ def test_version1_properties(oracle):
     assert np.abs(a - c).max() > 0.1 * np.abs(a).max()
     d = oracle.run(oracle.make_params(32, numblock=4, version=1, nthreads=1), pk)["records"]["d"]
     assert np.array_equal(a, d)  # one stream per yres: no dependence on the thread count
+
+
+# ---- direct-summation fixture (tests/golden/direct_sum.json) --------------------------------------------------------------
+def test_direct_sum_fixture_small_cases_equal_the_full_oracle_run(oracle):
+    """tests/golden/direct_sum.json is what the GPU suite checks the FULL-SIZE runs against (test_gpu_direct_sum.py).  Its
+    small cases are re-derived here two ways: zdo_direct_sum again (the fixture is what the committed generator produces)
+    and the oracle's complete path — LoadPlane, BlockArray, FFTs, WriteParticlesSlab — whose records at the same sites must
+    equal the mode-by-mode sums."""
+    import json
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_direct_sum", os.path.join(GOLDEN, "make_direct_sum.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    fx = json.load(open(os.path.join(GOLDEN, "direct_sum.json")))
+    assert set(fx) == set(gen.CASES)
+    opk = oracle.pk_from_file(WMAP, 720.0)
+    for name, c in fx.items():
+        assert [tuple(s) for s in c["sites"]] == gen.sites_for(c["ppd"]), name
+        assert c["params"] == gen.CASES[name]["kw"] and c["eig_ppd"] == gen.CASES[name].get("eig", 0), name
+        if c["ppd"] > 256:
+            continue
+        n = c["ppd"]
+        eig = oracle.synthetic_eigenmodes(c["eig_ppd"]) if c["eig_ppd"] else None
+        p = oracle.make_params(n, numblock=2, **c["params"])
+        again = oracle.direct_sum(p, opk, c["sites"], eig=eig)
+        want = np.array(c["values"])
+        assert np.abs(again - want).max() <= 1e-13 * np.abs(want).max(), name
+        ref = oracle.run(p, opk, eig=eig, eig_ppd=c["eig_ppd"])["records"]
+        scale = np.abs(ref["d"]).max()
+        for (z, y, x), w in zip(c["sites"], want):
+            assert np.abs(ref["d"][z, y, x][::-1] - w[:3]).max() <= 1e-12 * scale, (name, z, y, x)
+            assert np.abs(ref["v"][z, y, x][::-1] - w[3:6]).max() <= 1e-12 * scale, (name, z, y, x)

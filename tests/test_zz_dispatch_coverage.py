@@ -1,0 +1,96 @@
+"""Runs LAST (file name): every kernel variant the product can dispatch for the workloads of DESIGN.md §4's table must have been
+launched at least once by the GPU suite that ran before it in this process (VERDICT r3 #1c: round 3 shipped
+k_xfft_seq_plt<4096,16,true> without a test at its size).
+
+The library counts launches per launch site (zd_dispatch_report, include/zeldovich_hip.h: launcher name + template arguments =
+transform length, elements per thread, tile shape, packing).  EXPECTED lists, per row of the table, the launchers that row goes
+through; the test also writes the whole report to gpurun_out/dispatch_report.txt.
+
+Run alone (pytest tests/test_zz_dispatch_coverage.py) it has nothing to check and says so by failing — it is a suite-level test."""
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+# (launcher, template arguments as they appear in __PRETTY_FUNCTION__)
+EXPECTED = [
+    # PPD=4096 ZA RVZel, field store R=8 — the default bench
+    ("4096 ZA", "launch_genf_z", "ZR = 16, KIND = 5, PLAW = false"),
+    ("4096 ZA", "launch_gen_z", "ZR = 16, NJ = 4, PLT = false, PLAW = false"),   # the ky = 0 row
+    ("4096 ZA", "launch_zfft_f_t", "L = 512, E = 16, NC = 1"),
+    ("4096 ZA", "launch_yfft_f_t", "N = 4096, E = 16, W = 4,"),
+    ("4096 ZA", "launch_xfft_seq_t", "N = 4096, E = 16"),
+    # PPD=2048 ZA (R=2) and PPD=1024 ZA
+    ("2048 ZA", "launch_zfft_f_t", "L = 1024, E = 16, NC = 1"),
+    ("2048 ZA", "launch_yfft_f_t", "N = 2048, E = 16, W = 8,"),
+    ("2048 ZA", "launch_xfft_seq_t", "N = 2048, E = 16"),
+    ("1024 ZA", "launch_yfft_f_t", "N = 1024, E = 16, W = 8,"),
+    ("1024 ZA", "launch_xfft_seq_t", "N = 1024, E = 16"),
+    # PPD=2048 PLT+rescale (BASELINE C3): packed PLT3 arrays
+    ("2048 PLT", "launch_genf_z", "ZR = 16, KIND = 4, PLAW = false"),
+    ("2048 PLT", "launch_eig_lines", ""),
+    ("2048 PLT", "launch_zfft_t", "L = 1024, E = 16, W = 8"),
+    ("2048 PLT", "launch_yfft_t", "N = 2048, E = 16, W = 8"),
+    ("2048 PLT", "launch_xfft_seq_plt_t", "N = 2048, E = 16, SPLIT2 = true"),
+    # PPD=4096 PLT+rescale (R=16)
+    ("4096 PLT", "launch_zfft_t", "L = 256, E = 16, W = 16"),
+    ("4096 PLT", "launch_yfft_t", "N = 4096, E = 16, W = 4"),
+    ("4096 PLT", "launch_xfft_seq_plt_t", "N = 4096, E = 16, SPLIT2 = true"),
+    # PPD=8192 k_cutoff=2 ZA (R=16) / PLT field store (R=32) and PPD=16384 k_cutoff=4
+    ("8192 ZA", "launch_yfft_f_t", "N = 8192, E = 16, W = 2,"),
+    ("8192 ZA", "launch_xfft_seq_t", "N = 8192, E = 16"),
+    ("8192 PLT", "launch_genf_z", "ZR = 16, KIND = 6, PLAW = false"),
+    ("8192 PLT", "launch_xfft_two_t", "N = 8192, E = 16, PLT = true"),
+    ("16384 ZA", "launch_yfft_f_t", "N = 16384, E = 16, W = 1,"),
+    ("16384 ZA", "launch_xfft_two_t", "N = 16384, E = 16, PLT = false"),
+    # composite grids (zd_kernels_np2.hip): 3456 / 6912 (Q = 27), 4000 (Q = 125); production 6912 on one GPU: z lines of 108 and 192
+    ("3456 ZA", "launch_zfft_fq_t", "Q = 27"),
+    ("3456 ZA", "launch_yfft_fq_t", "P = 128, E = 16, Q = 27"),
+    ("6912 ZA", "launch_yfft_fq_t", "P = 256, E = 16, Q = 27"),
+    ("4000 ZA", "launch_yfft_fq_t", "Q = 125"),
+    ("6912 ZA one GPU", "launch_genf_z", "ZR = 4, KIND = 5"),
+    ("6912 PLT", "launch_genf_z", "ZR = 4, KIND = 6"),
+    # any even PPD (zd_kernels_any.hip)
+    ("1000/2000 any", "launch_any_cols_t", ""),
+    ("1000/2000 any", "launch_any_lines_t", ""),
+    ("1000/2000 any", "launch_any_scatter", ""),
+    ("1000/2000 any", "launch_any_emit", ""),
+    # reference arrays + f_NL + ZD_Version = 1 (rows of §7)
+    ("reference arrays", "launch_xfft_t", "NA = 2"),
+    ("reference arrays PLT", "launch_xfft_t", "NA = 4"),
+    ("f_NL", "launch_fnl_t", ""),
+    ("version 1", "launch_v1_draw", ""),
+]
+
+
+def test_every_shipped_kernel_variant_was_launched_by_the_suite():
+    import zeldovich_plt_amd.api as zd
+    rep = zd.dispatch_report()
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "dispatch_report.txt"), "w") as f:
+        for (name, line), cnt in sorted(rep.items()):
+            f.write("%10d  line %4d  %s\n" % (cnt, line, name))
+    total = sum(rep.values())
+    assert total > 10000, "run the whole GPU suite: this test checks what the tests before it launched (%d launches seen)" % total
+    missing = []
+    for row, launcher, targs in EXPECTED:
+        pat = re.compile(r"\b" + re.escape(launcher) + r"\b")
+        hit = any(cnt > 0 and pat.search(name) and targs in name for (name, _line), cnt in rep.items())
+        if not hit:
+            missing.append((row, launcher, targs))
+    assert not missing, "kernel variants of DESIGN §4 rows never launched by the suite: %r" % (missing,)
+    # every x / y / z launcher variant that WAS instantiated for a power-of-two grid up to 8192 and is reachable from the product's
+    # dispatch tables must be in the report: compare against the tables themselves
+    txt = open(os.path.join(ROOT, "zeldovich_plt_amd", "csrc", "zd_kernels.hip")).read()
+    table = re.search(r"int launch_zfft_fields\(.*?#undef ZCASE", txt, re.S).group(0)
+    for L, E, NC in re.findall(r"ZCASE\((\d+), (\d+), (\d+)\)", table):
+        want = "L = %s, E = %s, NC = %s" % (L, E, NC)
+        assert any("launch_zfft_f_t" in name and want in name for (name, _l) in rep), "k_zfft_f<%s> never launched" % want
+    table = re.search(r"int launch_yfft_fields\(.*?#undef YCASE", txt, re.S).group(0)
+    for N, E, W in re.findall(r"YCASE\((\d+), (\d+), (\d+)\)", table):
+        want = "N = %s, E = %s, W = %s," % (N, E, W)
+        assert any("launch_yfft_f_t" in name and want in name for (name, _l) in rep), "k_yfft_f<%s> never launched" % want

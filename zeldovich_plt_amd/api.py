@@ -80,10 +80,11 @@ EXPORTED_SYMBOLS = [
     "zd_plan_plane_z", "zd_plan_stage_z", "zd_plan_stage_y", "zd_plan_stage_x", "zd_plan_stats", "zd_comm_unique_id", "zd_comm_create", "zd_comm_destroy", "zd_plan_ring_bytes", "zd_plan_run_pass",
     "zd_params_from_file", "zd_pk_create_from_file", "zd_pk_create_powerlaw", "zd_pk_power",
     "zd_pk_sigmaR", "zd_pk_destroy", "zd_load_eigmodes", "zd_free", "zd_comm_abort", "zd_comm_traffic", "zd_choose_pass_groups", "zd_plan_run_passes",
+    "zd_dispatch_report",
 ]
 # test scaffolding: exists only in the -DZD_TESTING library (csrc/zd_testing.h, `make testing`), never in the product
 TESTING_SYMBOLS = ["zd_test_draws", "zd_test_modes", "zd_test_modes_table", "zd_test_v1_words", "zd_test_generate_loopback",
-                   "zd_test_fft"]
+                   "zd_test_fft", "zd_test_poison"]
 STORE_MODES = {"auto": 0, "reference": 1, "packed": 2, "fields": 3}  # zd_params.store_mode (ZD_STORE_*)
 
 _lib = None
@@ -129,6 +130,8 @@ def _load(path, testing):
         L.zd_test_modes_table.argtypes = [C.POINTER(ZdParams), C.POINTER(ZdPk), i64, vp, vp]
         L.zd_test_v1_words.argtypes = [i64, C.c_int32, vp]
         L.zd_test_fft.argtypes = [i32, i64, i32, vp, vp]
+        L.zd_test_poison.argtypes = [C.c_int]
+        L.zd_test_poison.restype = None
     L.zd_choose_stream_factor.argtypes = [C.POINTER(ZdParams), C.c_int, i64]
     L.zd_choose_pass_groups.argtypes = [C.POINTER(ZdParams), C.c_int, i64, C.POINTER(i32), C.POINTER(i32)]
     L.zd_plan_create.argtypes = [C.POINTER(ZdParams), C.POINTER(ZdPk), vp, i64, C.c_int, C.c_int, C.POINTER(vp)]
@@ -170,8 +173,23 @@ def _load(path, testing):
     L.zd_load_eigmodes.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(i64)]
     L.zd_free.argtypes = [vp]
     L.zd_free.restype = None
-    _lib = L
+    L.zd_dispatch_report.argtypes = [C.c_char_p, i64]
+    L.zd_dispatch_report.restype = i64
     return L
+
+
+def dispatch_report(testing=False):
+    """{(launcher with its template arguments, source line): launches so far} of the product library (testing=True: of the
+    -DZD_TESTING library, which counts its own launches) — zd_dispatch_report"""
+    L = load_testing_library() if testing else load_library()
+    n = L.zd_dispatch_report(None, 0)
+    buf = C.create_string_buffer(int(n) + 4096)
+    L.zd_dispatch_report(buf, len(buf))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        cnt, ln, name = line.split("\t", 2)
+        out[(name, int(ln))] = out.get((name, int(ln)), 0) + int(cnt)
+    return out
 
 
 def make_params(ppd, numblock=2, boxsize=720.0, seed=12346, k_cutoff=1.0, qPLT=0, qPLTrescale=0,
@@ -282,14 +300,14 @@ def _stats_dict(st):
                 modes_cached=bool(st.modes_cached), bytes_sent=st.bytes_sent)
 
 
-def generate(params, ps, eig=None, collect=True, loopback=False):
+def generate(params, ps, eig=None, collect=True, loopback=False, testing=False):
     """ZeldovichZ + ZeldovichXY on cuda:0 through zd_generate.
 
     collect=True gathers every delivered plane (host callback, like WriteParticlesSlab) into
     records[z, y, x] (and density[z, y, x] when qdensity); collect=False uses the NULL sink.
     loopback=True (tests; params.ngpu >= 2): zd_test_generate_loopback — the RCCL branch of the exchange on an in-process
     emulation of its calls."""
-    L = load_testing_library() if loopback else load_library()
+    L = load_testing_library() if (loopback or testing) else load_library()  # testing: zd_generate of the -DZD_TESTING build (zd_test_poison)
     entry = L.zd_test_generate_loopback if loopback else L.zd_generate
     n = int(params.ppd)
     st = ZdStats()

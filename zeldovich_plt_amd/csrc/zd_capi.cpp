@@ -38,6 +38,45 @@ using zdpcg::u128;
         }                                                                                            \
     } while (0)
 
+// ---- dispatch diagnostics (zd_launch.h DispatchSite) ----
+namespace zd {
+static std::atomic<DispatchSite *> g_dispatch_head{nullptr};
+DispatchSite::DispatchSite(const char *f, int l) : func(f), line(l) {
+    DispatchSite *h = g_dispatch_head.load(std::memory_order_relaxed);
+    do {
+        next = h;
+    } while (!g_dispatch_head.compare_exchange_weak(h, this, std::memory_order_release, std::memory_order_relaxed));
+}
+}  // namespace zd
+
+int64_t zd_dispatch_report(char *buf, int64_t cap) {
+    int64_t need = 0;
+    for (zd::DispatchSite *s = zd::g_dispatch_head.load(std::memory_order_acquire); s; s = s->next) {
+        char line[1024];
+        const int n = snprintf(line, sizeof line, "%lld\t%d\t%s\n", s->count.load(std::memory_order_relaxed), s->line, s->func);
+        if (n <= 0) continue;
+        if (buf && need + n < cap) memcpy(buf + need, line, (size_t) n);
+        need += n;
+    }
+    if (buf && cap > 0) buf[need < cap ? need : cap - 1] = 0;
+    return need + 1;
+}
+
+// Large device buffers the kernels only partly write (stores, exchange rings, phi fields).  In the -DZD_TESTING library
+// zd_test_poison(1) makes every such allocation start out as NaN bytes, so that a kernel reading something no kernel wrote
+// shows up in the parity tests instead of depending on what a fresh hipMalloc happens to contain.
+#ifdef ZD_TESTING
+static std::atomic<int> g_poison{0};
+void zd_test_poison(int on) { g_poison.store(on); }
+#endif
+hipError_t zd_store_alloc(void **p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+#ifdef ZD_TESTING
+    if (e == hipSuccess && g_poison.load()) e = hipMemset(*p, 0xFF, bytes);
+#endif
+    return e;
+}
+
 namespace {
 
 
@@ -487,8 +526,8 @@ static int make_phik(const zd_params *p, const zd_pk *pk, cplx **d_phik) {
     int frc     = 1;
     *d_phik     = nullptr;
     do {
-        if (hipMalloc(&d_phi, (size_t) zd_plan_exchange_bytes(ph)) != hipSuccess
-            || hipMalloc((void **) d_phik, (size_t) (N / 2) * N * N * 16) != hipSuccess) {
+        if (zd_store_alloc(&d_phi, (size_t) zd_plan_exchange_bytes(ph)) != hipSuccess
+            || zd_store_alloc((void **) d_phik, (size_t) (N / 2) * N * N * 16) != hipSuccess) {
             fprintf(stderr, "zeldovich_hip: f_NL needs %.1f GB of HBM for the phi field at PPD %lld\n",
                     (zd_plan_exchange_bytes(ph) + (N / 2) * N * N * 16) / 1e9, (long long) N);
             break;
@@ -987,7 +1026,7 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         Q.zb_rows    = 3 * pl->N;
         Q.kb_rows    = Q.zb_rows * pl->ring_planes;
         Q.chunk_rows = Q.kb_rows;
-        PLCHECK(hipMalloc((void **) &pl->d_ring, (size_t) Q.chunk_rows * Q.pitch * 16));
+        PLCHECK(zd_store_alloc((void **) &pl->d_ring, (size_t) Q.chunk_rows * Q.pitch * 16));
 
     }
     // columns no row of which survives the zero rule (column_is_zero with ky = 0): never written by the z stage, skipped by the
@@ -1001,6 +1040,7 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         if (all && lo >= 1) {
             pl->ec.xdead_lo = lo;
             pl->ec.xdead_hi = pl->N - lo;
+            S.prune |= zd::PRUNE_YTILE;  // the x kernels take zeros there: the y stage may skip those tiles
         }
     }
     g.var_slots     = pl->d_red->sumsq;
@@ -1300,12 +1340,12 @@ static int stage_z_impl(zd_plan *pl, int residue, void *d_send, hipStream_t st, 
     pl->ahead_n    = 0;
     // run ahead: the first slabs of the next pass go into the ring now; they execute while the caller's stream does
     // this pass's y and x transforms
-    if (K > 2 && residue + 1 < pl->npass && p_oneslab_off(pl)) {
+    if (K > 2 && residue + pl->pass_step < pl->npass && p_oneslab_off(pl)) {
         const int n = std::min(nslab, K);
-        pl->ahead_pass = residue + 1;
+        pl->ahead_pass = residue + pl->pass_step;  // (this rank's next pass: with pass groups not residue + 1)
         pl->ahead_g0   = pl->next_g;
         for (int slab = 0; slab < n; slab++)
-            if (issue_gen(residue + 1, slab, pl->next_g++, 0)) return 1;
+            if (issue_gen(residue + pl->pass_step, slab, pl->next_g++, 0)) return 1;
         pl->ahead_n = n;
     }
     if (detached) {  // nothing joins the caller's stream: whoever needs the store waits for done_ev
@@ -1543,7 +1583,7 @@ int zd_generate(const zd_params *p_in, const zd_pk *pk, const double *eig, int64
     std::thread writer;
     std::chrono::steady_clock::time_point t0;
     do {
-        if (hipMalloc(&d_store, (size_t) zd_plan_exchange_bytes(pl)) != hipSuccess) {
+        if (zd_store_alloc(&d_store, (size_t) zd_plan_exchange_bytes(pl)) != hipSuccess) {
             fprintf(stderr, "zeldovich_hip: cannot allocate the %.2f GB block store\n", zd_plan_exchange_bytes(pl) / 1e9);
             break;
         }

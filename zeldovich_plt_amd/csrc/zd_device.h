@@ -113,10 +113,15 @@ struct StoreLayout {
     int chunk_rows, kb_rows, zb_rows, a_rows;
     // pruning: a (kx,ky) column whose every kz mode is zeroed by the rule of zeldovich.cpp:350-353 is
     // identically zero after the z FFT; it is neither written by the z stage nor read by the y stage
-    int prune, kmax;
+    int prune, kmax;  // bits: 1 generator, 2 z FFT, 4 y FFT (per element), PRUNE_YTILE; bits 3..12 are tuning ablations
     double fund2, k2_cutoff;
     int nt;  // tuning (ZD_NT): non-temporal accesses, bit 0 y loads, 1 y stores, 2 x loads, 3 z stores, 4 z loads, 5 ring stores / 6 first-potential loads of k_yfft_f, 7 record stores
 };
+
+// StoreLayout::prune bit: the y stage skips whole column tiles without a live row.  Set only together with
+// EpiConst::xdead_lo / hi, i.e. when the consumer of the y stage's output takes zeros for those columns (k_xfft*); the f_NL phi
+// round (k_xphi / k_yfwd / k_zfwd read every column) keeps the tiles and the per-element rule only
+constexpr int PRUNE_YTILE = 1 << 15;
 
 // true iff every mode of column (kx, ky) (signed wavenumbers) is zero for all kz
 ZD_HD bool column_is_zero(const StoreLayout &L, int kx, int ky) {

@@ -1454,7 +1454,9 @@ __global__ __launch_bounds__(W *N / E, MINW) void k_yfft(StoreLayout S, const cp
     const int kxs = x > N / 2 ? x - N : x;
     // a tile none of whose columns has a live row: the z stage wrote nothing there and the x stage takes zeros for those
     // columns (EpiConst::xdead_lo / hi) — nothing to transform
-    if ((S.prune & 4) && __syncthreads_and(column_is_zero(S, kxs, 0))) return;
+    // (PRUNE_YTILE: set only together with xdead_lo / hi — the f_NL phi round's consumers k_xphi / k_yfwd / k_zfwd read every column,
+    // so its plan keeps the per-element zero rule below but transforms every tile)
+    if ((S.prune & PRUNE_YTILE) && __syncthreads_and(column_is_zero(S, kxs, 0))) return;
     double re[E], im[E];
     if constexpr (ONEBLOCK) {
         // single rank, all 2*Hq row slots of a (plane, array) contiguous: one 64-bit scalar base per
@@ -1610,7 +1612,7 @@ __device__ __forceinline__ void yfft_f_unit_t(const FieldLayout &F, const StoreL
     const int kx = x > N / 2 ? x - N : x;
     // a tile none of whose columns has a live row (k_cutoff = 2: half of the tiles) is neither transformed nor written: the x
     // stage takes zeros for those columns (EpiConst::xdead_lo / hi, the same rule)
-    if ((S.prune & 4) && __syncthreads_and(column_is_zero(S, kx, 0))) return;
+    if ((S.prune & PRUNE_YTILE) && __syncthreads_and(column_is_zero(S, kx, 0))) return;
     // potentials this array is made of.  ZA: E_a alone (a < 2), or (Z_0, Z_1).  PLT: the pairs (X, fX), (Y, Z), (fY, fZ) of
     // the fields X, Y, Z, fX, fY, fZ — every array is i P - Q like the ZA one of two
     const bool plt = F.nfield == 6;
@@ -2641,11 +2643,13 @@ static int launch_yfft_t(const StoreLayout &S, int nplanes, const void *tw, void
     set_dyn_lds<k_yfft<N, E, W, 1, false>>(shmem);
     set_dyn_lds<k_yfft<N, E, W, 1, true>>(shmem);
     dim3 grid(N / W, S.narray, nplanes), block(threads);
-    if (S.one_block)
+    if (S.one_block) {
         hipLaunchKernelGGL((k_yfft<N, E, W, 1, true>), grid, block, shmem, st, S, (const cplx *) tw, (cplx *) data);
-    else
+        ZD_LAUNCH_CHECK();
+    } else {
         hipLaunchKernelGGL((k_yfft<N, E, W, 1, false>), grid, block, shmem, st, S, (const cplx *) tw, (cplx *) data);
-    ZD_LAUNCH_CHECK();
+        ZD_LAUNCH_CHECK();
+    }
     return 0;
 }
 template <int L, int E, int NC>
@@ -2710,6 +2714,7 @@ static int launch_yfft_f_t(const FieldLayout &F, const StoreLayout &S, const voi
         dim3 grid((unsigned) std::max(8, ncu * per_cu / 8 * 8)), block(threads);
         hipLaunchKernelGGL((k_yfft_fp<N, E, W, MINW>), grid, block, shmem, st, F, S, (const cplx *) tw, (const cplx *) store, plane0,
                            ring_pitch, (cplx *) ring, nplanes);
+        ZD_LAUNCH_CHECK();
     } else {
         set_dyn_lds<k_yfft_f<N, E, W, MINW>>(shmem_max);
         dim3 grid(3 * (N / W), 1, nplanes), block(threads);
@@ -2984,19 +2989,21 @@ static int launch_fnl_t(int which, const StoreLayout &S, double f_NL, const void
         const double inv = 1. / N / N / N;
         hipLaunchKernelGGL((k_xphi<N, E, ROWS>), dim3(N / ROWS, nplanes), dim3(threads), shmem, st, S, f_NL, inv, (const cplx *) tw,
                            (cplx *) data);
+        ZD_LAUNCH_CHECK();
     } else {
         constexpr int threads = W * N / E;
         const size_t shmem = sizeof(double) * zdfft::ColsInner<N, W>::SIZE;
         if (which == 1) {
             set_dyn_lds<k_yfwd<N, E, W>>(shmem);
             hipLaunchKernelGGL((k_yfwd<N, E, W>), dim3(N / W, 1, nplanes), dim3(threads), shmem, st, S, (const cplx *) tw, (cplx *) data);
+            ZD_LAUNCH_CHECK();
         } else {
             set_dyn_lds<k_zfwd<N, E, W>>(shmem);
             hipLaunchKernelGGL((k_zfwd<N, E, W>), dim3(N / W, S.Hq), dim3(threads), shmem, st, S, lZq, (const cplx *) tw,
                                (const cplx *) data, (cplx *) phik);
+            ZD_LAUNCH_CHECK();
         }
     }
-    ZD_LAUNCH_CHECK();
     return 0;
 }
 // which: 0 = x pass (inverse, phi + f_NL phi^2, forward) and 1 = forward y, on the planes [0, nplanes) of `data` (a store or a

@@ -288,13 +288,16 @@ int launch_any_scatter(const JobList &jobs, const AnyLayout &A, int ky0, int nky
 int launch_any_emit(const AnyLayout &A, const EpiConst &ec, const void *store, int plane0, int nplanes, int z_first, int z_step, void *records,
                     float *density, Reduce *red, hipStream_t st) {
     dim3 grid((A.N + 255) / 256, A.N, nplanes), block(256);
-    if (A.narray == 1)
+    if (A.narray == 1) {
         hipLaunchKernelGGL(k_any_emit<1>, grid, block, 0, st, A, ec, (const cplx *) store, plane0, z_first, z_step, (char *) records, density, red);
-    else if (A.narray == 2)
+        ZD_LAUNCH_CHECK();
+    } else if (A.narray == 2) {
         hipLaunchKernelGGL(k_any_emit<2>, grid, block, 0, st, A, ec, (const cplx *) store, plane0, z_first, z_step, (char *) records, density, red);
-    else
+        ZD_LAUNCH_CHECK();
+    } else {
         hipLaunchKernelGGL(k_any_emit<4>, grid, block, 0, st, A, ec, (const cplx *) store, plane0, z_first, z_step, (char *) records, density, red);
-    ZD_LAUNCH_CHECK();
+        ZD_LAUNCH_CHECK();
+    }
     return 0;
 }
 

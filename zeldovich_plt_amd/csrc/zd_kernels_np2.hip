@@ -129,7 +129,7 @@ __global__ __launch_bounds__(W *Q *P / E) void k_yfft_fq(FieldLayout F, StoreLay
     const int x = tile * W + w, xm = x ? N - x : 0;
     const int zl = plane0 + blockIdx.z;
     const int kx = x > N / 2 ? x - N : x;
-    if ((S.prune & 4) && __syncthreads_and(column_is_zero(S, kx, 0))) return;  // a tile without a live row: see k_yfft_f
+    if ((S.prune & PRUNE_YTILE) && __syncthreads_and(column_is_zero(S, kx, 0))) return;  // a tile without a live row: see k_yfft_f
     // ZA: E_a alone (a < 2) or (Z_0, Z_1); PLT: the pairs (X, fX), (Y, Z), (fY, fZ) of the six sums — see k_yfft_f
     const bool plt = F.nfield == 6, two = plt || a == 2;
     const int f0 = plt ? (a == 0 ? 0 : (a == 1 ? 1 : 4)) : (a == 2 ? 1 : 2 * a);

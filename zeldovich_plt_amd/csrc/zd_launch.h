@@ -4,8 +4,24 @@
 #include <stdio.h>
 #include "zd_device.h"
 
+// Dispatch diagnostics (zd_dispatch_report, include/zeldovich_hip.h): every launch site counts its launches under the name of
+// the launcher instantiation it sits in (template arguments included) — which kernel variant a configuration really took.
+// One relaxed atomic increment per launch; a site registers itself in a lock-free list the first time it is reached.
+#include <atomic>
+namespace zd {
+struct DispatchSite {
+    const char *func;
+    int line;
+    std::atomic<long long> count{0};
+    DispatchSite *next = nullptr;
+    DispatchSite(const char *f, int l);
+};
+}  // namespace zd
+
 #define ZD_LAUNCH_CHECK()                                                                       \
     do {                                                                                        \
+        static zd::DispatchSite site__(__PRETTY_FUNCTION__, __LINE__);                          \
+        site__.count.fetch_add(1, std::memory_order_relaxed);                                   \
         hipError_t e__ = hipGetLastError();                                                     \
         if (e__ != hipSuccess) {                                                                \
             fprintf(stderr, "zeldovich_hip: launch failed at %s:%d: %s\n", __FILE__, __LINE__,  \
@@ -15,19 +31,23 @@
     } while (0)
 
 // hipFuncAttributeMaxDynamicSharedMemorySize belongs to (kernel, device): ZD_NumGPU runs one host thread per device through
-// the same launchers, so "already set" is kept per device (bit d of one word per kernel) — a process-wide flag would leave
+// the same launchers, so what has been set is kept per device — a process-wide flag would leave
 // every device but the first with the 64 KB default and the launches of the large-LDS kernels would fail there.
 #if defined(__HIPCC__)
 #include <atomic>
 template <auto Kernel>
 static inline void set_dyn_lds(size_t bytes) {
-    static std::atomic<unsigned long long> done{0};
+    // largest size set so far per device: a kernel whose dynamic LDS depends on run-time arguments gets the attribute raised when
+    // a later launch needs more than the first one did
+    static std::atomic<size_t> have[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    const unsigned long long bit = 1ULL << (dev & 63);
-    if (done.load(std::memory_order_acquire) & bit) return;
+    std::atomic<size_t> &h = have[dev & 63];
+    if (bytes == 0 || h.load(std::memory_order_acquire) >= bytes) return;
     hipFuncSetAttribute((const void *) Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
-    done.fetch_or(bit, std::memory_order_release);
+    size_t cur = h.load(std::memory_order_relaxed);
+    while (cur < bytes && !h.compare_exchange_weak(cur, bytes, std::memory_order_release, std::memory_order_relaxed)) {
+    }
 }
 #endif
 

@@ -235,6 +235,10 @@ struct zd_comm {
     int rank = 0, nranks = 1;
     int kind = 0;  // 0 RCCL, 1 local
     ncclComm_t nccl = nullptr;
+    // Guards `nccl` against an abort from another thread (thread-per-GPU driver: whichever rank thread fails aborts EVERY
+    // communicator of the process): held by a rank around each group of RCCL host calls, and by the aborting thread while it
+    // aborts (= frees) this communicator and clears the pointer.  A rank therefore never enters RCCL with a freed handle.
+    std::mutex nccl_mu;
     bool owns_nccl = false;  // zd_comm_create: this object aborts / destroys the communicator; thread-per-GPU driver: the driver does
     LocalGroup *grp = nullptr;
     hipStream_t s_comm = nullptr;
@@ -288,7 +292,7 @@ int comm_ring(zd_comm *c, int64_t ring_b, int gp, hipStream_t st) {
         c->ring       = nullptr;
         c->ring_bytes = 0;
     }
-    MHIP(hipMalloc((void **) &c->ring, (size_t) ring_b));
+    MHIP(zd_store_alloc((void **) &c->ring, (size_t) ring_b));
     c->slot_used[0] = c->slot_used[1] = false;
     c->ring_bytes   = ring_b;
     c->slot_bytes   = ring_b / 2;
@@ -345,6 +349,7 @@ void zd_comm_abort(zd_comm *c) {
     if (!c) return;
     c->own_failed.store(1);
     if (c->failed) c->failed->store(1, std::memory_order_release);
+    std::lock_guard<std::mutex> lk(c->nccl_mu);
     if (c->kind == 0 && c->owns_nccl && c->nccl && rccl() && rccl()->CommAbort) {
         rccl()->CommAbort(c->nccl);  // frees the communicator: not destroyed again
         c->nccl = nullptr;
@@ -484,6 +489,8 @@ static int run_pass_body(zd_plan *pl, zd_comm *c, int pass, void *d_store, void 
                                     hipMemcpyDeviceToDevice, c->s_comm));
         } else {
             RcclApi *R = rccl();
+            std::lock_guard<std::mutex> lk(c->nccl_mu);
+            if (comm_failed(c) || !c->nccl) return 1;  // a peer failed (and may have aborted this communicator)
             MNCCL(R->GroupStart());
             for (int p = 0; p < G; p++) {
                 const char *sb = (const char *) d_store + (size_t) p * chunk_b + (size_t) p0 * cpb;
@@ -564,6 +571,7 @@ static int run_passes_impl(zd_plan *pl, zd_comm *c, int first, int step, void *d
                            int64_t rec_planes, zd_pass_cb cb, void *user, void *hip_stream) {
     hipStream_t st = (hipStream_t) hip_stream;
     if (first < 0 || step < 1) return 1;
+    pl->pass_step = step;
     PassCb pc{cb, user, 0};
     const bool pipelined = c && pl->nranks > 1 && c->kind == 0 && d_store2 != nullptr && first + step < pl->npass;
     if (!pipelined) {
@@ -578,7 +586,8 @@ static int run_passes_impl(zd_plan *pl, zd_comm *c, int first, int step, void *d
     int rc = 0, i = 0;
     do {
         // the first Z stage starts after whatever the caller queued on its stream (the stores' previous users)
-        MHIP(hipEventRecord(c->ev_z, st));
+        // (no MHIP in this block: a failure must reach the abort epilogue below, or the peers spin in their queued send / receive kernels)
+        if (hipEventRecord(c->ev_z, st) != hipSuccess) { rc = 1; break; }
         if ((rc = zd_plan_stage_z_detached(pl, first, stores[0], st, c->ev_z, c->ev_zd[0]))) break;
         for (int pass = first; pass < pl->npass && !rc; pass += step, i++) {
             const int b = i & 1, nxt = pass + step;
@@ -589,8 +598,7 @@ static int run_passes_impl(zd_plan *pl, zd_comm *c, int first, int step, void *d
         }
         if (rc) break;
         // the caller's stream ends behind the last sends (the stores may be freed or rewritten by the caller afterwards)
-        MHIP(hipEventRecord(c->ev_z, c->s_comm));
-        MHIP(hipStreamWaitEvent(st, c->ev_z, 0));
+        if (hipEventRecord(c->ev_z, c->s_comm) != hipSuccess || hipStreamWaitEvent(st, c->ev_z, 0) != hipSuccess) rc = 1;
     } while (0);
     if (rc) {
         if (c->failed) c->failed->store(1, std::memory_order_release);
@@ -639,6 +647,8 @@ static int phi_round(zd_plan *ph, zd_comm *c, void *d_store, void *d_phik, doubl
             }
         } else {
             RcclApi *R = rccl();
+            std::lock_guard<std::mutex> lk(c->nccl_mu);
+            if (comm_failed(c) || !c->nccl) return 1;  // (see run_pass_body)
             MNCCL(R->GroupStart());
             for (int p = 0; p < G; p++) {
                 char *sb = (char *) d_store + (size_t) p * chunk_b + (size_t) p0 * cpb;  // my rows, planes of rank p
@@ -845,9 +855,15 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
     // One failure flag for the job.  The rank that fails sets it and aborts EVERY communicator of the process (they are all
     // here): the send / receive kernels its peers have queued for it drain instead of spinning, the peers' stream syncs
     // return, they see the flag and leave.  Aborted communicators are freed by the abort, not destroyed again.
+    // (the abort FREES a communicator, and a healthy rank thread may be about to enter RCCL with the same handle —
+    // every rank's zd_comm lives for the whole job, owned by this driver, and its `nccl_mu` is held around each group of RCCL
+    // host calls of its rank and around the abort of its communicator; after the abort the handle is gone from the zd_comm
+    // and the rank's next exchange returns 1 before touching RCCL.)
     std::atomic<int> job_failed{0};
     std::mutex abort_mu;
     bool aborted = false;
+    std::vector<zd_comm *> comms(G, nullptr);
+    for (int g = 0; g < G; g++) comms[g] = new zd_comm;
     auto abort_all = [&]() {
         job_failed.store(1, std::memory_order_release);
         for (LocalGroup &grp : grps) grp.fail();
@@ -855,11 +871,14 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
         if (aborted || transport != 0) return;
         aborted = true;
         RcclApi *R = rccl();
-        for (int g = 0; g < G; g++)
+        for (int g = 0; g < G; g++) {
+            std::lock_guard<std::mutex> lc(comms[g]->nccl_mu);
             if (nccls[g] && R && R->CommAbort) {
                 R->CommAbort(nccls[g]);
                 nccls[g] = nullptr;
             }
+            comms[g]->nccl = nullptr;
+        }
     };
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> threads;
@@ -874,7 +893,7 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
             float *d_dens = nullptr, *h_dens = nullptr;
             void *d_phik = nullptr;
             char *h_rec = nullptr;
-            zd_comm *c  = new zd_comm;
+            zd_comm *c  = comms[g];
             hipStream_t st = nullptr;
             do {
                 if (hipSetDevice(me.device) != hipSuccess) break;
@@ -883,7 +902,10 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
                 c->rank   = rk;
                 c->nranks = gsz;
                 c->kind   = transport == 2 ? 0 : transport;  // the loopback emulation runs the RCCL branch
-                c->nccl   = nccls[g];
+                {
+                    std::lock_guard<std::mutex> lc(c->nccl_mu);
+                    c->nccl = nccls[g];
+                }
                 c->grp    = &grps[grp_id];
                 c->failed = &job_failed;
                 if (comm_prepare(c)) break;
@@ -893,8 +915,8 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
                     bool ok     = false;
                     do {
                         if (zd_plan_create_phi(&p, pk, rk, gsz, &ph)) break;
-                        if (hipMalloc(&d_phi, (size_t) zd_plan_exchange_bytes(ph)) != hipSuccess
-                            || hipMalloc(&d_phik, (size_t) ph->Hq * ph->N * ph->N * 16) != hipSuccess) {
+                        if (zd_store_alloc(&d_phi, (size_t) zd_plan_exchange_bytes(ph)) != hipSuccess
+                            || zd_store_alloc(&d_phik, (size_t) ph->Hq * ph->N * ph->N * 16) != hipSuccess) {
                             fprintf(stderr, "zeldovich_hip: rank %d: f_NL needs %.1f GB of HBM for the phi field\n", g,
                                     (zd_plan_exchange_bytes(ph) + (double) ph->Hq * ph->N * ph->N * 16) / 1e9);
                             break;
@@ -917,7 +939,7 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
                 const int64_t ring_b = cb ? ((int64_t) 1 << 30) : ((int64_t) 4 << 30);
                 int64_t rec_planes = std::max<int64_t>(ps, std::min<int64_t>(zd_plan_local_planes(pl),
                                                                              ring_b / (int64_t) (plane_rec_b + (want_dens ? nn * 4 : 0))) / ps * ps);
-                if (hipMalloc(&d_store, (size_t) zd_plan_exchange_bytes(pl)) != hipSuccess) {
+                if (zd_store_alloc(&d_store, (size_t) zd_plan_exchange_bytes(pl)) != hipSuccess) {
                     fprintf(stderr, "zeldovich_hip: rank %d cannot allocate the %.2f GB block store\n", g, zd_plan_exchange_bytes(pl) / 1e9);
                     break;
                 }
@@ -938,7 +960,7 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
                     size_t free_b = 0, total_b = 0;
                     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess
                         && free_b > (size_t) zd_plan_exchange_bytes(pl) * ((G + ndev - 1) / ndev) + ((size_t) 12 << 30))
-                        if (hipMalloc(&d_store2, (size_t) zd_plan_exchange_bytes(pl)) != hipSuccess) d_store2 = nullptr;
+                        if (zd_store_alloc(&d_store2, (size_t) zd_plan_exchange_bytes(pl)) != hipSuccess) d_store2 = nullptr;
                 }
                 GroupSink sink{pl, grp_id, &dl, h_rec, plane_rec_b, cb ? d_dens : nullptr, h_dens, -1, &job_failed, &job_failed};
                 if (run_passes_impl(pl, c, grp_id, groups, d_store, d_store2, d_rec, d_dens, rec_planes, sink_cb, &sink, st)) break;
@@ -955,12 +977,15 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
             hipFree(d_phik);
             if (h_rec) hipHostFree(h_rec);
             if (h_dens) hipHostFree(h_dens);
-            c->nccl = nullptr;  // destroyed (or aborted) by the driver, after every thread has left RCCL
-            zd_comm_destroy(c);
             if (pl) zd_plan_destroy(pl);
         });
     }
     for (auto &t : threads) t.join();
+    for (int g = 0; g < G; g++) {  // the communicators themselves are destroyed (or were aborted) by this driver, below / above
+        hipSetDevice(ctx[g].device);
+        comms[g]->nccl = nullptr;
+        zd_comm_destroy(comms[g]);
+    }
     if (transport == 2) {
 #ifdef ZD_TESTING
         g_rccl_override = nullptr;

@@ -55,6 +55,7 @@ struct zd_plan {
     std::vector<hipEvent_t> ev_gen, ev_fft;
     int slab_rows = 0;        // rows generated per k_gen launch
     long long next_g = 0;     // running slab number: slab g lives in ring slot g % K
+    int pass_step = 1;        // distance to this rank's next pass (pass groups: zd_plan_run_passes deals passes first, first + step, ...)
     int ahead_pass = -1;      // pass whose first `ahead_n` slabs (numbers ahead_g0...) are already being generated
     long long ahead_g0 = 0;
     int ahead_n = 0;
@@ -96,5 +97,7 @@ int zd_plan_phi_zfwd(zd_plan *pl, void *d_store, void *d_phik, void *hip_stream)
 void zd_plan_tick(zd_plan *pl, int kind, void *hip_stream, int begin);
 int zd_plan_stage_z_detached(zd_plan *pl, int residue, void *d_send, void *hip_stream, void *wait_event, void *done_event);
 }
+// hipMalloc for the large, partly written buffers (stores, rings, phi fields); NaN-filled under zd_test_poison (testing library)
+hipError_t zd_store_alloc(void **p, size_t bytes);
 int zd_generate_multi(const zd_params *p, const zd_pk *pk, const double *eig, int64_t eig_ppd, zd_slab_cb cb, void *user,
                       zd_stats *out, int transport);

@@ -7,6 +7,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default)
 /* ---- device test hooks (each needs a GPU) -------------------- */
 /* n counter-addressed draws: out[2*i], out[2*i+1] = the two uint64 of mode (kx,ky,kz)[i] */
 int zd_test_draws(int64_t seed, int64_t n, const int32_t *kxyz, uint64_t *out);
@@ -26,6 +27,9 @@ int zd_test_v1_words(int64_t seed, int32_t nblocks, uint32_t *out);
 /* batch of `lines` independent length-n inverse FFTs, host in/out [lines][n] complex double;
  * axis_kind 0: the contiguous-line kernel path (x pass), 1: the strided-line path (y/z passes) */
 int zd_test_fft(int32_t n, int64_t lines, int32_t axis_kind, const double *in, double *out);
+/* on != 0: every store / exchange ring / phi field the library allocates from now on starts out as NaN bytes */
+void zd_test_poison(int on);
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif
