@@ -63,6 +63,19 @@ def synthetic_eigenmodes(ppd_e=128, seed=7, amp=0.03, singular=False):
     return np.ascontiguousarray(out)
 
 
+def source_sha():
+    """sha-256 over the native sources (= `make -C zeldovich_plt_amd/csrc srcsha`, tests/conftest.py source_sha)"""
+    import glob
+    import hashlib
+    csrc = os.path.join(ROOT, "zeldovich_plt_amd", "csrc")
+    names = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.cpp"))
+                   + [os.path.join(ROOT, "include", "zeldovich_hip.h")])
+    h = hashlib.sha256()
+    for n in names:
+        h.update(open(n, "rb").read())
+    return h.hexdigest()
+
+
 def cpu_baseline(ppd, plt, fmt, eig):
     """oracle (CPU port of the reference path) on the host cores, bounded sample of the workload"""
     from oracle import zdo
@@ -80,10 +93,14 @@ def cpu_baseline(ppd, plt, fmt, eig):
     out = zdo.run(p, pk, eig=eig if plt else None, eig_ppd=eig.shape[0] if plt else 0)
     st = out["stats"]
     t = st.t_stage1 + st.t_store + st.t_load + st.t_fft2d + st.t_write
-    return {"value": n ** 3 / t, "unit": "particles/s", "cores": cores, "kind": "port",
+    fft = zdo.fft_backend()  # "fftw3" when the host has libfftw3.so.3 (the reference's transform), else the oracle's own
+    return {"value": n ** 3 / t, "unit": "particles/s", "cores": cores, "kind": "port", "fft": fft,
+            "phase_seconds": {"LoadPlane+zFFT": st.t_stage1, "StoreBlock": st.t_store, "LoadBlock": st.t_load,
+                              "FFT2D": st.t_fft2d, "WriteParticlesSlab": st.t_write},
             "sample": "PPD=%d %s %s, full grid->displacements (ZeldovichZ+ZeldovichXY timers), OpenMP on %d threads, "
-                      "radix-2 CPU FFT (FFTW3 absent); wall %.1fs" % (n, "PLT+rescale" if plt else "ZA", fmt, cores,
-                                                                     time.time() - t0)}
+                      "%s; wall %.1fs" % (n, "PLT+rescale" if plt else "ZA", fmt, cores,
+                                          "FFTW3 (dlopen)" if fft == "fftw3" else "radix-2 CPU FFT (no libfftw3.so.3 on this host)",
+                                          time.time() - t0)}
 
 
 def main():
@@ -103,6 +120,9 @@ def main():
                          "one GPU per group while the passes, after at most one doubling of the stream factor, deal out over the N GPUs; else "
                          "one group with the all-to-all exchange)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--two-stores", action="store_true",
+                    help="one GPU: a second block store, the Z stage of pass p + 1 issued beside the y / x stages of pass p "
+                         "(zd_plan_run_passes); use with --stream 2R so that two stores fit (A/B measurement, DESIGN §8)")
     ap.add_argument("--dist", action="store_true",
                     help="take the N > 1 code path (torch.distributed RCCL group, zd.Comm id broadcast, per-rank gathers) whatever "
                          "the world size: rehearses it on one GPU under torch.distributed.run --nproc-per-node 1")
@@ -145,41 +165,81 @@ def main():
         t = torch.tensor([budget], dtype=torch.int64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         budget = int(t.item())
-    # How the GPUs share the job (the library's policy, zd_choose_pass_groups): `groups` independent groups of gsz ranks;
-    # group j runs the residue passes j, j + groups, ...; inside a group the rows / planes are sharded with one exchange per pass
-    p.stream_factor = args.stream
-    p.pass_groups = args.groups
-    g_, R_ = ctypes.c_int32(), ctypes.c_int32()
-    if zd.load_library().zd_choose_pass_groups(ctypes.byref(p), world, budget, ctypes.byref(g_), ctypes.byref(R_)):
-        raise SystemExit("PPD=%d does not fit %d GPU(s)" % (N, world))
-    groups, R = g_.value, R_.value
-    p.stream_factor = R
-    grp_id, grank, gsz = split_ranks(rank, world, groups)
-    plan = zd.Plan(p, ps, eig=eig, rank=grank, nranks=gsz)
-    assert plan.passes % groups == 0
-    comm = None
-    if multi and (gsz > 1 or args.dist):
-        # the library's own RCCL communicator, one per group; torch.distributed only carries the 128-byte ids (rank 0 of every
-        # group makes one) and the timing fences
-        def exchange_id(raw):
-            mine = torch.tensor(list(raw), dtype=torch.uint8, device="cuda")
-            allr = [torch.zeros_like(mine) for _ in range(world)]
-            dist.all_gather(allr, mine)
-            return bytes(allr[grp_id * gsz].cpu().tolist())
-        comm = zd.Comm(grank, gsz, exchange_id)
-    pipe = SlabPipeline(HipEngine(plan, N, comm=comm), N, world=gsz, dist=dist, device="cuda")
-    pipelined = False
-    if comm is not None and gsz > 1 and plan.passes // groups >= 2:
-        free_now = torch.tensor([torch.cuda.mem_get_info()[0]], dtype=torch.int64, device="cuda")
-        dist.all_reduce(free_now, op=dist.ReduceOp.MIN)  # every rank of the job takes the same decision
-        if int(free_now.item()) > plan.exchange_bytes + (12 << 30):
-            pipe.alloc_second_store()  # passes pipelined: Z stage of pass p + 1 beside the exchange of pass p
+    def run_split(groups_req):
+        """one measurement of the workload with the GPUs split into `groups_req` pass groups (0 = the library's choice): plan,
+        communicator, buffers, W warm-up + K timed steps between fences, per-rank spans.  The caller closes what it returns."""
+        # How the GPUs share the job (the library's policy, zd_choose_pass_groups): `groups` independent groups of gsz ranks;
+        # group j runs the residue passes j, j + groups, ...; inside a group the rows / planes are sharded with one exchange per pass
+        p.stream_factor = args.stream
+        p.pass_groups = groups_req
+        g_, R_ = ctypes.c_int32(), ctypes.c_int32()
+        if zd.load_library().zd_choose_pass_groups(ctypes.byref(p), world, budget, ctypes.byref(g_), ctypes.byref(R_)):
+            return None
+        groups, R = g_.value, R_.value
+        p.stream_factor = R
+        grp_id, grank, gsz = split_ranks(rank, world, groups)
+        plan = zd.Plan(p, ps, eig=eig, rank=grank, nranks=gsz)
+        assert plan.passes % groups == 0
+        comm = None
+        if multi and (gsz > 1 or args.dist):
+            # the library's own RCCL communicator, one per group; torch.distributed only carries the 128-byte ids (rank 0 of every
+            # group makes one) and the timing fences.  zd_comm_create ends with a 1 MB grouped send / receive between neighbours:
+            # a mis-wired communicator fails here, in milliseconds, not inside pass 0
+            def exchange_id(raw):
+                mine = torch.tensor(list(raw), dtype=torch.uint8, device="cuda")
+                allr = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(allr, mine)
+                return bytes(allr[grp_id * gsz].cpu().tolist())
+            comm = zd.Comm(grank, gsz, exchange_id)
+        pipe = SlabPipeline(HipEngine(plan, N, comm=comm), N, world=gsz, dist=dist, device="cuda")
+        pipelined = False
+        if comm is not None and gsz > 1 and plan.passes // groups >= 2:
+            free_now = torch.tensor([torch.cuda.mem_get_info()[0]], dtype=torch.int64, device="cuda")
+            dist.all_reduce(free_now, op=dist.ReduceOp.MIN)  # every rank of the job takes the same decision
+            if int(free_now.item()) > plan.exchange_bytes + (12 << 30):
+                pipe.alloc_second_store()  # passes pipelined: Z stage of pass p + 1 beside the exchange of pass p
+                pipelined = True
+        if args.two_stores and gsz == 1 and plan.passes // groups >= 2:
+            pipe.alloc_second_store()  # one GPU: Z stage of pass p + 1 beside the XY stages of pass p
             pipelined = True
 
-    def step():
-        # per residue pass, inside the library (zd_plan_run_pass): Z stage -> exchange in plane groups over RCCL/xGMI,
-        # overlapped with -> y FFT -> x FFT + epilogue of the previous group
-        pipe.run(pass_first=grp_id, pass_step=groups)
+        def step():
+            # per residue pass, inside the library (zd_plan_run_pass): Z stage -> exchange in plane groups over RCCL/xGMI,
+            # overlapped with -> y FFT -> x FFT + epilogue of the previous group
+            pipe.run(pass_first=grp_id, pass_step=groups)
+
+        for _ in range(args.warmup):
+            step()
+        fence()
+        plan.stats()  # drop warm-up kernel timers
+        if comm is not None:
+            comm.traffic(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        st = plan.stats()
+        per_rank = None
+        if multi:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            # what every rank did in the timed region, so that a scaling curve can be read: Z stage, time the compute stream
+            # stood waiting for exchanged planes, XY stages (hipEvent spans on the launch stream), bytes sent to peers
+            mine = torch.tensor([dt, st["kernel_ms"]["z_stage"], st["kernel_ms"]["exchange_wait"], st["kernel_ms"]["k_yfft"],
+                                 st["kernel_ms"]["k_xfft"], float(st["bytes_sent"])], dtype=torch.float64, device="cuda")
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            dt = float(t.item())
+            per_rank = [{"rank": i, "wall_ms_per_step": float(v[0]) / args.steps * 1e3, "z_stage_ms": float(v[1]) / args.steps,
+                         "exchange_wait_ms": float(v[2]) / args.steps, "y_ms": float(v[3]) / args.steps,
+                         "x_ms": float(v[4]) / args.steps, "GB_sent_per_step": float(v[5]) / args.steps / 1e9,
+                         "send_GBps_while_waiting_or_computing": (float(v[5]) / 1e9) / max(float(v[0]), 1e-9)}
+                        for i, v in enumerate(allr)]
+            if gsz > 1:  # ranks that exchange: RCCL must have been on the data path of EVERY rank
+                assert all(r["GB_sent_per_step"] > 0 for r in per_rank), per_rank
+        return dict(groups=groups, R=R, gsz=gsz, grp_id=grp_id, plan=plan, comm=comm, pipe=pipe, pipelined=pipelined, dt=dt, st=st,
+                    per_rank=per_rank)
 
     def fence():
         torch.cuda.synchronize()
@@ -187,32 +247,31 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    plan.stats()  # drop warm-up kernel timers
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    st = plan.stats()
-    per_rank = None
-    if multi:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        # what every rank did in the timed region, so that a scaling curve can be read: Z stage, time the compute stream
-        # stood waiting for exchanged planes, XY stages (hipEvent spans on the launch stream), bytes sent to peers
-        mine = torch.tensor([dt, st["kernel_ms"]["z_stage"], st["kernel_ms"]["exchange_wait"], st["kernel_ms"]["k_yfft"],
-                             st["kernel_ms"]["k_xfft"], float(st["bytes_sent"])], dtype=torch.float64, device="cuda")
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        dt = float(t.item())
-        per_rank = [{"rank": i, "wall_ms_per_step": float(v[0]) / args.steps * 1e3, "z_stage_ms": float(v[1]) / args.steps,
-                     "exchange_wait_ms": float(v[2]) / args.steps, "y_ms": float(v[3]) / args.steps,
-                     "x_ms": float(v[4]) / args.steps, "GB_sent_per_step": float(v[5]) / args.steps / 1e9,
-                     "send_GBps_while_waiting_or_computing": (float(v[5]) / 1e9) / max(float(v[0]), 1e-9)}
-                    for i, v in enumerate(allr)]
+    def mode_summary(m):
+        """what the JSON line says about one split of the GPUs"""
+        pl_ = m["plan"]
+        d = {"groups": m["groups"], "ranks_per_group": m["gsz"], "stream_factor": m["R"], "passes": pl_.passes,
+             "passes_per_gpu": pl_.passes // m["groups"], "s_per_step": m["dt"] / args.steps,
+             "particles_per_s": float(N) ** 3 * args.steps / m["dt"], "pipelined_over_two_send_stores": m["pipelined"],
+             "block_store_GB_per_rank_and_pass": pl_.exchange_bytes / 1e9}
+        if m["per_rank"] is not None:
+            d["per_rank"] = m["per_rank"]
+            d["GB_sent_per_step"] = sum(r["GB_sent_per_step"] for r in m["per_rank"])
+            d["max_exchange_wait_ms"] = max(r["exchange_wait_ms"] for r in m["per_rank"])
+        return d
+
+    def close_mode(m):
+        m["plan"].close()
+        if m["comm"] is not None:
+            m["comm"].close()
+        m["pipe"] = m["plan"] = m["comm"] = None
+        torch.cuda.empty_cache()
+
+    main_mode = run_split(args.groups)
+    if main_mode is None:
+        raise SystemExit("PPD=%d does not fit %d GPU(s)" % (N, world))
+    groups, R, gsz, plan, comm, pipe, pipelined = (main_mode[k] for k in ("groups", "R", "gsz", "plan", "comm", "pipe", "pipelined"))
+    dt, st, per_rank = main_mode["dt"], main_mode["st"], main_mode["per_rank"]
 
     # one extra UNTIMED pass with the two-stream overlap of the Z stage switched off: every kernel alone on the chip
     # (in the timed region k_gen and k_zfft share it, so their hipEvent spans there include each other)
@@ -244,14 +303,21 @@ def main():
         design = {"z_stage": 3.0 * store_b,                       # folded inputs written + read, store written
                   "k_yfft": (store_b + inter_b) if fields else 2.0 * store_b,
                   "k_xfft": inter_b + recsize * particles}
-        traffic_file = None
+        # PMC bytes per launch come from a rocprofv3 --pmc run of THIS command (scripts/gpu_profile.sh), committed as
+        # profiles/traffic_latest.json together with the sha-256 of the native sources it profiled; a figure measured on other
+        # kernels than the ones in this tree is not reported (traffic: null + traffic_stale)
+        traffic_file, traffic_stale = None, None
         tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
                 if tj.get("workload") == "PPD=%d plt=%d" % (N, int(plt)) and tj.get("store_arrays") == plan.narray \
                         and tj.get("passes") == plan.passes:
-                    traffic_file = tj
+                    if tj.get("source_sha") == source_sha():
+                        traffic_file = tj
+                    else:
+                        traffic_stale = ("profiles/traffic_latest.json was measured on sources %s, this tree is %s: re-run "
+                                         "scripts/gpu_profile.sh" % (str(tj.get("source_sha"))[:12], source_sha()[:12]))
             except Exception:
                 traffic_file = None
 
@@ -325,7 +391,10 @@ def main():
                                     if dom == "z_stage" and not plt else "")},
             "kernels": per_kernel,
             "kernels_isolated": isolated,
+            "source_sha": source_sha(),
         }
+        if traffic_stale:
+            out["roofline"]["traffic_stale"] = traffic_stale
         if per_rank is not None:
             out["per_rank"] = per_rank
             out["exchange"] = {"transport": "RCCL grouped ncclSend/ncclRecv per plane group (zd_plan_run_pass)",
@@ -337,8 +406,30 @@ def main():
             except Exception as e:  # the baseline is a reported number, never the product path
                 out["cpu_baseline"] = {"value": None, "unit": "particles/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}
+    # N > 1 (or --dist): the OTHER way to share the job is timed in the same run, so that one SCALE record holds both — BASELINE C4
+    # names the slab all-to-all ("one group of all GPUs"), the library's default for PPD=4096 is one GPU per pass group with no
+    # exchange at all; `value` is the default's, `modes` has both with per-rank spans and bytes
+    modes = None
+    if multi:
+        # a split is named by what happens between its GPUs: ranks of a group exchange (all_to_all) or every GPU is its own group
+        first_name = "all_to_all" if gsz > 1 else "pass_groups"
+        other_name = "pass_groups" if first_name == "all_to_all" else "all_to_all"
+        modes = {"default": first_name, first_name: mode_summary(main_mode)}
+        close_mode(main_mode)
+        plan = comm = pipe = None
+        other = run_split(world if first_name == "all_to_all" else 1)  # one GPU per group <-> one group of all GPUs
+        if other is not None and (world == 1 or (other["gsz"] > 1) != (gsz > 1)):
+            modes[other_name] = mode_summary(other)
+        else:
+            modes[other_name] = {"unavailable": "the passes of this workload do not deal out that way on %d GPU(s)" % world}
+        if other is not None:
+            close_mode(other)
+    if rank == 0:
+        if modes is not None:
+            out["modes"] = modes
         print(json.dumps(out))
-    plan.close()
+    if plan is not None:
+        plan.close()
     if comm is not None:
         comm.close()
     if multi:

@@ -131,6 +131,11 @@ void zdo_get_eigenmode(const double *eig, int64_t eig_ppd, int kx, int ky, int k
 int zdo_direct_sum(const zdo_params *p, const zdo_pk *pk, const double *eig, int64_t eig_ppd, int nsites, const int *sites,
                    double *out);
 
+/* which 1-D transform the oracle runs: "fftw3" when the host has libfftw3.so.3 (bound with dlopen; what the reference calls,
+ * src/zeldovich.cpp:39-135), else the built-in "radix-2"; zdo_fft_use_fftw(0) forces the built-in one */
+const char *zdo_fft_backend(void);
+void zdo_fft_use_fftw(int on);
+
 /* record sizes: src/output.h:19-42 */
 int zdo_record_size(int icformat);
 int zdo_narray(const zdo_params *p); /* src/zeldovich.cpp:871-876 */

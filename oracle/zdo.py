@@ -91,6 +91,7 @@ def lib():
         L.zdo_get_eigenmode.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64,
                                         C.c_int, C.POINTER(C.c_double)]
         L.zdo_direct_sum.argtypes = [C.POINTER(Params), C.POINTER(Pk), C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+        L.zdo_fft_backend.restype = C.c_char_p
         L.zdo_pk_set_primordial.argtypes = [C.POINTER(Pk), C.c_double]
         L.zdo_infer_Tk.argtypes = [C.POINTER(Pk), C.c_double]
         L.zdo_infer_Tk.restype = C.c_double
@@ -99,6 +100,11 @@ def lib():
         L.zdo_blockarray_roundtrip.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
         _lib = L
     return _lib
+
+
+def fft_backend():
+    """'fftw3' when the host has libfftw3.so.3 (what the reference calls), else the oracle's built-in 'radix-2'"""
+    return lib().zdo_fft_backend().decode()
 
 
 def have_ref():

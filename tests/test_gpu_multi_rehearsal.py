@@ -46,6 +46,17 @@ def test_bench_distributed_code_path_on_one_gpu():
     for k in ("z_stage_ms", "exchange_wait_ms", "y_ms", "x_ms", "GB_sent_per_step", "wall_ms_per_step"):
         assert k in pr[0]
     assert pr[0]["z_stage_ms"] > 0 and pr[0]["x_ms"] > 0 and pr[0]["GB_sent_per_step"] == 0.0  # one rank sends nothing
+    # both ways of sharing the job are timed in one run: `value` is the library's default split, `modes` holds
+    # the exchange-free pass groups AND the slab all-to-all BASELINE C4 names, each with its per-rank spans and bytes
+    m = d["modes"]
+    assert m["default"] in ("pass_groups", "all_to_all") and set(m) == {"default", "pass_groups", "all_to_all"}
+    for name in ("pass_groups", "all_to_all"):
+        e = m[name]
+        for k in ("groups", "ranks_per_group", "stream_factor", "passes", "passes_per_gpu", "s_per_step", "particles_per_s",
+                  "per_rank", "GB_sent_per_step", "max_exchange_wait_ms", "pipelined_over_two_send_stores"):
+            assert k in e, (name, k)
+        assert e["s_per_step"] > 0 and len(e["per_rank"]) == 1 and e["per_rank"][0]["x_ms"] > 0
+    assert abs(m[m["default"]]["particles_per_s"] - d["value"]) <= 1e-9 * d["value"]
 
 
 def test_failing_consumer_returns_an_error_instead_of_hanging(zd):

@@ -1176,6 +1176,8 @@ void zd_plan_destroy(zd_plan *pl) {
     if (pl->s_gen) hipStreamDestroy(pl->s_gen);
     if (pl->s_fft) hipStreamDestroy(pl->s_fft);
     if (pl->ev_fork) hipEventDestroy(pl->ev_fork);
+    for (hipEvent_t e : pl->ev_pipe)
+        if (e) hipEventDestroy(e);
     for (hipEvent_t e : pl->ev_gen)
         if (e) hipEventDestroy(e);
     for (hipEvent_t e : pl->ev_fft)

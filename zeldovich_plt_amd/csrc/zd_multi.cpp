@@ -341,6 +341,41 @@ int zd_comm_create(int rank, int nranks, const void *id128, zd_comm **out) {
         delete c;
         return 1;
     }
+    // Handshake: 1 MB to the next rank, 1 MB from the previous one, as ONE grouped send / receive on the communication stream —
+    // the call pattern of the exchange.  A communicator that is wired wrongly (ranks on the wrong devices, an id that did not
+    // reach everybody, a transport that cannot reach a peer) fails or times out HERE, in well under a minute, instead of
+    // inside pass 0 with 200 GB of stores allocated.
+    if (nranks > 1) {
+        const size_t nb = (size_t) 1 << 20;
+        char *buf = nullptr;
+        bool ok = hipMalloc((void **) &buf, 2 * nb) == hipSuccess && hipMemsetAsync(buf, 0x5a, nb, c->s_comm) == hipSuccess;
+        if (ok) {
+            ok = R->GroupStart() == ncclSuccess;
+            ok = ok && R->Send(buf, nb, ncclChar, (rank + 1) % nranks, c->nccl, c->s_comm) == ncclSuccess;
+            ok = ok && R->Recv(buf + nb, nb, ncclChar, (rank + nranks - 1) % nranks, c->nccl, c->s_comm) == ncclSuccess;
+            ok = (R->GroupEnd() == ncclSuccess) && ok;
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        while (ok) {
+            const hipError_t q = hipStreamQuery(c->s_comm);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady || std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) ok = false;
+            else std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        }
+        unsigned char probe[2] = {0, 0};
+        if (ok) ok = hipMemcpy(probe, buf + nb, 1, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(probe + 1, buf + 2 * nb - 1, 1, hipMemcpyDeviceToHost) == hipSuccess
+                     && probe[0] == 0x5a && probe[1] == 0x5a;
+        if (!ok) {
+            fprintf(stderr, "zeldovich_hip: rank %d of %d: the 1 MB send / receive handshake with the neighbouring ranks failed or timed out: "
+                            "the communicator is not usable\n", rank, nranks);
+            zd_comm_abort(c);  // queued send / receive kernels drain
+            hipFree(buf);
+            zd_comm_destroy(c);
+            return 1;
+        }
+        hipFree(buf);
+        c->bytes_sent = c->bytes_received = 0;
+    }
     *out = c;
     return 0;
 }
@@ -449,6 +484,7 @@ static int run_pass_body(zd_plan *pl, zd_comm *c, int pass, void *d_store, void 
             if (zd_plan_stage_x_group(pl, pass, d_store, pl->Zq, q0, q0, n, d_records, d_density, st)) return 1;
             if (cb && cb(user, q0, n, d_records, st)) return 1;
         }
+        if (sends_done) MHIP(hipEventRecord(sends_done, st));  // (one rank, two stores: the XY stages have left d_store)
         return 0;
     }
     if (c->nranks != pl->nranks || c->rank != pl->rank) {
@@ -574,6 +610,26 @@ static int run_passes_impl(zd_plan *pl, zd_comm *c, int first, int step, void *d
     pl->pass_step = step;
     PassCb pc{cb, user, 0};
     const bool pipelined = c && pl->nranks > 1 && c->kind == 0 && d_store2 != nullptr && first + step < pl->npass;
+    // ONE rank with a second store: the Z stage of pass p + 1 — vector-bound — is issued detached into the other
+    // store while the y / x stages of pass p — HBM-bound — run on the caller's stream; its z FFT waits until the XY stages of pass
+    // p - 1 have left that store.  Two stores of half the size mean twice the passes (twice the generations), so whether this
+    // pays is a measurement: bench.py --two-stores (profiles/r04_tuning_notes.md).
+    if (!pipelined && pl->nranks == 1 && d_store2 != nullptr && first + step < pl->npass && pl->overlap && !pl->any) {
+        for (hipEvent_t &e : pl->ev_pipe)
+            if (!e) MHIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        hipEvent_t ev_start = pl->ev_pipe[0], *ev_zd = pl->ev_pipe + 1, *ev_xy = pl->ev_pipe + 3;
+        void *stores[2] = {d_store, d_store2};
+        MHIP(hipEventRecord(ev_start, st));
+        if (zd_plan_stage_z_detached(pl, first, stores[0], st, ev_start, ev_zd[0])) return 1;
+        int i = 0;
+        for (int pass = first; pass < pl->npass; pass += step, i++) {
+            const int b = i & 1, nxt = pass + step;
+            if (nxt < pl->npass && zd_plan_stage_z_detached(pl, nxt, stores[1 - b], st, i >= 1 ? ev_xy[1 - b] : ev_start, ev_zd[1 - b])) return 1;
+            pc.pass = pass;
+            if (run_pass_body(pl, nullptr, pass, stores[b], d_records, d_density, rec_planes, pass_cb_adaptor, &pc, st, ev_zd[b], ev_xy[b])) return 1;
+        }
+        return 0;
+    }
     if (!pipelined) {
         for (int pass = first; pass < pl->npass; pass += step) {
             pc.pass = pass;

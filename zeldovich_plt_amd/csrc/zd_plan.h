@@ -61,6 +61,7 @@ struct zd_plan {
     int ahead_n = 0;
     hipStream_t s_gen = nullptr, s_fft = nullptr;
     hipEvent_t ev_fork = nullptr;
+    hipEvent_t ev_pipe[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // one rank, two stores (zd_plan_run_passes): start, Z done x2, XY done x2
     bool overlap = true;
     // ZD_Version = 1 (zd_kernels_v1.hip): mt19937 streams, one per yres; accepted pairs of the slab being generated
     int v1_block = 0;               // PPD / NumBlock streams (0: version 2)
