@@ -114,6 +114,9 @@ typedef struct zd_stats {
     int32_t modes_cached;       /* 1 if the Gaussian mode amplitudes were kept in HBM across passes */
     int64_t bytes_sent;         /* N > 1 ranks: bytes sent to OTHER ranks since the last zd_plan_stats / by this zd_generate call
                                  * (zd_generate: summed over the ranks) */
+    int64_t max_disp_index[3];  /* lattice site (z * ppd + y) * ppd + x of max_disp[j]: the FIRST site in the reference's (z, y, x)
+                                 * loop order that holds the largest |displacement| (output.cpp:190-193 compares with a strict >);
+                                 * -1 if the field is identically zero */
 } zd_stats;
 
 /* Replacement for the per-plane callback WriteParticlesSlab (src/output.cpp:41-234).

@@ -53,7 +53,7 @@ class ZdStats(C.Structure):
         ("max_disp", C.c_double * 3), ("density_variance", C.c_double), ("seconds_total", C.c_double),
         ("kernel_ms", C.c_double * 6), ("kernel_launches", C.c_int64 * 6),
         ("bytes_intermediate", C.c_int64), ("stream_factor", C.c_int32), ("modes_cached", C.c_int32),
-        ("bytes_sent", C.c_int64),
+        ("bytes_sent", C.c_int64), ("max_disp_index", C.c_int64 * 3),
     ]
 
 
@@ -297,7 +297,8 @@ def _stats_dict(st):
                 seconds_total=st.seconds_total, kernel_ms=dict(zip(KERNEL_NAMES, list(st.kernel_ms))),
                 kernel_launches=dict(zip(KERNEL_NAMES, list(st.kernel_launches))),
                 bytes_intermediate=st.bytes_intermediate, stream_factor=st.stream_factor,
-                modes_cached=bool(st.modes_cached), bytes_sent=st.bytes_sent)
+                modes_cached=bool(st.modes_cached), bytes_sent=st.bytes_sent,
+                max_disp_index=np.array(list(st.max_disp_index)))
 
 
 def generate(params, ps, eig=None, collect=True, loopback=False, testing=False):

@@ -1468,16 +1468,18 @@ int zd_plan_stats(zd_plan *pl, zd_stats *out) {
     out->density_variance = pl->pack != zd::PACK_NONE ? ss * (double) pl->N * (double) pl->N * (double) pl->N : ss;
     pl->var_pending       = true;
     for (int j = 0; j < 3; j++) {
-        double mp = 0, mn = 0;
-        for (int i = 0; i < zd::NSLOT; i++) {
-            double a, b;
-            memcpy(&a, &h.maxpos[j][i], 8);
-            memcpy(&b, &h.maxneg[j][i], 8);
-            mp = std::max(mp, a);
-            mn = std::max(mn, b);
-        }
-        // output.cpp:190-193 keeps the signed value of the largest |pos|
-        out->max_disp[j] = (mp >= mn) ? mp : -mn;
+        // output.cpp:190-193 keeps the signed value of the largest |pos|, the first one in (z, y, x) order on a tie: the slots hold
+        // (|v|, (linear index << 1) | negative) of their best record
+        unsigned long long babs = 0, bkey = 0;
+        for (int i = 0; i < zd::NSLOT; i++)
+            if (h.maxabs[j][i] > babs || (h.maxabs[j][i] == babs && babs != 0 && h.maxkey[j][i] < bkey)) {
+                babs = h.maxabs[j][i];
+                bkey = h.maxkey[j][i];
+            }
+        double a;
+        memcpy(&a, &babs, 8);
+        out->max_disp[j]       = (bkey & 1ULL) ? -a : a;
+        out->max_disp_index[j] = babs ? (int64_t) (bkey >> 1) : -1;
     }
     for (int k = 0; k < ZD_K_COUNT; k++) {
         out->kernel_ms[k]       = pl->kernel_ms[k];

@@ -269,8 +269,11 @@ struct AnyLayout {  // store [plane][array][row y][x]
 constexpr int NSLOT = 64;
 struct Reduce {
     double sumsq[NSLOT];
-    unsigned long long maxpos[3][NSLOT];  // bit pattern of max(+v)
-    unsigned long long maxneg[3][NSLOT];  // bit pattern of max(-v)
+    // max_disp (output.cpp:190-193: largest |v| per axis, first occurrence in (z, y, x) order on a tie): bit pattern of |v|, and
+    // (linear lattice index << 1) | (v < 0) of the record that holds it; updated as a pair under lock[slot] (zd_epi.h max_commit)
+    unsigned long long maxabs[3][NSLOT];
+    unsigned long long maxkey[3][NSLOT];
+    unsigned int lock[NSLOT];
 };
 
 // y stage of the field stores: workgroup index -> (column tile of W columns, array a of 3).  Workgroups go to the 8 XCDs round-robin

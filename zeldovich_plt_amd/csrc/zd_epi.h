@@ -63,48 +63,153 @@ __device__ __forceinline__ void emit_record(char *__restrict__ records, long lon
 }
 
 
+// max_disp of WriteParticlesSlab (src/output.cpp:28,190-193): per axis the SIGNED displacement of largest magnitude, and on a tie in
+// magnitude the one met first in the reference's (z, y, x) loop order — `if (fabs(pos) > fabs(max)) max = pos` with a strict
+// comparison.  Tracked as (signed value, linear lattice index (z N + y) N + x) per thread, reduced over the workgroup and combined
+// globally by the key (|v|, smaller index).  (Rounds 1-3 kept max(+v) and max(-v) apart and let +v win a tie.)
+struct MaxAbs {
+    double v[3] = {0.0, 0.0, 0.0};
+    unsigned long long lin[3] = {0ULL, 0ULL, 0ULL};
+};
+// strict form: the caller visits its records in increasing linear index (the first record of a magnitude stays)
+__device__ __forceinline__ void max_track(MaxAbs &m, const double (&pos)[3], unsigned long long lin) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const bool g = fabs(pos[j]) > fabs(m.v[j]);
+        m.v[j]   = g ? pos[j] : m.v[j];
+        m.lin[j] = g ? lin : m.lin[j];
+    }
+}
+// the same with a 32-bit tag local to the thread's row(s) (kernels held to 128 registers); widen() turns it into the lattice index
+struct MaxAbs32 {
+    double v[3] = {0.0, 0.0, 0.0};
+    int tag[3] = {0, 0, 0};
+};
+__device__ __forceinline__ void max_track(MaxAbs32 &m, const double (&pos)[3], int tag) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const bool g = fabs(pos[j]) > fabs(m.v[j]);
+        m.v[j]   = g ? pos[j] : m.v[j];
+        m.tag[j] = g ? tag : m.tag[j];
+    }
+}
+// any visiting order: ties in magnitude go to the smaller index
+__device__ __forceinline__ bool max_better(double v, unsigned long long lin, double cur, unsigned long long curlin) {
+    const double a = fabs(v), b = fabs(cur);
+    return a > b || (a == b && a > 0.0 && lin < curlin);
+}
+__device__ __forceinline__ void max_track_any(MaxAbs32 &m, const double (&pos)[3], int tag) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const bool g = max_better(pos[j], (unsigned long long) (unsigned) tag, m.v[j], (unsigned long long) (unsigned) m.tag[j]);
+        m.v[j]   = g ? pos[j] : m.v[j];
+        m.tag[j] = g ? tag : m.tag[j];
+    }
+}
+__device__ __forceinline__ void max_track_any(MaxAbs &m, const double (&pos)[3], unsigned long long lin) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const bool g = max_better(pos[j], lin, m.v[j], m.lin[j]);
+        m.v[j]   = g ? pos[j] : m.v[j];
+        m.lin[j] = g ? lin : m.lin[j];
+    }
+}
+
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one candidate of a workgroup into the replicated global slot: maxabs = bit pattern of |v| (monotone in |v| for v >= 0),
+// maxkey = (linear index << 1) | (v < 0).  Almost every workgroup leaves after two loads (its |v| is below the slot's); a
+// candidate that can improve the slot updates the pair under the slot's lock.
+__device__ __forceinline__ void max_commit(Reduce *__restrict__ red, int j, int slot, double v, unsigned long long lin) {
+    const unsigned long long myabs = dbits(fabs(v)), mykey = (lin << 1) | (v < 0.0 ? 1ULL : 0ULL);
+    if (myabs == 0ULL) return;
+    const unsigned long long cur = ld_agent(&red->maxabs[j][slot]);
+    if (myabs < cur) return;
+    // (pair read without the lock: the key of a given magnitude only decreases, and a larger magnitude beats this candidate anyway)
+    if (myabs == cur && mykey >= ld_agent(&red->maxkey[j][slot])) return;
+    while (atomicCAS(&red->lock[slot], 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(2);
+    const unsigned long long a = ld_agent(&red->maxabs[j][slot]), k = ld_agent(&red->maxkey[j][slot]);
+    if (myabs > a || (myabs == a && mykey < k)) {
+        __hip_atomic_store(&red->maxkey[j][slot], mykey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&red->maxabs[j][slot], myabs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __threadfence();
+    atomicExch(&red->lock[slot], 0u);
+}
+
 // workgroup reduction of the epilogue -> one atomic per quantity into a replicated slot
 template <int NT, int NA>
-__device__ __forceinline__ void xfft_reduce(double *lds, Reduce *__restrict__ red, double ssq, double (&mp)[3], double (&mn)[3]) {
+__device__ __forceinline__ void xfft_reduce(double *lds, Reduce *__restrict__ red, double ssq, MaxAbs &m) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         ssq += __shfl_down(ssq, off);
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-            mp[j] = fmax(mp[j], __shfl_down(mp[j], off));
-            mn[j] = fmax(mn[j], __shfl_down(mn[j], off));
+            const double ov = __shfl_down(m.v[j], off);
+            const unsigned long long ol = __shfl_down(m.lin[j], off);
+            const bool g = max_better(ov, ol, m.v[j], m.lin[j]);
+            m.v[j]   = g ? ov : m.v[j];
+            m.lin[j] = g ? ol : m.lin[j];
         }
     }
     __syncthreads();
-    double *scr = lds;  // 7 doubles per wave
+    double *scr = lds;  // 7 doubles per wave: ssq, v[3], lin[3] (bit patterns)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (lane == 0) {
         scr[wave * 7 + 0] = ssq;
         for (int j = 0; j < 3; j++) {
-            scr[wave * 7 + 1 + j] = mp[j];
-            scr[wave * 7 + 4 + j] = mn[j];
+            scr[wave * 7 + 1 + j] = m.v[j];
+            scr[wave * 7 + 4 + j] = __longlong_as_double((long long) m.lin[j]);
         }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         constexpr int NW = (NT + 63) / 64;
-        double tot = 0, a3[3] = {0, 0, 0}, b3[3] = {0, 0, 0};
+        double tot = 0;
+        MaxAbs b;
 #pragma unroll 1  // (unrolled, the 7 NW values of a 1024-thread workgroup were all loaded first: 136 spilled dwords)
         for (int i = 0; i < NW; i++) {
             tot += scr[i * 7];
             for (int j = 0; j < 3; j++) {
-                a3[j] = fmax(a3[j], scr[i * 7 + 1 + j]);
-                b3[j] = fmax(b3[j], scr[i * 7 + 4 + j]);
+                const double ov = scr[i * 7 + 1 + j];
+                const unsigned long long ol = (unsigned long long) __double_as_longlong(scr[i * 7 + 4 + j]);
+                if (max_better(ov, ol, b.v[j], b.lin[j])) {
+                    b.v[j]   = ov;
+                    b.lin[j] = ol;
+                }
             }
         }
         const int slot = (blockIdx.x + blockIdx.y * 7) % NSLOT;
         if (NA != 3) atomicAdd(&red->sumsq[slot], tot);
         if (NA >= 2) {
-            for (int j = 0; j < 3; j++) {
-                atomicMax(&red->maxpos[j][slot], dbits(fabs(a3[j])));
-                atomicMax(&red->maxneg[j][slot], dbits(fabs(b3[j])));
-            }
+            for (int j = 0; j < 3; j++) max_commit(red, j, slot, b.v[j], b.lin[j]);
         }
     }
 }
 
+// the same through LDS only, for workgroups that are not a whole number of waves (composite sizes: N/16 threads); lds: 6 doubles
+// per thread.  All threads of the workgroup must call it.
+template <int NT>
+__device__ __forceinline__ void max_reduce_lds(double *lds, Reduce *__restrict__ red, const MaxAbs &m) {
+    __syncthreads();
+    for (int j = 0; j < 3; j++) {
+        lds[threadIdx.x * 6 + j]     = m.v[j];
+        lds[threadIdx.x * 6 + 3 + j] = __longlong_as_double((long long) m.lin[j]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {  // thread j reduces axis j
+        const int j = threadIdx.x;
+        double bv = 0.0;
+        unsigned long long bl = 0ULL;
+        for (int i = 0; i < NT; i++) {
+            const double ov = lds[i * 6 + j];
+            const unsigned long long ol = (unsigned long long) __double_as_longlong(lds[i * 6 + 3 + j]);
+            if (max_better(ov, ol, bv, bl)) {
+                bv = ov;
+                bl = ol;
+            }
+        }
+        max_commit(red, j, (blockIdx.x + blockIdx.y * 7) % NSLOT, bv, bl);
+    }
+}

@@ -1795,17 +1795,15 @@ constexpr int XFFT_SEQ_NH(int N, int NA, int lds_dbl) {
 template <int N, int NA, int ROWS, int NXH, int NT>
 __device__ __forceinline__ void xfft_consume(const EpiConst &ec, const double *__restrict__ fld, int h, int z, long long plane_rec0,
                                              char *__restrict__ records, float *__restrict__ density, double &ssq,
-                                             double (&mp)[3], double (&mn)[3]) {
+                                             MaxAbs32 &mx) {
     for (int i = threadIdx.x; i < ROWS * NXH; i += NT) {
             const int r = i / NXH, xl = i - r * NXH, xx = xl + h * NXH;
             const int yy = blockIdx.x * ROWS + r;
             const double *f = fld + (r * 2 * NA) * NXH + xl;
             auto finish = [&](long long pidx, int zz, const double (&pos)[3], const double (&vel)[3]) {
-#pragma unroll
-                for (int j = 0; j < 3; j++) {
-                    mp[j] = fmax(mp[j], pos[j]);
-                    mn[j] = fmax(mn[j], -pos[j]);
-                }
+                // (rows and x ranges are not visited in index order here: ties by index.  The index tracked is local to the workgroup —
+                // (plane of the pair, row, column) — and made global by k_xfft before the reduction: registers)
+                max_track_any(mx, pos, ((zz != z ? ROWS : 0) + r) * N + xx);
                 if (records) emit_record(records, pidx, ec, zz, yy, xx, pos, vel);
             };
             if constexpr (NA == 3) {
@@ -1886,7 +1884,9 @@ __global__ __launch_bounds__(ROWS *NA *N / E, (ROWS * NA * N / E == 512 ? 4 : 1)
 
     // ---- WriteParticlesSlab (src/output.cpp:86-203) ----
     const int z = z_first + z_step * (int) blockIdx.y;
-    double ssq = 0.0, mp[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
+    double ssq = 0.0;
+    MaxAbs32 mx;  // (column / workgroup-local tags; made lattice indices in front of the reduction)
+    MaxAbs mg;
     const long long plane_rec0 = (long long) blockIdx.y * N * N;
     if constexpr (NA == 3 && !PLT3D) {
         if (ec.pack == PACK_ZAFIELD) {
@@ -1909,18 +1909,19 @@ __global__ __launch_bounds__(ROWS *NA *N / E, (ROWS * NA * N / E == 512 ? 4 : 1)
                     const double2 c = cz[row * N + xx];
                     const double pos[3] = {re[e], im[e], a ? c.y : c.x};
                     const double vel[3] = {pos[0] * ec.vnorm, pos[1] * ec.vnorm, pos[2] * ec.vnorm};
-#pragma unroll
-                    for (int j = 0; j < 3; j++) {
-                        mp[j] = fmax(mp[j], pos[j]);
-                        mn[j] = fmax(mn[j], -pos[j]);
-                    }
+                    max_track(mx, pos, xx);  // (column only; the row's base is added below)
                     if (records)
                         emit_record(records, 2 * plane_rec0 + (long long) a * N * N + (long long) y * N + xx, ec, z + a * ec.z_pair, y, xx,
                                     pos, vel, ZD_NTBIT(S, 128));
                 }
             }
             __syncthreads();
-            xfft_reduce<NT, NA>(lds, red, ssq, mp, mn);
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                mg.v[j]   = mx.v[j];
+                mg.lin[j] = ((unsigned long long) (z + a * ec.z_pair) * N + (unsigned long long) y) * N + (unsigned) mx.tag[j];
+            }
+            xfft_reduce<NT, NA>(lds, red, ssq, mg);
             return;
         }
     }
@@ -1944,16 +1945,23 @@ __global__ __launch_bounds__(ROWS *NA *N / E, (ROWS * NA * N / E == 512 ? 4 : 1)
                     const double2 c0 = st[row * N + xx], c2 = st[(ROWS + row) * N + xx];
                     const double pos[3] = {c0.x, re[e], im[e]};
                     const double vel[3] = {c0.y * ec.vnorm, c2.x * ec.vnorm, c2.y * ec.vnorm};
-#pragma unroll
-                    for (int j = 0; j < 3; j++) {
-                        mp[j] = fmax(mp[j], pos[j]);
-                        mn[j] = fmax(mn[j], -pos[j]);
-                    }
                     if (records) emit_record(records, plane_rec0 + (long long) y * N + xx, ec, z, y, xx, pos, vel);
+                }
+                // (max_disp in a loop of its own: inside the record loop it cost 36 spilled registers at PPD = 8192)
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    const int xx = t2 + T * e;
+                    const double pos[3] = {st[row * N + xx].x, re[e], im[e]};
+                    max_track(mx, pos, xx);  // (column only; the row's base is added below)
                 }
             }
             __syncthreads();
-            xfft_reduce<NT, NA>(lds, red, ssq, mp, mn);
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                mg.v[j]   = mx.v[j];
+                mg.lin[j] = ((unsigned long long) z * N + (unsigned long long) y) * N + (unsigned) mx.tag[j];
+            }
+            xfft_reduce<NT, NA>(lds, red, ssq, mg);
             return;
         }
     }
@@ -1975,9 +1983,15 @@ __global__ __launch_bounds__(ROWS *NA *N / E, (ROWS * NA * N / E == 512 ? 4 : 1)
         __syncthreads();
         // (Writing 32-byte records by lane pairs — 16 B per lane, 1 KB of consecutive bytes per wave — was measured
         // 15 % SLOWER than one lane per record: the extra LDS reads cost more than the store pattern gains.)
-        xfft_consume<N, NA, ROWS, NXH, NT>(ec, fld, h, z, plane_rec0, records, density, ssq, mp, mn);
+        xfft_consume<N, NA, ROWS, NXH, NT>(ec, fld, h, z, plane_rec0, records, density, ssq, mx);
     }
-    xfft_reduce<NT, NA>(lds, red, ssq, mp, mn);
+#pragma unroll
+    for (int j = 0; j < 3; j++) {  // workgroup-local index of xfft_consume -> lattice index
+        const unsigned lt = (unsigned) mx.tag[j], w2 = lt / (unsigned) (ROWS * N), rr = (lt / (unsigned) N) % (unsigned) ROWS, xx = lt % (unsigned) N;
+        mg.v[j]   = mx.v[j];
+        mg.lin[j] = ((unsigned long long) (z + (int) w2 * ec.z_pair) * N + (unsigned long long) (blockIdx.x * ROWS + rr)) * N + xx;
+    }
+    xfft_reduce<NT, NA>(lds, red, ssq, mg);
 }
 
 // k_xfft_seq: the x pass of the field store with ONE row per workgroup: N/E threads transform its three arrays one after the
@@ -2005,7 +2019,7 @@ __global__ __launch_bounds__(N / E, 2) void k_xfft_seq(StoreLayout S, EpiConst e
 #pragma unroll
     for (int e = 0; e < E; e++) cr[e] = 0.0;
     const int z = z_first + z_step * (int) blockIdx.y;
-    double mp[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
+    MaxAbs mx;
     const long long plane_rec0 = 2 * (long long) blockIdx.y * N * N;
 #pragma unroll 1
     for (int it = 0; it < 3; it++) {
@@ -2044,16 +2058,12 @@ __global__ __launch_bounds__(N / E, 2) void k_xfft_seq(StoreLayout S, EpiConst e
             const int xx = t2 + T * e;
             const double pos[3] = {re[e], im[e], a ? czi[xx] : cr[e]};
             const double vel[3] = {pos[0] * ec.vnorm, pos[1] * ec.vnorm, pos[2] * ec.vnorm};
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                mp[j] = fmax(mp[j], pos[j]);
-                mn[j] = fmax(mn[j], -pos[j]);
-            }
+            max_track(mx, pos, ((unsigned long long) (z + a * ec.z_pair) * N + (unsigned long long) y) * N + (unsigned long long) xx);
             if (records) emit_record(records, plane_rec0 + (long long) a * N * N + (long long) y * N + xx, ec, z + a * ec.z_pair, y, xx, pos, vel);
         }
     }
     __syncthreads();
-    xfft_reduce<NT, 3>(lds, red, 0.0, mp, mn);
+    xfft_reduce<NT, 3>(lds, red, 0.0, mx);
 }
 
 // k_xfft_seq_plt: the one-row form for the PLT3 packing qx + i vx | qy + i qz | vy + i vz (ONE plane per store plane): array 0 first
@@ -2080,7 +2090,7 @@ __global__ __launch_bounds__(N / E, 2) void k_xfft_seq_plt(StoreLayout S, EpiCon
 #pragma unroll
     for (int e = 0; e < (SPLIT2 ? E : 1); e++) c2r[e] = 0.0;
     const int z = z_first + z_step * (int) blockIdx.y;
-    double mp[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
+    MaxAbs mx;
     const long long plane_rec0 = (long long) blockIdx.y * N * N;
 #pragma unroll 1
     for (int it = 0; it < 3; it++) {
@@ -2133,16 +2143,12 @@ __global__ __launch_bounds__(N / E, 2) void k_xfft_seq_plt(StoreLayout S, EpiCon
                 c2 = c2s[xx];
             const double pos[3] = {c0r[e], re[e], im[e]};
             const double vel[3] = {c0i[e] * ec.vnorm, c2.x * ec.vnorm, c2.y * ec.vnorm};
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                mp[j] = fmax(mp[j], pos[j]);
-                mn[j] = fmax(mn[j], -pos[j]);
-            }
+            max_track(mx, pos, ((unsigned long long) z * N + (unsigned long long) y) * N + (unsigned long long) xx);
             if (records) emit_record(records, plane_rec0 + (long long) y * N + xx, ec, z, y, xx, pos, vel);
         }
     }
     __syncthreads();
-    xfft_reduce<NT, 3>(lds, red, 0.0, mp, mn);
+    xfft_reduce<NT, 3>(lds, red, 0.0, mx);
 }
 
 // k_xfft_two: the same x pass as two launches of one line per workgroup (PPD = 16384: a line alone takes the 1024 threads
@@ -2188,7 +2194,7 @@ __global__ __launch_bounds__(N / E, (N / E <= 512 ? 4 : 1)) void k_xfft_two(Stor
         return;
     }
     const int z = z_first + z_step * (int) blockIdx.y + (plt ? 0 : a * ec.z_pair);
-    double mp[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
+    MaxAbs32 mx;
     const long long rec0 = plt ? (long long) blockIdx.y * N * N + (long long) y * N
                                : 2 * (long long) blockIdx.y * N * N + (long long) a * N * N + (long long) y * N;
 #pragma unroll
@@ -2204,15 +2210,30 @@ __global__ __launch_bounds__(N / E, (N / E <= 512 ? 4 : 1)) void k_xfft_two(Stor
             pos[0] = re[e]; pos[1] = im[e]; pos[2] = a ? c2.y : c2.x;
             vel[0] = pos[0] * ec.vnorm; vel[1] = pos[1] * ec.vnorm; vel[2] = pos[2] * ec.vnorm;
         }
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            mp[j] = fmax(mp[j], pos[j]);
-            mn[j] = fmax(mn[j], -pos[j]);
-        }
         if (records) emit_record(records, rec0 + xx, ec, z, y, xx, pos, vel);
     }
+    // max_disp in a loop of its own (the displacement component that comes from the other ring row is read again: an L2 hit):
+    // tracked inside the record loop it cost 40 spilled registers in this 128-register kernel
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int xx = t2 + T * e;
+        double pos[3];
+        if constexpr (plt) {
+            pos[0] = row0[xx].x; pos[1] = re[e]; pos[2] = im[e];
+        } else {
+            const cplx c2 = row2[xx];
+            pos[0] = re[e]; pos[1] = im[e]; pos[2] = a ? c2.y : c2.x;
+        }
+        max_track(mx, pos, xx);  // (column only: one row per thread; the row's base is added below)
+    }
     __syncthreads();
-    xfft_reduce<NT, 3>(lds, red, 0.0, mp, mn);
+    MaxAbs mg;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        mg.v[j]   = mx.v[j];
+        mg.lin[j] = ((unsigned long long) z * N + (unsigned long long) y) * N + (unsigned) mx.tag[j];
+    }
+    xfft_reduce<NT, 3>(lds, red, 0.0, mg);
 }
 
 // ------------------------------------------------------------------------------------------------

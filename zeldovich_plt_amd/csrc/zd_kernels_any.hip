@@ -165,7 +165,8 @@ __global__ __launch_bounds__(256) void k_any_emit(AnyLayout A, EpiConst ec, cons
     const int N = A.N;
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, pl = plane0 + blockIdx.z;
     const int z = z_first + z_step * (int) blockIdx.z;
-    double ssq = 0.0, mp[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
+    double ssq = 0.0;
+    MaxAbs mx;
     if (x < N) {
         const cplx *row = store + (((long long) pl * A.narray) * N + y) * A.pitch + x;
         const long long astride = (long long) N * A.pitch;
@@ -183,20 +184,11 @@ __global__ __launch_bounds__(256) void k_any_emit(AnyLayout A, EpiConst ec, cons
                 vel[1] = a3.x * ec.vnorm;
                 vel[2] = a3.y * ec.vnorm;
             }
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                mp[j] = pos[j];
-                mn[j] = -pos[j];
-            }
+            max_track(mx, pos, ((unsigned long long) z * N + (unsigned long long) y) * N + (unsigned long long) x);
             if (records) emit_record(records, pidx, ec, z, y, x, pos, vel);
         }
     }
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-        mp[j] = fmax(mp[j], 0.0);
-        mn[j] = fmax(mn[j], 0.0);
-    }
-    xfft_reduce<256, NA>(scr, red, ssq, mp, mn);
+    xfft_reduce<256, NA>(scr, red, ssq, mx);
 }
 
 // ZD_f_NL, phi round (zeldovich.cpp:699-790): phi(x) = Re of the inverse transform -> (phi + f_NL phi^2) / N^3, real

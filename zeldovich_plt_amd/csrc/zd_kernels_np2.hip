@@ -221,7 +221,7 @@ __global__ __launch_bounds__(3 * Q *P / E) void k_xfft_q3(EpiConst ec, const cpl
     }
     LQ::run(re, im, t, a, n2, lds, twP, twN, twQ);
     const int z = z_first + z_step * (int) blockIdx.y;
-    double mp[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
+    MaxAbs mx;
     const long long plane_rec0 = 2 * (long long) blockIdx.y * N * N;
     double2 *cz = reinterpret_cast<double2 *>(lds);  // [x] = {qz_r0, qz_r1}
     if constexpr (PLT) {
@@ -239,11 +239,7 @@ __global__ __launch_bounds__(3 * Q *P / E) void k_xfft_q3(EpiConst ec, const cpl
                 const double2 c0 = cz[xx], c2 = cz[N + xx];
                 const double pos[3] = {c0.x, re[e], im[e]};
                 const double vel[3] = {c0.y * ec.vnorm, c2.x * ec.vnorm, c2.y * ec.vnorm};
-#pragma unroll
-                for (int j = 0; j < 3; j++) {
-                    mp[j] = fmax(mp[j], pos[j]);
-                    mn[j] = fmax(mn[j], -pos[j]);
-                }
+                max_track(mx, pos, ((unsigned long long) z * N + (unsigned long long) y) * N + (unsigned long long) xx);
                 if (records) emit_record(records, (long long) blockIdx.y * N * N + (long long) y * N + xx, ec, z, y, xx, pos, vel);
             }
         }
@@ -260,30 +256,13 @@ __global__ __launch_bounds__(3 * Q *P / E) void k_xfft_q3(EpiConst ec, const cpl
             const double2 cv = cz[xx];
             const double pos[3] = {re[e], im[e], a ? cv.y : cv.x};
             const double vel[3] = {pos[0] * ec.vnorm, pos[1] * ec.vnorm, pos[2] * ec.vnorm};
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                mp[j] = fmax(mp[j], pos[j]);
-                mn[j] = fmax(mn[j], -pos[j]);
-            }
+            max_track(mx, pos, ((unsigned long long) (z + a * ec.z_pair) * N + (unsigned long long) y) * N + (unsigned long long) xx);
             if (records) emit_record(records, plane_rec0 + (long long) a * N * N + (long long) y * N + xx, ec, z + a * ec.z_pair, y, xx, pos, vel);
         }
     }
     }
-    __syncthreads();
-    for (int j = 0; j < 3; j++) {
-        lds[threadIdx.x * 6 + j]     = mp[j];
-        lds[threadIdx.x * 6 + 3 + j] = mn[j];
-    }
-    __syncthreads();
-    if (threadIdx.x < 6) {  // thread j reduces one of the six quantities
-        double m = 0;
-        for (int i = 0; i < NT; i++) m = fmax(m, lds[i * 6 + threadIdx.x]);
-        const int slot = (blockIdx.x + blockIdx.y * 7) % NSLOT;
-        if (threadIdx.x < 3)
-            atomicMax(&red->maxpos[threadIdx.x][slot], dbits(fabs(m)));
-        else
-            atomicMax(&red->maxneg[threadIdx.x - 3][slot], dbits(fabs(m)));
-    }
+    // workgroup reduction through LDS (the workgroup is N/16 threads per line: not a whole number of waves, so no wave shuffles)
+    max_reduce_lds<NT>(lds, red, mx);
 }
 
 // x stage + epilogue where the three lines of a row do not fit one workgroup (PPD > 5461): one line per workgroup, two
@@ -326,7 +305,7 @@ __global__ __launch_bounds__(Q *P / E, 4) void k_xfft_seq_q(EpiConst ec, const c
         return;
     }
     const int z = z_first + z_step * (int) blockIdx.y + (PLT ? 0 : a * ec.z_pair);
-    double mp[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
+    MaxAbs mx;
     const long long rec0 = PLT ? (long long) blockIdx.y * N * N + (long long) y * N
                                : 2 * (long long) blockIdx.y * N * N + (long long) a * N * N + (long long) y * N;
 #pragma unroll
@@ -342,29 +321,11 @@ __global__ __launch_bounds__(Q *P / E, 4) void k_xfft_seq_q(EpiConst ec, const c
             pos[0] = re[e]; pos[1] = im[e]; pos[2] = a ? c2.y : c2.x;
             vel[0] = pos[0] * ec.vnorm; vel[1] = pos[1] * ec.vnorm; vel[2] = pos[2] * ec.vnorm;
         }
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            mp[j] = fmax(mp[j], pos[j]);
-            mn[j] = fmax(mn[j], -pos[j]);
-        }
+        max_track(mx, pos, ((unsigned long long) z * N + (unsigned long long) y) * N + (unsigned long long) xx);
         if (records) emit_record(records, rec0 + xx, ec, z, y, xx, pos, vel);
     }
-    // workgroup reduction through LDS (the workgroup is N/16 threads: not a whole number of waves, so no wave shuffles)
-    __syncthreads();
-    for (int j = 0; j < 3; j++) {
-        lds[threadIdx.x * 6 + j]     = mp[j];
-        lds[threadIdx.x * 6 + 3 + j] = mn[j];
-    }
-    __syncthreads();
-    if (threadIdx.x < 6) {  // thread j reduces one of the six quantities
-        double m = 0;
-        for (int i = 0; i < NT; i++) m = fmax(m, lds[i * 6 + threadIdx.x]);
-        const int slot = (blockIdx.x + blockIdx.y * 7) % NSLOT;
-        if (threadIdx.x < 3)
-            atomicMax(&red->maxpos[threadIdx.x][slot], dbits(fabs(m)));
-        else
-            atomicMax(&red->maxneg[threadIdx.x - 3][slot], dbits(fabs(m)));
-    }
+    // workgroup reduction through LDS (the workgroup is N/16 threads per line: not a whole number of waves, so no wave shuffles)
+    max_reduce_lds<NT>(lds, red, mx);
 }
 
 // The ZA ring in ONE launch where three lines do not fit a workgroup (the form k_xfft_seq has for PPD = 8192): Q*P/E threads own
@@ -389,7 +350,7 @@ __global__ __launch_bounds__(Q *P / E) void k_xfft_seq1_q(EpiConst ec, const cpl
 #pragma unroll
     for (int e = 0; e < E; e++) cr[e] = 0.0;
     const int z = z_first + z_step * (int) blockIdx.y;
-    double mp[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
+    MaxAbs mx;
     // ONE copy of the transform in a rolled loop over the arrays 2, 0, 1 (three inlined copies spilled 350-760 registers)
 #pragma unroll 1
     for (int it = 0; it < 3; it++) {
@@ -425,30 +386,12 @@ __global__ __launch_bounds__(Q *P / E) void k_xfft_seq1_q(EpiConst ec, const cpl
             const int xx = (t2 + T * e) + P * n2;
             const double pos[3] = {re[e], im[e], a ? czi[xx] : cr[e]};
             const double vel[3] = {pos[0] * ec.vnorm, pos[1] * ec.vnorm, pos[2] * ec.vnorm};
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                mp[j] = fmax(mp[j], pos[j]);
-                mn[j] = fmax(mn[j], -pos[j]);
-            }
+            max_track(mx, pos, ((unsigned long long) (z + a * ec.z_pair) * N + (unsigned long long) y) * N + (unsigned long long) xx);
             if (records) emit_record(records, rec0 + xx, ec, z + a * ec.z_pair, y, xx, pos, vel);
         }
     }
-    // workgroup reduction through LDS (the workgroup is N/16 threads: not a whole number of waves, so no wave shuffles)
-    __syncthreads();
-    for (int j = 0; j < 3; j++) {
-        lds[threadIdx.x * 6 + j]     = mp[j];
-        lds[threadIdx.x * 6 + 3 + j] = mn[j];
-    }
-    __syncthreads();
-    if (threadIdx.x < 6) {  // thread j reduces one of the six quantities
-        double m = 0;
-        for (int i = 0; i < NT; i++) m = fmax(m, lds[i * 6 + threadIdx.x]);
-        const int slot = (blockIdx.x + blockIdx.y * 7) % NSLOT;
-        if (threadIdx.x < 3)
-            atomicMax(&red->maxpos[threadIdx.x][slot], dbits(fabs(m)));
-        else
-            atomicMax(&red->maxneg[threadIdx.x - 3][slot], dbits(fabs(m)));
-    }
+    // workgroup reduction through LDS (the workgroup is N/16 threads per line: not a whole number of waves, so no wave shuffles)
+    max_reduce_lds<NT>(lds, red, mx);
 }
 
 namespace zd {

@@ -1063,8 +1063,14 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
     *out = ctx[0].stats;
     for (int g = 1; g < G; g++) {
         out->density_variance += ctx[g].stats.density_variance;
-        for (int j = 0; j < 3; j++)
-            if (std::abs(ctx[g].stats.max_disp[j]) > std::abs(out->max_disp[j])) out->max_disp[j] = ctx[g].stats.max_disp[j];
+        for (int j = 0; j < 3; j++) {  // largest |v|; on a tie the record met first in (z, y, x) order (output.cpp:190-193)
+            const double a = std::abs(ctx[g].stats.max_disp[j]), b = std::abs(out->max_disp[j]);
+            const int64_t ia = ctx[g].stats.max_disp_index[j], ib = out->max_disp_index[j];
+            if (a > b || (a == b && a > 0 && ia >= 0 && (ib < 0 || ia < ib))) {
+                out->max_disp[j]       = ctx[g].stats.max_disp[j];
+                out->max_disp_index[j] = ia;
+            }
+        }
         for (int k = 0; k < ZD_K_COUNT; k++) {
             out->kernel_ms[k] = std::max(out->kernel_ms[k], ctx[g].stats.kernel_ms[k]);
             out->kernel_launches[k] += ctx[g].stats.kernel_launches[k];
