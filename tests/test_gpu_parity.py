@@ -747,6 +747,27 @@ def test_eight_ranks_equal_one_rank(zd, ps):
     assert np.abs(a["max_disp"] - b["max_disp"]).max() <= 1e-11 * np.abs(a["max_disp"]).max()
 
 
+@pytest.mark.parametrize("n,kw", [
+    (96, dict(stream_factor=2)),                    # 32 * 3
+    (160, dict(stream_factor=2, fmt="RVZel")),      # 32 * 5
+    (288, dict(stream_factor=6)),                   # 32 * 9, three passes
+    (192, dict(stream_factor=4, k_cutoff=2.0)),     # pruned columns
+    (192, dict(stream_factor=2, ngpu=2)),           # two ranks that exchange the six fields
+])
+def test_density_on_composite_grids_vs_oracle(zd, oracle, ps, opk, n, kw):
+    """ZD_qdensity = 1 on the composite grids (round 4): the ZA field store carries the density sums D of the two
+    residues as fields 4, 5 (generator kind GENF_ZAFD), the y stage builds one more array delta_r0 + i delta_r1 and `k_xdens_q`
+    writes the float32 density planes (src/output.cpp:93-101,217-224) — instead of the ~6x slower convolution path.  Records,
+    density planes, max_disp and density_variance against the oracle."""
+    kw = dict(kw)
+    plan = zd.Plan(zd.make_params(n, qdensity=1, **{k: v for k, v in kw.items() if k not in ("fmt", "ngpu")}), ps)
+    assert plan.store_mode == "fields" and plan.plane_step == 2  # the six-field store, not the reference arrays of the convolution path
+    plan.close()
+    got, ref = _compare(zd, oracle, ps, opk, n, qdensity=1, **kw)
+    assert got["density"] is not None and np.abs(ref["density"]).max() > 0
+    assert sorted(got["planes_seen"]) == list(range(n))
+
+
 @pytest.mark.parametrize("n", [24, 72, 216, 48, 144, 432, 96, 288, 864, 192, 576, 1728, 384, 1152, 3456, 768, 2304, 6912,
                                1536, 4608, 3072])
 @pytest.mark.parametrize("kind", [0, 1])

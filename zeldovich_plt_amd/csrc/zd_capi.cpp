@@ -287,10 +287,18 @@ zdpcg::Affine row_jump_full(long long drows) {  // 2*65536*drows draws
 
 extern "C" {
 
+// ZD_qdensity = 1 on the composite grids (PPD = 2^a 3^b 5^c; round 4): the ZA field store carries two more half-space sums — the
+// density D of the two residues of a pass — and the y / x stages add one array, delta_r0 + i delta_r1 (zd_kernels_np2.hip).  The
+// power-of-two grids keep the reference's arrays for ZD_qdensity (their kernels exist); ZD_qdensity = 2 (density only), PLT and
+// f_NL with a density stay on the convolution path for composite PPDs.
+static bool dens_fields(const zd_params *p) {
+    return p->qdensity == 1 && !p->qPLT && p->f_NL == 0. && p->qoneslab < 0 && !is_pow2(p->ppd) && zd::np2_supported_ppd((int) p->ppd)
+           && (p->store_mode == ZD_STORE_AUTO || p->store_mode == ZD_STORE_FIELDS);
+}
 // Packed stores (zd_device.h PACK_*): without ZD_qdensity the density field is not transformed.
 static int pack_mode(const zd_params *p, int R) {
     if (p->store_mode == ZD_STORE_REFERENCE) return zd::PACK_NONE;
-    if (p->qdensity != 0 || p->f_NL != 0.) return zd::PACK_NONE;
+    if ((p->qdensity != 0 && !dens_fields(p)) || p->f_NL != 0.) return zd::PACK_NONE;
     if (p->qoneslab >= 0) return zd::PACK_NONE;  // density_variance is then the sum over that one slab (output.cpp:197)
     {   // The packed stores treat every field as the transform of a REAL field (Hermitian modes) and take
         // density_variance from sum |D|^2.  That needs every mode with a component on the Nyquist plane |k_i| = N/2 to
@@ -381,7 +389,7 @@ static int64_t field_rows(const zd_params *p, int nranks, std::vector<zd::FieldR
 static int64_t store_bytes(const zd_params *p, int R, int nranks) {
     const int64_t N = p->ppd;
     const int pm = pack_mode(p, R);
-    if (zd::pack_is_fields(pm)) return (N / R) * (pm == zd::PACK_PLTFIELD ? 6 : 4) * field_rows(p, nranks, nullptr) * 16;
+    if (zd::pack_is_fields(pm)) return (N / R) * (pm == zd::PACK_PLTFIELD ? 6 : (dens_fields(p) ? 6 : 4)) * field_rows(p, nranks, nullptr) * 16;
     return N * (N + store_row_pad(N)) * (N / R) / nranks * 16 * store_arrays(p, R);
 }
 // ring between the y and x stages of the field store: planes of the three PACK_ZAPAIR arrays
@@ -422,8 +430,8 @@ int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes
         if (N > 4096 && N / R > 2048) continue;  // the field store's z FFT stops at 2048 and PPD > 4096 has no other store worth using
         int64_t store = store_bytes(p, R, nranks);
         if (nranks > 1) store += std::min<int64_t>(store, (int64_t) 9 << 30);  // + the two-slot exchange ring (zd_multi.cpp), not a second store
-        if (zd::pack_is_fields(pack_mode(p, R)))
-            store += (int64_t) field_ring_planes(N, N / R / nranks) * 3 * N * (N + store_row_pad(N)) * 16;
+        if (zd::pack_is_fields(pack_mode(p, R)))  // + the y -> x ring (3 arrays; 4 with the density array)
+            store += (int64_t) field_ring_planes(N, N / R / nranks) * (dens_fields(p) ? 4 : 3) * N * (N + store_row_pad(N)) * 16;
         if (store <= budget_bytes) return R;
     }
     return np2 ? any_factor() : -1;
@@ -691,6 +699,11 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         return 1;
     }
     if (pl->pack != zd::PACK_NONE) pl->narray = 3;
+    pl->dens    = pl->pack == zd::PACK_ZAFIELD && dens_fields(p) && np2;
+    if (pl->pack == zd::PACK_ZAFIELD && dens_fields(p) && !np2) {  // (cannot happen: dens_fields is composite-only)
+        delete pl;
+        return 1;
+    }
     pl->pstep   = (pl->pack == zd::PACK_ZAPAIR || pl->pack == zd::PACK_ZAFIELD) ? 2 : 1;
     pl->npass   = R / pl->pstep;
     pl->R       = R;
@@ -905,6 +918,10 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
             add(zd::JOB_Z, 1, 0, 0);
             add(zd::JOB_E, 2, 0, 1);
             add(zd::JOB_Z, 3, 0, 1);
+            if (pl->dens) {  // ZD_qdensity = 1: the density sums of the two residues
+                add(zd::JOB_DENS, 4, 0, 0);
+                add(zd::JOB_DENS, 5, 0, 1);
+            }
         } else if (pl->pack == zd::PACK_ZAPAIR) {  // (qy + i qz)_r0 | (qy + i qz)_r1 | qx_r0 + i qx_r1
             add(zd::JOB_B_SELF, 0, 0, 0);
             add(zd::JOB_B_TWIN, 0, 1, 0);
@@ -1002,7 +1019,8 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         while ((1 << pl->F.lZq) < pl->Zq) pl->F.lZq++;
         pl->F.Zq          = pl->Zq;
         pl->F.field_elems = fe;
-        pl->F.nfield      = pl->pack == zd::PACK_PLTFIELD ? 6 : 4;
+        pl->F.ndens       = pl->dens ? 2 : 0;
+        pl->F.nfield      = pl->pack == zd::PACK_PLTFIELD ? 6 : 4 + pl->F.ndens;
         pl->F.chunk_elems = (int64_t) pl->Zq * pl->F.nfield * fe;
         pl->F.rows        = pl->d_fieldrows;
         pl->store_bytes_  = pl->F.chunk_elems * nranks * 16;
@@ -1027,6 +1045,8 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         Q.kb_rows    = Q.zb_rows * pl->ring_planes;
         Q.chunk_rows = Q.kb_rows;
         PLCHECK(zd_store_alloc((void **) &pl->d_ring, (size_t) Q.chunk_rows * Q.pitch * 16));
+        if (pl->dens)  // the density array delta_r0 + i delta_r1 of the ring's planes: [plane][y][x]
+            PLCHECK(zd_store_alloc((void **) &pl->d_ring_dens, (size_t) pl->ring_planes * pl->N * Q.pitch * 16));
 
     }
     // columns no row of which survives the zero rule (column_is_zero with ky = 0): never written by the z stage, skipped by the
@@ -1167,6 +1187,7 @@ void zd_plan_destroy(zd_plan *pl) {
     hipFree(pl->d_red);
     hipFree(pl->d_fieldrows);
     hipFree(pl->d_ring);
+    hipFree(pl->d_ring_dens);
     hipFree(pl->d_v1streams);
     hipFree(pl->d_v1dev);
     hipFree(pl->d_v1err);
@@ -1409,7 +1430,7 @@ int zd_plan_stage_x_group(zd_plan *pl, int residue, const void *d_recv, int chun
                 (long long) plane0, (long long) nplanes, ps, (long long) chunk_planes * ps);
         return 1;
     }
-    if (d_density && pl->pack != zd::PACK_NONE) return 1;  // packed stores carry no density field
+    if (d_density && pl->pack != zd::PACK_NONE && !pl->dens) return 1;  // packed stores carry no density field (but the six-field store)
     if (pl->any) {  // x lines of the planes in place (each plane once), then the particle epilogue
         const int z_first = (int) zd_plan_plane_z(pl, residue, gplane0);
         cplx *first = (cplx *) const_cast<void *>(d_recv) + (long long) plane0 * pl->narray * pl->N * pl->AL.pitch;
@@ -1428,13 +1449,19 @@ int zd_plan_stage_x_group(zd_plan *pl, int residue, const void *d_recv, int chun
             char *rec_g = d_records ? (char *) d_records + (size_t) g0 * ps * pl->N * pl->N * pl->ec.recsize : nullptr;
             const int z_first = (int) zd_plan_plane_z(pl, residue, gplane0 + (int64_t) g0 * ps);
             tick(pl, ZD_K_YFFT, st, true);
-            if (pl->d_twq_n ? zd::launch_yfft_fields_np2(F, pl->S, pl->d_twq_n, d_recv, p0 + g0, ng, pl->SR.pitch, pl->d_ring, st)
+            if (pl->d_twq_n ? zd::launch_yfft_fields_np2(F, pl->S, pl->d_twq_n, d_recv, p0 + g0, ng, pl->SR.pitch, pl->d_ring, 0, st)
                             : zd::launch_yfft_fields(F, pl->S, pl->d_twN, d_recv, p0 + g0, ng, pl->SR.pitch, pl->d_ring, st))
+                return 1;
+            if (pl->dens && d_density
+                && zd::launch_yfft_fields_np2(F, pl->S, pl->d_twq_n, d_recv, p0 + g0, ng, pl->SR.pitch, pl->d_ring_dens, 1, st))
                 return 1;
             tick(pl, ZD_K_YFFT, st, false);
             tick(pl, ZD_K_XFFT, st, true);
             if (pl->d_twq_n ? zd::launch_xfft_np2(pl->N, pl->ec, pl->d_twq_n, pl->d_ring, pl->SR.pitch, ng, z_first, pl->R, rec_g, pl->d_red, st)
                             : zd::launch_xfft(pl->SR, pl->ec, pl->d_twN, pl->d_ring, 0, ng, z_first, pl->R, rec_g, nullptr, pl->d_red, st))
+                return 1;
+            if (pl->dens && d_density
+                && zd::launch_xdens_np2(pl->N, pl->d_twq_n, pl->d_ring_dens, pl->SR.pitch, ng, d_density + (size_t) g0 * ps * pl->N * pl->N, st))
                 return 1;
             tick(pl, ZD_K_XFFT, st, false);
         }

@@ -226,7 +226,8 @@ struct FieldRow {  // one record per BLOCK of FIELD_RB rows, 8 bytes: one load p
 struct FieldLayout {
     int lG, lZq;                 // log2(ranks), log2(planes per chunk)
     int Zq;                      // planes per chunk (not a power of two for PPD = 2^a 3^b on several ranks)
-    int nfield;                  // 4 (ZA: E0, Z0, E1, Z1) or 6 (PLT: X, Y, Z, fX, fY, fZ)
+    int nfield;                  // 4 (ZA: E0, Z0, E1, Z1), 6 (PLT: X, Y, Z, fX, fY, fZ), or 6 = ZA + the density sums D0, D1 (ndens = 2)
+    int ndens;                   // 2: fields 4, 5 are the density sums of the two residues (ZD_qdensity = 1 on the composite grids)
     long long chunk_elems;       // elements per chunk = Zq * nfield * field_elems
     long long field_elems;       // elements per (plane, field) image = sum of the row lengths
     const FieldRow *rows;        // [Hq / FIELD_RB] device table

@@ -120,7 +120,7 @@ __device__ __forceinline__ unsigned long long ld_agent(const unsigned long long 
 }
 // one candidate of a workgroup into the replicated global slot: maxabs = bit pattern of |v| (monotone in |v| for v >= 0),
 // maxkey = (linear index << 1) | (v < 0).  Almost every workgroup leaves after two loads (its |v| is below the slot's); a
-// candidate that can improve the slot updates the pair under the slot's lock.
+// candidate that can improve the slot updates the pair under the slot's lock.  Call it from ONE lane of a wave at a time.
 __device__ __forceinline__ void max_commit(Reduce *__restrict__ red, int j, int slot, double v, unsigned long long lin) {
     const unsigned long long myabs = dbits(fabs(v)), mykey = (lin << 1) | (v < 0.0 ? 1ULL : 0ULL);
     if (myabs == 0ULL) return;
@@ -128,7 +128,9 @@ __device__ __forceinline__ void max_commit(Reduce *__restrict__ red, int j, int 
     if (myabs < cur) return;
     // (pair read without the lock: the key of a given magnitude only decreases, and a larger magnitude beats this candidate anyway)
     if (myabs == cur && mykey >= ld_agent(&red->maxkey[j][slot])) return;
-    while (atomicCAS(&red->lock[slot], 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(2);
+    // (bounded: a holder is a running wave a few memory operations from its release, so the bound is never reached; if it ever
+    // were, an unlocked update — possibly torn against a concurrent one — is preferred to a wave that never finishes)
+    for (unsigned spin = 0; atomicCAS(&red->lock[slot], 0u, 1u) != 0u && spin < (1u << 22); spin++) __builtin_amdgcn_s_sleep(2);
     const unsigned long long a = ld_agent(&red->maxabs[j][slot]), k = ld_agent(&red->maxkey[j][slot]);
     if (myabs > a || (myabs == a && mykey < k)) {
         __hip_atomic_store(&red->maxkey[j][slot], mykey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -198,18 +200,22 @@ __device__ __forceinline__ void max_reduce_lds(double *lds, Reduce *__restrict__
         lds[threadIdx.x * 6 + 3 + j] = __longlong_as_double((long long) m.lin[j]);
     }
     __syncthreads();
-    if (threadIdx.x < 3) {  // thread j reduces axis j
-        const int j = threadIdx.x;
-        double bv = 0.0;
-        unsigned long long bl = 0ULL;
-        for (int i = 0; i < NT; i++) {
-            const double ov = lds[i * 6 + j];
-            const unsigned long long ol = (unsigned long long) __double_as_longlong(lds[i * 6 + 3 + j]);
-            if (max_better(ov, ol, bv, bl)) {
-                bv = ov;
-                bl = ol;
+    // ONE lane commits the three axes one after the other: max_commit takes the slot's lock, and two lanes of a wave spinning on a
+    // lock a third lane of the same wave holds never let it reach the release (lanes of a wave reconverge behind the loop)
+    if (threadIdx.x == 0) {
+#pragma unroll 1
+        for (int j = 0; j < 3; j++) {
+            double bv = 0.0;
+            unsigned long long bl = 0ULL;
+            for (int i = 0; i < NT; i++) {
+                const double ov = lds[i * 6 + j];
+                const unsigned long long ol = (unsigned long long) __double_as_longlong(lds[i * 6 + 3 + j]);
+                if (max_better(ov, ol, bv, bl)) {
+                    bv = ov;
+                    bl = ol;
+                }
             }
+            max_commit(red, j, (blockIdx.x + blockIdx.y * 7) % NSLOT, bv, bl);
         }
-        max_commit(red, j, (blockIdx.x + blockIdx.y * 7) % NSLOT, bv, bl);
     }
 }

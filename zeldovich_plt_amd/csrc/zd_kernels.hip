@@ -691,7 +691,8 @@ __device__ __forceinline__ double genf_power(const GenConst &g, const double *T,
 // grid: (ceil(N/GEN_BX), L/ZR, nrows)  block: GEN_BX          row kyl = kyl0 + blockIdx.z of the slab
 enum { GENF_DENS = 0, GENF_ZA = 1, GENF_PLT = 2, GENF_ZAP = 3 /* PACK_ZAPAIR */, GENF_PLTN = 4 /* PACK_PLT3 */,
        GENF_ZAF = 5 /* PACK_ZAFIELD: the sums of GENF_ZAP written out as they are (E, Z of both residues) */,
-       GENF_PLTF = 6 /* PACK_PLTFIELD: the sums of GENF_PLTN written out as they are */ };
+       GENF_PLTF = 6 /* PACK_PLTFIELD: the sums of GENF_PLTN written out as they are */,
+       GENF_ZAFD = 7 /* PACK_ZAFIELD + ZD_qdensity = 1: the four potentials and the density sum D of both residues (six fields) */ };
 
 __device__ __forceinline__ void cmac(double &ar, double &ai, double c, double dr, double di) {
     ar = fma(c, dr, ar);
@@ -1060,15 +1061,15 @@ __device__ __forceinline__ double genf_tile_mirror(const GenConst &g, const GenJ
                                                    int zW, int ky0, int kyl_arg, int kyl_first, int nky, int L, int residue,
                                                    int residue2, int bx, int by, const cplx *__restrict__ twN,
                                                    cplx *__restrict__ Y) {
-    static_assert(KIND == GENF_DENS || KIND == GENF_ZA || KIND == GENF_ZAP || KIND == GENF_ZAF, "ZA kinds only");
-    constexpr bool ZA2 = KIND == GENF_ZAP || KIND == GENF_ZAF;  // two residues per pass
-    constexpr int NACC = KIND == GENF_DENS ? 1 : KIND == GENF_ZA ? 3 : 4;
+    static_assert(KIND == GENF_DENS || KIND == GENF_ZA || KIND == GENF_ZAP || KIND == GENF_ZAF || KIND == GENF_ZAFD, "ZA kinds only");
+    constexpr bool ZA2 = KIND == GENF_ZAP || KIND == GENF_ZAF || KIND == GENF_ZAFD;  // two residues per pass
+    constexpr int NACC = KIND == GENF_DENS ? 1 : KIND == GENF_ZA ? 3 : KIND == GENF_ZAFD ? 6 : 4;
     double vsum = 0.0;
     const int N = g.N, half = g.half, R = N / L;
     // Field store (GENF_ZAF): the folded inputs and the store are laid out in blocks of FIELD_RB = 8 rows x 1 column (one
     // 128-byte line, zd_device.h), so a workgroup takes 8 rows x 32 columns (kyl_arg = the row GROUP) and a lane's 7
     // neighbours hold the other rows of its column; elsewhere a workgroup is one row x GEN_BX columns.
-    constexpr bool BLK = KIND == GENF_ZAF;
+    constexpr bool BLK = KIND == GENF_ZAF || KIND == GENF_ZAFD;
     const int rsub = BLK ? (int) (threadIdx.x & (FIELD_RB - 1)) : 0;
     const int xh   = BLK ? bx * (GEN_BX / FIELD_RB) + (int) (threadIdx.x / FIELD_RB) : bx * GEN_BX + (int) threadIdx.x;  // 0 .. N/2
     const int kyl  = BLK ? kyl_arg * FIELD_RB + rsub : kyl_arg;
@@ -1179,6 +1180,10 @@ __device__ __forceinline__ double genf_tile_mirror(const GenConst &g, const GenJ
                     ar[2 * PAR] += er;
                     ai[2 * PAR] += ei;
                     cmac(ar[2 * PAR + 1], ai[2 * PAR + 1], dkz, er, ei);
+                    if constexpr (KIND == GENF_ZAFD) {  // the density sum: D times the fold twiddle alone; slots [4] De, [5] Do
+                        ar[4 + PAR] += d0r * wr - d0i * wi;
+                        ai[4 + PAR] += d0r * wi + d0i * wr;
+                    }
                 } else {
                     const double dr = d0r * wr - d0i * wi, di = d0r * wi + d0i * wr;
                     ar[0] += dr;
@@ -1202,6 +1207,11 @@ __device__ __forceinline__ double genf_tile_mirror(const GenConst &g, const GenJ
                 a[1] = ze + zo;  // Z(r0)
                 a[2] = ee - eo;  // E(r1)
                 a[3] = ze - zo;  // Z(r1)
+                if constexpr (KIND == GENF_ZAFD) {
+                    const double de = a[4], dd = a[5];
+                    a[4] = de + dd;  // D(r0)
+                    a[5] = de - dd;  // D(r1)
+                }
             };
             combine(aAr);
             combine(aAi);
@@ -1235,12 +1245,16 @@ __device__ __forceinline__ double genf_tile_mirror(const GenConst &g, const GenJ
                 putp(1, ar[0] + xr, ai[0] + xi);       // JOB_A_TWIN
                 putp(2, -ar[2] - yi, -ai[2] + yr);     // JOB_B_SELF
                 putp(3, ar[2] - yi, ai[2] + yr);       // JOB_B_TWIN
-            } else if constexpr (KIND == GENF_ZAF) {
+            } else if constexpr (KIND == GENF_ZAF || KIND == GENF_ZAFD) {
                 auto putq = [&](int j, double vr, double vi) { put(j, vr * qr - vi * qi, vr * qi + vi * qr); };
                 putp(0, ar[0], ai[0]);                 // E(r0)
                 putp(1, ar[1], ai[1]);                 // Z(r0)
                 putq(2, ar[2], ai[2]);                 // E(r1)
                 putq(3, ar[3], ai[3]);                 // Z(r1)
+                if constexpr (KIND == GENF_ZAFD) {
+                    putp(4, ar[4], ai[4]);             // D(r0)
+                    putq(5, ar[5], ai[5]);             // D(r1)
+                }
             } else {
                 auto putq = [&](int j, double vr, double vi) { put(j, vr * qr - vi * qi, vr * qi + vi * qr); };
                 const double y0r = dky * ar[0], y0i = dky * ai[0], y1r = dky * ar[2], y1i = dky * ai[2];
@@ -1272,7 +1286,8 @@ template <int ZR, int KIND, bool PLAW, bool MIRROR>
 // in 0.26 s — so overlapping the two kernels buys nothing there, and at PPD=4096 the capped generator is simply slower.)
 // The ZA kinds are held to 128 registers (three generator workgroups + one 256-thread z-FFT workgroup of 128 registers fill a
 // SIMD's 512 exactly; at 129 the allocation granule of 8 makes it 136 and the z FFT no longer fits beside them).
-__global__ __launch_bounds__(GEN_BX, (KIND == GENF_ZAF || KIND == GENF_ZAP || KIND == GENF_ZA || KIND == GENF_DENS) ? 4 : 1)
+// (GENF_ZAFD — six fields, ZD_qdensity on the composite grids — is left at three workgroups per CU: its two extra pairs of sums do not fit 128)
+__global__ __launch_bounds__(GEN_BX, (KIND == GENF_ZAF || KIND == GENF_ZAP || KIND == GENF_ZA || KIND == GENF_DENS) ? 4 : (KIND == GENF_ZAFD ? 3 : 1))
 void k_genf(GenConst g, GenJumps J, StoreLayout S, int zW, int ky0, int kyl0, int nky,
                                                  int nrows, int L, int residue, int residue2,
                                                  const cplx *__restrict__ twN, cplx *__restrict__ Y,
@@ -1281,7 +1296,7 @@ void k_genf(GenConst g, GenJumps J, StoreLayout S, int zW, int ky0, int kyl0, in
     for (int i = threadIdx.x; i < g.genf_n / 2; i += GEN_BX)
         reinterpret_cast<double2 *>(T)[i] = reinterpret_cast<const double2 *>(g.genf_tab)[i];
     unsigned *slot = reinterpret_cast<unsigned *>(T + g.genf_n);
-    constexpr bool BLK = (MIRROR && KIND == GENF_ZAF) || KIND == GENF_PLTF;  // 8 rows x 32 columns per workgroup
+    constexpr bool BLK = (MIRROR && (KIND == GENF_ZAF || KIND == GENF_ZAFD)) || KIND == GENF_PLTF;  // 8 rows x 32 columns per workgroup
     constexpr int XW = BLK ? GEN_BX / FIELD_RB : GEN_BX;
     const int gx = ((MIRROR ? g.N / 2 + 1 : g.N) + XW - 1) / XW, gy = L / ZR;
     const int gz = BLK ? nky / FIELD_RB : nrows;  // row groups of the whole slab (lanes of rows < kyl0 idle), or rows
@@ -2428,7 +2443,7 @@ static int launch_gen_t(const GenConst &g, const GenJumps &J, const JobList &job
     if (gen_zr(L) == GEN_ZR) return launch_gen_z<GEN_ZR, NJ, PLT, PLAW>(g, J, jobs, S, ky0, nky, nrows, L, residue, residue2, twN, Y, st);
     // the short walks exist for the field stores (their ky = 0 row: 4 ZA jobs, 6 PLT jobs) and for the reference arrays of the
     // any-PPD path (1, 4 or 7 jobs)
-    if constexpr ((NJ == 4 && !PLT) || (NJ == 6 && PLT)) {
+    if constexpr ((NJ == 4 && !PLT) || NJ == 6) {
         if (gen_zr(L) == 4 && pack_is_fields(jobs.pack))
             return launch_gen_z<4, NJ, PLT, PLAW>(g, J, jobs, S, ky0, nky, nrows, L, residue, residue2, twN, Y, st);
     }
@@ -2446,16 +2461,16 @@ static int launch_genf_z(const GenConst &g, const GenJumps &J, const StoreLayout
                          int L, int residue, int residue2, const void *twN, void *Y, unsigned *tile_ctr, int max_wgs,
                          hipStream_t st) {
     const int N = g.N;
-    constexpr bool za = KIND == GENF_DENS || KIND == GENF_ZA || KIND == GENF_ZAP || KIND == GENF_ZAF;
+    constexpr bool za = KIND == GENF_DENS || KIND == GENF_ZA || KIND == GENF_ZAP || KIND == GENF_ZAF || KIND == GENF_ZAFD;
 #ifdef ZD_TUNING
     static const bool mirror_off = getenv("ZD_GEN_NO_MIRROR") != nullptr;
 #else
     constexpr bool mirror_off = false;
 #endif
-    const bool mirror = za && (!mirror_off || KIND == GENF_ZAF);  // the field store's blocked layout exists in the mirror form only
+    const bool mirror = za && (!mirror_off || KIND == GENF_ZAF || KIND == GENF_ZAFD);  // the field store's blocked layout exists in the mirror form only
     // the mirror form folds the second residue of a pass as (-1)^k1 times the first: it must be residue + R/2
-    if (mirror && (KIND == GENF_ZAP || KIND == GENF_ZAF) && residue2 != residue + (N / L) / 2) return 2;
-    const bool blk = (mirror && KIND == GENF_ZAF) || KIND == GENF_PLTF;
+    if (mirror && (KIND == GENF_ZAP || KIND == GENF_ZAF || KIND == GENF_ZAFD) && residue2 != residue + (N / L) / 2) return 2;
+    const bool blk = (mirror && (KIND == GENF_ZAF || KIND == GENF_ZAFD)) || KIND == GENF_PLTF;
     const int xw = blk ? GEN_BX / FIELD_RB : GEN_BX;
     const int gx = ((mirror ? N / 2 + 1 : N) + xw - 1) / xw;
     const long long ntiles = (long long) gx * (L / ZR) * (blk ? nky / FIELD_RB : nrows);
@@ -2464,17 +2479,21 @@ static int launch_genf_z(const GenConst &g, const GenJumps &J, const StoreLayout
     if constexpr (za) {
         if (mirror) {
             hipLaunchKernelGGL((k_genf<ZR, KIND, PLAW, true>), grid, block, shmem, st, g, J, S,
-                               KIND == GENF_ZAF ? zfft_fields_tile_columns(L) : zfft_tile_width(L), ky0, kyl0,
+                               (KIND == GENF_ZAF || KIND == GENF_ZAFD) ? zfft_fields_tile_columns(L) : zfft_tile_width(L), ky0, kyl0,
                                nky, nrows, L, residue, residue2, (const cplx *) twN, (cplx *) Y, tile_ctr);
             ZD_LAUNCH_CHECK();
             return 0;
         }
     }
-    hipLaunchKernelGGL((k_genf<ZR, KIND, PLAW, false>), grid, block, shmem, st, g, J, S,
-                       KIND == GENF_PLTF ? zfft_fields_tile_columns(L) : zfft_tile_width(L), ky0, kyl0, nky,
-                       nrows, L, residue, residue2, (const cplx *) twN, (cplx *) Y, tile_ctr);
-    ZD_LAUNCH_CHECK();
-    return 0;
+    if constexpr (KIND == GENF_ZAFD) {
+        return 2;  // (mirror form only)
+    } else {
+        hipLaunchKernelGGL((k_genf<ZR, KIND, PLAW, false>), grid, block, shmem, st, g, J, S,
+                           KIND == GENF_PLTF ? zfft_fields_tile_columns(L) : zfft_tile_width(L), ky0, kyl0, nky,
+                           nrows, L, residue, residue2, (const cplx *) twN, (cplx *) Y, tile_ctr);
+        ZD_LAUNCH_CHECK();
+        return 0;
+    }
 }
 template <int KIND, bool PLAW>
 static int launch_genf_t(const GenConst &g, const GenJumps &J, const StoreLayout &S, int ky0, int kyl0, int nky, int nrows,
@@ -2482,7 +2501,7 @@ static int launch_genf_t(const GenConst &g, const GenJumps &J, const StoreLayout
                          hipStream_t st) {
     if (gen_zr(L) == GEN_ZR)
         return launch_genf_z<GEN_ZR, KIND, PLAW>(g, J, S, ky0, kyl0, nky, nrows, L, residue, residue2, twN, Y, tile_ctr, max_wgs, st);
-    if constexpr (KIND == GENF_ZAF || KIND == GENF_PLTF) {  // the short walk of the field stores (z lines of 108)
+    if constexpr (KIND == GENF_ZAF || KIND == GENF_PLTF || KIND == GENF_ZAFD) {  // the short walk of the field stores (z lines of 108)
         if (gen_zr(L) == 4)
             return launch_genf_z<4, KIND, PLAW>(g, J, S, ky0, kyl0, nky, nrows, L, residue, residue2, twN, Y, tile_ctr, max_wgs, st);
     }
@@ -2509,6 +2528,7 @@ static int genf_kind(const JobList &jobs, bool plt) {
     static const int pln[6]  = {JOB_XV_SELF, JOB_XV_TWIN, JOB_B_SELF, JOB_B_TWIN, JOB_D_SELF, JOB_D_TWIN};
     static const int zaf[4]  = {JOB_E, JOB_Z, JOB_E, JOB_Z};
     static const int plf[6]  = {JOB_PX, JOB_PY, JOB_PZ, JOB_PFX, JOB_PFY, JOB_PFZ};
+    static const int zafd[6] = {JOB_E, JOB_Z, JOB_E, JOB_Z, JOB_DENS, JOB_DENS};
     auto same = [&](const int *ref, int n) {
         if (jobs.n != n) return false;
         for (int j = 0; j < n; j++)
@@ -2517,7 +2537,7 @@ static int genf_kind(const JobList &jobs, bool plt) {
     };
     if (jobs.n == 1 && jobs.kind[0] == JOB_DENS) return GENF_DENS;
     if (jobs.pack == PACK_ZAPAIR) return (!plt && same(zap, 6)) ? GENF_ZAP : -1;
-    if (jobs.pack == PACK_ZAFIELD) return (!plt && same(zaf, 4)) ? GENF_ZAF : -1;
+    if (jobs.pack == PACK_ZAFIELD) return (!plt && same(zaf, 4)) ? GENF_ZAF : ((!plt && same(zafd, 6)) ? GENF_ZAFD : -1);
     if (jobs.pack == PACK_PLTFIELD) return (plt && same(plf, 6)) ? GENF_PLTF : -1;
     if (jobs.pack == PACK_PLT3) return (plt && same(pln, 6)) ? GENF_PLTN : -1;
     if (!plt && same(std7, 4)) return GENF_ZA;
@@ -2536,7 +2556,7 @@ int launch_gen(const GenConst &g, const GenJumps &J, const JobList &jobs, const 
     const int kind = genf_kind(jobs, g.qPLT != 0);
     const int zr = gen_zr(L);
     const bool ref_kind = kind == GENF_DENS || kind == GENF_ZA || kind == GENF_PLT;
-    const bool zr_ok = zr == GEN_ZR || (zr == 4 && (kind == GENF_ZAF || kind == GENF_PLTF || ref_kind)) || (zr == 2 && ref_kind);
+    const bool zr_ok = zr == GEN_ZR || (zr == 4 && (kind == GENF_ZAF || kind == GENF_ZAFD || kind == GENF_PLTF || ref_kind)) || (zr == 2 && ref_kind);
     const bool fast = g.genf_tab && tile_ctr && !g.phik && !g.gen_phi && !g.qonemode && !g.v1dev && !ZD_TUNE(g.ablate & 15) && !force_general
                       && kind >= 0 && zr_ok;
     int general_rows = nky;
@@ -2554,6 +2574,7 @@ int launch_gen(const GenConst &g, const GenJumps &J, const JobList &jobs, const 
             FCASE(GENF_PLTN)
             FCASE(GENF_ZAF)
             FCASE(GENF_PLTF)
+            FCASE(GENF_ZAFD)
 #undef FCASE
             if (rc) return rc;
         }

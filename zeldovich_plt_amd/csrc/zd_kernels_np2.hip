@@ -117,7 +117,7 @@ template <int P, int E, int Q, int W>
 __global__ __launch_bounds__(W *Q *P / E) void k_yfft_fq(FieldLayout F, StoreLayout S, const cplx *__restrict__ twP,
                                                         const cplx *__restrict__ twN, const cplx *__restrict__ twQ,
                                                         const cplx *__restrict__ store, int plane0, int ring_pitch,
-                                                        cplx *__restrict__ ring) {
+                                                        cplx *__restrict__ ring, int dens) {
     constexpr int N = P * Q, NT = N / W;
     using LQ = zdfft::LineQ<P, E, Q, W, false>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -126,14 +126,21 @@ __global__ __launch_bounds__(W *Q *P / E) void k_yfft_fq(FieldLayout F, StoreLay
     const int w = c % W, n2 = c / W;
     int tile, a;
     ytile_of<NT, W>((int) blockIdx.x, tile, a);  // XCD-aware order (zd_device.h)
+    // dens (ZD_qdensity = 1, six-field store): a launch of its own over the NT column tiles builds the density array
+    //   delta_r0 + i delta_r1 = D_0 + i D_1   (rows y > N/2: conj D_0 + i conj D_1 — D is Hermitian like E)
+    // from the fields 4, 5 into `ring` = the density ring [plane][y][x]
+    if (dens) {
+        tile = (int) blockIdx.x;
+        a    = 0;
+    }
     const int x = tile * W + w, xm = x ? N - x : 0;
     const int zl = plane0 + blockIdx.z;
     const int kx = x > N / 2 ? x - N : x;
     if ((S.prune & PRUNE_YTILE) && __syncthreads_and(column_is_zero(S, kx, 0))) return;  // a tile without a live row: see k_yfft_f
     // ZA: E_a alone (a < 2) or (Z_0, Z_1); PLT: the pairs (X, fX), (Y, Z), (fY, fZ) of the six sums — see k_yfft_f
-    const bool plt = F.nfield == 6, two = plt || a == 2;
-    const int f0 = plt ? (a == 0 ? 0 : (a == 1 ? 1 : 4)) : (a == 2 ? 1 : 2 * a);
-    const int f1 = plt ? (a == 0 ? 3 : (a == 1 ? 2 : 5)) : 3;
+    const bool plt = F.nfield == 6 && !F.ndens, two = plt || a == 2 || dens;
+    const int f0 = dens ? 4 : (plt ? (a == 0 ? 0 : (a == 1 ? 1 : 4)) : (a == 2 ? 1 : 2 * a));
+    const int f1 = dens ? 5 : (plt ? (a == 0 ? 3 : (a == 1 ? 2 : 5)) : 3);
     const cplx *p0 = store + (long long) (zl * F.nfield + f0) * F.field_elems;
     const long long d01 = two ? (long long) (f1 - f0) * F.field_elems : 0;
     double re[E], im[E];
@@ -171,7 +178,10 @@ __global__ __launch_bounds__(W *Q *P / E) void k_yfft_fq(FieldLayout F, StoreLay
             const bool mir = y > N / 2;
             const double s = mir ? -1.0 : 1.0;
             double vr, vi;
-            if (two) {
+            if (dens) {
+                vr = u[j].x - s * v[j].y;
+                vi = s * u[j].y + v[j].x;
+            } else if (two) {
                 vr = -u[j].y - s * v[j].x;
                 vi = s * u[j].x - v[j].y;
             } else {
@@ -184,7 +194,7 @@ __global__ __launch_bounds__(W *Q *P / E) void k_yfft_fq(FieldLayout F, StoreLay
         }
     }
     LQ::run(re, im, t, w, n2, lds, twP, twN, twQ);
-    cplx *base = ring + ((long long) ((int) blockIdx.z * 3 + a) * N) * ring_pitch + x;
+    cplx *base = ring + ((long long) (dens ? (int) blockIdx.z : (int) blockIdx.z * 3 + a) * N) * ring_pitch + x;
 #pragma unroll
     for (int e = 0; e < E; e++) {
         const int y = (t + T * e) + P * n2;
@@ -394,7 +404,51 @@ __global__ __launch_bounds__(Q *P / E) void k_xfft_seq1_q(EpiConst ec, const cpl
     max_reduce_lds<NT>(lds, red, mx);
 }
 
+// x stage of the density array (ZD_qdensity = 1 on the six-field store): one row of delta_r0 + i delta_r1 per workgroup -> the
+// float32 density planes of the two residues (WriteParticlesSlab's dens_out, src/output.cpp:93-101,217-224).  density_variance
+// comes from the generator (sum |D|^2), as for every packed store.
+//   grid: (N, planes)   block: Q*P/E       density: [2 * planes][N][N] in delivery order (r0 plane, r1 plane per store plane)
+template <int P, int E, int Q>
+__global__ __launch_bounds__(Q *P / E) void k_xdens_q(const cplx *__restrict__ twP, const cplx *__restrict__ twN, const cplx *__restrict__ twQ,
+                                                    const cplx *__restrict__ dring, int ring_pitch, float *__restrict__ density) {
+    constexpr int N = P * Q;
+    using LQ = zdfft::LineQ<P, E, Q, 1, true>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int T = LQ::T;
+    const int t = threadIdx.x % T, n2 = threadIdx.x / T;
+    const int y = blockIdx.x, pl = blockIdx.y;
+    const cplx *src = dring + ((long long) pl * N + y) * ring_pitch;
+    double re[E], im[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const cplx v = src[Q * (t + T * e) + n2];
+        re[e] = v.x;
+        im[e] = v.y;
+    }
+    LQ::run(re, im, t, 0, n2, lds, twP, twN, twQ);
+    float *d0 = density + (2 * (long long) pl * N + y) * N, *d1 = d0 + (long long) N * N;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int xx = (t + T * e) + P * n2;
+        d0[xx] = (float) re[e];
+        d1[xx] = (float) im[e];
+    }
+}
+
 namespace zd {
+
+template <int P, int E, int Q>
+static int launch_xdens_q_t(const cplx *tw, const void *dring, int ring_pitch, int nplanes, float *density, hipStream_t st) {
+    constexpr int N = P * Q, threads = Q * P / E;
+    using LQ = zdfft::LineQ<P, E, Q, 1, true>;
+    const size_t shmem = sizeof(double) * (size_t) LQ::LDS_DOUBLES;
+    if (shmem > 160 * 1024) return 2;
+    set_dyn_lds<k_xdens_q<P, E, Q>>(shmem);
+    hipLaunchKernelGGL((k_xdens_q<P, E, Q>), dim3(N, nplanes), dim3(threads), shmem, st, tw, tw + P, tw + P + N, (const cplx *) dring, ring_pitch,
+                       density);
+    ZD_LAUNCH_CHECK();
+    return 0;
+}
 
 // ---- launchers of the field-store pipeline ----
 template <int P, int E, int Q, int NC>
@@ -449,15 +503,15 @@ int zfft_fields_np2_columns(int L) {
 
 template <int P, int E, int Q, int W>
 static int launch_yfft_fq_t(const FieldLayout &F, const StoreLayout &S, const cplx *tw, const void *store, int plane0, int nplanes,
-                            int ring_pitch, void *ring, hipStream_t st) {
+                            int ring_pitch, void *ring, int dens, hipStream_t st) {
     constexpr int threads = W * Q * P / E, N = P * Q;
     static_assert(threads <= 1024, "workgroup too large");
     const size_t shmem = sizeof(double) * zdfft::LineQ<P, E, Q, W, false>::LDS_DOUBLES;
     if (shmem > 160 * 1024) return 2;
     set_dyn_lds<k_yfft_fq<P, E, Q, W>>(shmem);
-    dim3 grid(3 * (N / W), 1, nplanes), block(threads);
+    dim3 grid((dens ? 1 : 3) * (N / W), 1, nplanes), block(threads);
     hipLaunchKernelGGL((k_yfft_fq<P, E, Q, W>), grid, block, shmem, st, F, S, tw, tw + P, tw + P + N, (const cplx *) store, plane0,
-                       ring_pitch, (cplx *) ring);
+                       ring_pitch, (cplx *) ring, dens);
     ZD_LAUNCH_CHECK();
     return 0;
 }
@@ -522,9 +576,9 @@ static int launch_xfft_q_t(const EpiConst &ec, const cplx *tw, const void *ring,
     X(32, 75, 4) X(64, 75, 2)                                                                                              \
     X(32, 125, 4) X(64, 125, 2)
 int launch_yfft_fields_np2(const FieldLayout &F, const StoreLayout &S, const void *tw, const void *store, int plane0, int nplanes,
-                           int ring_pitch, void *ring, hipStream_t st) {
+                           int ring_pitch, void *ring, int dens, hipStream_t st) {
 #define YC(p, q, w) \
-    if (S.N == (p) * (q)) return launch_yfft_fq_t<p, 16, q, w>(F, S, (const cplx *) tw, store, plane0, nplanes, ring_pitch, ring, st);
+    if (S.N == (p) * (q)) return launch_yfft_fq_t<p, 16, q, w>(F, S, (const cplx *) tw, store, plane0, nplanes, ring_pitch, ring, dens, st);
     NP2_SIZES(YC)
 #undef YC
     fprintf(stderr, "zeldovich_hip: PPD %d is not among the supported 2^a 3^b sizes\n", S.N);
@@ -540,6 +594,14 @@ int launch_xfft_np2(int N, const EpiConst &ec, const void *tw, const void *ring,
     NP2_SIZES(XC)
 #undef XC
     fprintf(stderr, "zeldovich_hip: PPD %d is not among the supported 2^a 3^b sizes\n", N);
+    return 2;
+}
+// density planes of `nplanes` store planes from the density ring (k_xdens_q)
+int launch_xdens_np2(int N, const void *tw, const void *dring, int ring_pitch, int nplanes, float *density, hipStream_t st) {
+#define DC(p, q, w) \
+    if (N == (p) * (q)) return launch_xdens_q_t<p, 16, q>((const cplx *) tw, dring, ring_pitch, nplanes, density, st);
+    NP2_SIZES(DC)
+#undef DC
     return 2;
 }
 bool np2_supported_ppd(int N) {

@@ -90,7 +90,8 @@ int zfft_fields_np2_columns(int L);
 int launch_zfft_fields_np2(int L, const FieldLayout &F, const StoreLayout &S, int ky0, int kyloc0, int nky, const void *Y,
                            const void *tw, void *out, hipStream_t st);
 int launch_yfft_fields_np2(const FieldLayout &F, const StoreLayout &S, const void *tw, const void *store, int plane0, int nplanes,
-                           int ring_pitch, void *ring, hipStream_t st);
+                           int ring_pitch, void *ring, int dens, hipStream_t st);
+int launch_xdens_np2(int N, const void *tw, const void *dring, int ring_pitch, int nplanes, float *density, hipStream_t st);
 int launch_xfft_np2(int N, const EpiConst &ec, const void *tw, const void *ring, int ring_pitch, int nplanes, int z_first, int z_step,
                     void *records, Reduce *red, hipStream_t st);
 int launch_test_fftq(int n, int kind, const void *twP, const void *twN, const void *twQ, const void *in, void *out, long long lines,
