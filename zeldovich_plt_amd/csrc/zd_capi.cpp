@@ -825,6 +825,16 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         pl->J.fwd_full[1]  = row_jump_full(Lr + wrap);
         pl->J.back_full[0] = row_jump_full(back);
         pl->J.back_full[1] = row_jump_full(back > 0 ? back + wrap : back - wrap);
+        // the mirrored walker of genf_tile_kz: the same moves negated (crossing z = N/2 in its own direction of motion)
+        const long long mf = -Lr, mb = -back;
+        pl->J.mfwd[0]       = row_jump(mf);
+        pl->J.mfwd[1]       = row_jump(mf - wrap);
+        pl->J.mback[0]      = row_jump(mb);
+        pl->J.mback[1]      = row_jump(mb > 0 ? mb + wrap : mb - wrap);
+        pl->J.mfwd_full[0]  = row_jump_full(mf);
+        pl->J.mfwd_full[1]  = row_jump_full(mf - wrap);
+        pl->J.mback_full[0] = row_jump_full(mb);
+        pl->J.mback_full[1] = row_jump_full(mb > 0 ? mb + wrap : mb - wrap);
     }
     {
         std::vector<cplx> twN = make_twiddles(pl->N), twL = make_twiddles(pl->L);

@@ -84,7 +84,18 @@ struct GenJumps {
     // the same moves for a mode whose draws are not needed (k_genf, all 64 modes of a wave zeroed):
     // 2*65536*drows draws in one map
     zdpcg::Affine fwd_full[2], back_full[2];
+    // the mirrored walk of genf_tile_kz (PLT kinds: a thread also owns the lines L - k2, visited z' = N - z): every move negated —
+    // z' -> z' - L inside a fold, z' -> z' + (R-1)L - 1 to the next line — with the same wrap variants and full-stride forms
+    zdpcg::Affine mfwd[2], mback[2], mfwd_full[2], mback_full[2];
 };
+
+// genf_tile_kz (PLT kinds, kz mirror folded in): the lines k2 = 0 .. L/2 of the lower half in chunks of ZR; a lone last line
+// (L/2 a multiple of ZR) is taken by the chunk before it.  0: no pairing (odd L)
+ZD_HD int kz_chunks(int L, int ZR) {
+    if (L % 2 || L < 4) return 0;
+    const int lines = L / 2 + 1;
+    return lines % ZR == 1 && lines > 1 ? lines / ZR : (lines + ZR - 1) / ZR;
+}
 
 // Addressing of the z-transformed block store ("BlockArray", include/block_array.h:26-35, re-laid
 // out for the GPU).  Rows are grouped by the rank that generated them: rank g holds half-space rows

@@ -190,8 +190,9 @@ __device__ __forceinline__ void xfft_reduce(double *lds, Reduce *__restrict__ re
     }
 }
 
-// the same through LDS only, for workgroups that are not a whole number of waves (composite sizes: N/16 threads); lds: 6 doubles
-// per thread.  All threads of the workgroup must call it.
+// the same through LDS only, for workgroups that are not a whole number of waves (composite sizes: N/16 threads per line); lds: 6
+// doubles per thread.  A tree over the threads (log2 NT steps; a single thread scanning all NT entries cost the x stage of PPD=3456
+// 60 % when this reduction was first written that way), then ONE lane commits the three axes.  All threads must call it.
 template <int NT>
 __device__ __forceinline__ void max_reduce_lds(double *lds, Reduce *__restrict__ red, const MaxAbs &m) {
     __syncthreads();
@@ -199,23 +200,29 @@ __device__ __forceinline__ void max_reduce_lds(double *lds, Reduce *__restrict__
         lds[threadIdx.x * 6 + j]     = m.v[j];
         lds[threadIdx.x * 6 + 3 + j] = __longlong_as_double((long long) m.lin[j]);
     }
-    __syncthreads();
+    constexpr int TOP = NT <= 1 ? 1 : 1 << (32 - __builtin_clz((unsigned) (NT - 1)));  // smallest power of two >= NT
+#pragma unroll 1
+    for (int stride = TOP / 2; stride >= 1; stride >>= 1) {
+        __syncthreads();
+        const int o = (int) threadIdx.x + stride;
+        if ((int) threadIdx.x < stride && o < NT) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const double ov = lds[o * 6 + j], cv = lds[threadIdx.x * 6 + j];
+                const unsigned long long ol = (unsigned long long) __double_as_longlong(lds[o * 6 + 3 + j]);
+                const unsigned long long cl = (unsigned long long) __double_as_longlong(lds[threadIdx.x * 6 + 3 + j]);
+                if (max_better(ov, ol, cv, cl)) {
+                    lds[threadIdx.x * 6 + j]     = ov;
+                    lds[threadIdx.x * 6 + 3 + j] = __longlong_as_double((long long) ol);
+                }
+            }
+        }
+    }
     // ONE lane commits the three axes one after the other: max_commit takes the slot's lock, and two lanes of a wave spinning on a
     // lock a third lane of the same wave holds never let it reach the release (lanes of a wave reconverge behind the loop)
     if (threadIdx.x == 0) {
 #pragma unroll 1
-        for (int j = 0; j < 3; j++) {
-            double bv = 0.0;
-            unsigned long long bl = 0ULL;
-            for (int i = 0; i < NT; i++) {
-                const double ov = lds[i * 6 + j];
-                const unsigned long long ol = (unsigned long long) __double_as_longlong(lds[i * 6 + 3 + j]);
-                if (max_better(ov, ol, bv, bl)) {
-                    bv = ov;
-                    bl = ol;
-                }
-            }
-            max_commit(red, j, (blockIdx.x + blockIdx.y * 7) % NSLOT, bv, bl);
-        }
+        for (int j = 0; j < 3; j++)
+            max_commit(red, j, (blockIdx.x + blockIdx.y * 7) % NSLOT, lds[j], (unsigned long long) __double_as_longlong(lds[3 + j]));
     }
 }

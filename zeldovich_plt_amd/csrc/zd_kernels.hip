@@ -1052,6 +1052,168 @@ __device__ __forceinline__ double genf_tile(const GenConst &g, const GenJumps &J
     return vsum;
 }
 
+// genf_tile for the PLT kinds with the kz mirror folded in (round 4).  The modes (kx, ky, kz) and (kx, ky, -kz) of one column share
+// |k|^2 — hence the zero rule, P(k) and 1/k^2 — AND the eigenmode: the table holds the +kz half space, e(-kz) = (e_x, e_y, -e_z),
+// lambda the same (src/zeldovich.cpp:239-247), so k.e, the normalisation, f and the rescale factor are the same numbers: more than
+// half of a PLT mode's ~350 instructions.  Only the draws, Box-Muller and the sums stay separate.  In the folded index
+// z = k2 + L k1 the mirror of (k2, k1) is (L - k2, R - 1 - k1): a thread owns ZR lines k2 of the LOWER half [0, L/2] and their
+// mirror lines L - k2, with a second RNG walker that runs the mirrored order (every move of the first walker negated).  The lines
+// k2 = 0 and k2 = L/2 are their own mirrors (z -> N - z stays on the line): they are walked unpaired.
+//   tiles: (x block, kz_chunks(L, ZR) chunks of the lower half, row)
+template <int ZR, int KIND, bool PLAW>
+__device__ __forceinline__ double genf_tile_kz(const GenConst &g, const GenJumps &J, const StoreLayout &S, const double *T, int zW,
+                                               int ky0, int kyl_arg, int kyl_first, int nky, int L, int residue, int bx, int by,
+                                               const cplx *__restrict__ twN, cplx *__restrict__ Y) {
+    static_assert(KIND == GENF_PLTN || KIND == GENF_PLTF, "PLT kinds of the packed / field stores");
+    constexpr bool BLK = KIND == GENF_PLTF;
+    double vsum = 0.0;
+    const int N = g.N, half = g.half, R = N / L;
+    const int rsub = BLK ? (int) (threadIdx.x & (FIELD_RB - 1)) : 0;
+    const int x    = BLK ? bx * (GEN_BX / FIELD_RB) + (int) (threadIdx.x / FIELD_RB) : bx * GEN_BX + (int) threadIdx.x;
+    const int kyl  = BLK ? kyl_arg * FIELD_RB + rsub : kyl_arg;
+    const int k20 = by * ZR;
+    const int ky  = ky0 + kyl * S.ky_stride;  // >= 1
+    if (x >= N || kyl < kyl_first) return 0.0;
+    const int kx = x > half ? x - N : x;
+    if (S.prune & 1) {  // see genf_tile
+        bool all_zero = true;
+        const int xt0 = x - x % zW;
+        if constexpr (BLK) {
+            for (int i = 0; i < zW; i++)
+                for (int r = 0; r < FIELD_RB; r++)
+                    all_zero = all_zero && column_is_zero(S, (xt0 + i) > half ? xt0 + i - N : xt0 + i,
+                                                          ky0 + (kyl_arg * FIELD_RB + r) * S.ky_stride);
+        } else {
+            for (int i = -1; i <= zW; i++) {
+                const int xi = modn(N, xt0 + i + N);
+                all_zero = all_zero && column_is_zero(S, xi > half ? xi - N : xi, ky);
+            }
+        }
+        if (all_zero) return 0.0;
+    }
+    const int kxy2  = kx * kx + ky * ky;
+    const bool dead = (kx < 0 ? -kx : kx) == g.kmax || ky == g.kmax;  // zeldovich.cpp:350
+    EigXY exy = {};
+    if (!g.eig_lines) exy = eig_xy(g, eig_axis(g, eig_index_x(g, kx)), eig_axis(g, ky));
+    const uint64_t offx = (uint64_t) (kx & 65535);
+    // walker A at (k2 = k20, k1 = 0): z = k20 <= L/2 <= N/2; walker B at the mirror of the first PAIRED line (k2 = max(k20, 1),
+    // k1 = 0), z' = N - k2, kz' = -k2; both one step ahead of their mode's counter
+    u128 sA = advance_bits(g.row_state[ky], 2ULL * ((uint64_t) (k20 & 65535) * 65536ULL + offx) + 1ULL);
+    u128 sB = advance_bits(g.row_state[ky], 2ULL * ((uint64_t) ((-(k20 > 0 ? k20 : 1)) & 65535) * 65536ULL + offx) + 1ULL);
+    const int nz = by == kz_chunks(L, ZR) - 1 ? L / 2 + 1 - k20 : ZR;  // the last chunk ends with the self-mirrored line k2 = L/2
+#pragma unroll 1
+    for (int zi = 0; zi < nz; zi++) {
+        const int k2 = k20 + zi, k2m = L - k2;
+        const bool pair = k2 != 0 && 2 * k2 != L;  // (tile-uniform)
+        double aAr[6], aAi[6], aBr[6], aBi[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) aAr[j] = aAi[j] = aBr[j] = aBi[j] = 0.0;
+#pragma unroll 1
+        for (int k1 = 0; k1 < R; k1++) {
+            const int z  = k2 + L * k1, zm = N - z;  // zm: the mirror position (paired lines: 0 < z < N, z != N/2)
+            const int kz = z > half ? z - N : z;
+            const int k2i = kxy2 + kz * kz;
+            const bool live = !dead && (kz < 0 ? -kz : kz) != g.kmax && (g.corner_modes || k2i < g.k2i_cut);
+            const bool last = k1 + 1 >= R;
+            const int zn = last ? k2 + 1 : z + L, zmn = N - zn;  // next positions of the two walkers
+            const int selA = (z > half) != (zn > half), selB = (zm > half) != (zmn > half);
+            const bool any = __any(live);
+            zdpcg::Affine mA, mB;
+            if (!last) {
+                mA = any ? J.fwd[selA] : J.fwd_full[selA];
+                mB = any ? J.mfwd[selB] : J.mfwd_full[selB];
+            } else {
+                mA = any ? J.back[selA] : J.back_full[selA];
+                mB = any ? J.mback[selB] : J.mback_full[selB];
+            }
+            if (!any) {  // all 64 columns zeroed at this |kz|: only the walks move on
+                sA = zdpcg::apply(mA, sA);
+                if (pair) sB = zdpcg::apply(mB, sB);
+                continue;
+            }
+            const uint64_t r1A = zdpcg::output(sA);
+            const u128 tA      = zdpcg::step(sA);
+            const uint64_t r2A = zdpcg::output(tA);
+            sA = zdpcg::apply(mA, tA);
+            uint64_t r1B = 0, r2B = 0;
+            if (pair) {
+                r1B = zdpcg::output(sB);
+                const u128 tB = zdpcg::step(sB);
+                r2B = zdpcg::output(tB);
+                sB  = zdpcg::apply(mB, tB);
+            }
+            // ---- shared by the two modes: P(k), 1/k^2, the eigenmode (its z component changes sign), f, rescale ----
+            const double k2v = (double) k2i * g.fundamental2;
+            const double P   = genf_power<PLAW>(g, T, k2v);
+            const double ik2 = frcp(k2v);
+            double e[4];
+            if (g.eig_lines)  // (uniform) the slab's (x, y)-interpolated lines
+                eigenmode_lines(g, kx, ky, kz, kyl, x, eig_axis(g, eig_index_z(g, kz)), e);
+            else
+                eigenmode_fast(g, kx, ky, kz, exy, eig_axis(g, eig_index_z(g, kz)), e);
+            const double f = (sqrt_pos(1. + 24 * e[3] * g.f_cluster) - 1) * .25;
+            double rescale = 1.0;
+            if (g.qPLTrescale) rescale = fexp(g.ln_growth_ratio * (g.target_f - f), T);
+            const double sx = rescale * e[0] * g.fundamental * ik2;
+            const double sy = rescale * e[1] * g.fundamental * ik2;
+            const double sz = rescale * e[2] * g.fundamental * ik2;
+            auto one = [&](uint64_t r1, uint64_t r2, int kf, double szs, double (&ar)[6], double (&ai)[6]) {
+                // cgauss<2> (power_spectrum.cpp:338-359); zeroed lanes of a live wave ride along with amplitude 0
+                const uint64_t m1 = r1 + 1ULL;
+                double v = P;
+                if (!g.fixed_power) v = -P * flog(u64_to_double(m1), 64, T);
+                v = (m1 == 0 && !g.fixed_power) || !live ? 0.0 : v;
+                const double amp = sqrt_pos(v);
+                double sn, cs;
+                sincos_u01(u64_to_double(r2 + 1ULL), T, sn, cs);
+                double dr = amp * cs, di = amp * sn;
+                vsum = fma(dr, dr, fma(di, di, vsum));
+                if (R > 1) {  // W_R^{kf r}: kf = the mode's own fold index
+                    const cplx w = twN[modn(N, kf * residue * L)];
+                    const double a = dr * w.x - di * w.y, b = dr * w.y + di * w.x;
+                    dr = a;
+                    di = b;
+                }
+                cmac(ar[0], ai[0], sx, dr, di);
+                cmac(ar[1], ai[1], sy, dr, di);
+                cmac(ar[2], ai[2], szs, dr, di);
+                cmac(ar[3], ai[3], f * sx, dr, di);
+                cmac(ar[4], ai[4], f * sy, dr, di);
+                cmac(ar[5], ai[5], f * szs, dr, di);
+            };
+            one(r1A, r2A, k1, sz, aAr, aAi);
+            if (pair) one(r1B, r2B, R - 1 - k1, -sz, aBr, aBi);
+        }
+        // ---- outputs of line k2 (and of its mirror line k2m) from the six sums, times W_N^{line r} ----
+        auto emit = [&](int line, const double (&ar)[6], const double (&ai)[6]) {
+            double pr = 1.0, pi = 0.0;
+            if (R > 1) {
+                const cplx w = twN[modn(N, line * residue)];
+                pr = w.x;
+                pi = w.y;
+            }
+            auto putp = [&](int j, double vr, double vi) {
+                const unsigned idx = BLK ? y_index_blocked(j, kyl, nky, L, line, N, x) : (unsigned) (((j * nky + kyl) * L + line) * N + x);
+                Y[idx] = cplx{vr * pr - vi * pi, vr * pi + vi * pr};
+            };
+            if constexpr (KIND == GENF_PLTF) {
+#pragma unroll
+                for (int j = 0; j < 6; j++) putp(j, ar[j], ai[j]);  // X, Y, Z, fX, fY, fZ
+            } else {
+                putp(0, -ai[0] - ar[3], ar[0] - ai[3]);   // JOB_XV_SELF (i - f) s_x D = i X - fX
+                putp(1, -ai[0] + ar[3], ar[0] + ai[3]);   // JOB_XV_TWIN (i + f) s_x D = i X + fX
+                putp(2, -ar[2] - ai[1], -ai[2] + ar[1]);  // JOB_B_SELF  -Z + i Y
+                putp(3, ar[2] - ai[1], ai[2] + ar[1]);    // JOB_B_TWIN   Z + i Y
+                putp(4, -ar[5] - ai[4], -ai[5] + ar[4]);  // JOB_D_SELF  -fZ + i fY
+                putp(5, ar[5] - ai[4], ai[5] + ar[4]);    // JOB_D_TWIN   fZ + i fY
+            }
+        };
+        emit(k2, aAr, aAi);
+        if (pair) emit(k2m, aBr, aBi);
+    }
+    return vsum;
+}
+
 // genf_tile for the ZA kinds with the x mirror folded in: a thread owns the columns kx = +xh and kx = -xh (x = xh
 // and N - xh).  The two modes of a (ky, kz) share |k|^2, hence the zero rule, P(k) and 1/k^2 — a quarter of the
 // arithmetic of a mode; the two RNG walks, Box-Muller draws and field sums stay separate.  (The PLT kinds keep
@@ -1287,6 +1449,9 @@ template <int ZR, int KIND, bool PLAW, bool MIRROR>
 // The ZA kinds are held to 128 registers (three generator workgroups + one 256-thread z-FFT workgroup of 128 registers fill a
 // SIMD's 512 exactly; at 129 the allocation granule of 8 makes it 136 and the z FFT no longer fits beside them).
 // (GENF_ZAFD — six fields, ZD_qdensity on the composite grids — is left at three workgroups per CU: its two extra pairs of sums do not fit 128)
+// (PLT kinds, MIRROR = the kz-paired form genf_tile_kz: 201-209 registers, two workgroups per CU + the z FFT beside them.  Held to 168
+// — three workgroups per CU, 46 spilled dwords — the generator alone is faster, 4.36 s against 4.72 s per step at PPD=4096 PLT, but
+// then no z-FFT workgroup fits a CU beside three of them and the Z stage takes 5.45 s against 4.97 s: profiles/r04_tuning_notes.md)
 __global__ __launch_bounds__(GEN_BX, (KIND == GENF_ZAF || KIND == GENF_ZAP || KIND == GENF_ZA || KIND == GENF_DENS) ? 4 : (KIND == GENF_ZAFD ? 3 : 1))
 void k_genf(GenConst g, GenJumps J, StoreLayout S, int zW, int ky0, int kyl0, int nky,
                                                  int nrows, int L, int residue, int residue2,
@@ -1296,9 +1461,13 @@ void k_genf(GenConst g, GenJumps J, StoreLayout S, int zW, int ky0, int kyl0, in
     for (int i = threadIdx.x; i < g.genf_n / 2; i += GEN_BX)
         reinterpret_cast<double2 *>(T)[i] = reinterpret_cast<const double2 *>(g.genf_tab)[i];
     unsigned *slot = reinterpret_cast<unsigned *>(T + g.genf_n);
-    constexpr bool BLK = (MIRROR && (KIND == GENF_ZAF || KIND == GENF_ZAFD)) || KIND == GENF_PLTF;  // 8 rows x 32 columns per workgroup
+    // PLT kinds of the packed / field stores: MIRROR selects the kz-paired form (genf_tile_kz), a kernel of its own so that the
+    // unpaired one keeps its 148 registers (three workgroups per CU)
+    constexpr bool KZ = MIRROR && (KIND == GENF_PLTN || KIND == GENF_PLTF);
+    constexpr bool XMIR = MIRROR && !KZ;  // ZA kinds: the x mirror (genf_tile_mirror)
+    constexpr bool BLK = (XMIR && (KIND == GENF_ZAF || KIND == GENF_ZAFD)) || KIND == GENF_PLTF;  // 8 rows x 32 columns per workgroup
     constexpr int XW = BLK ? GEN_BX / FIELD_RB : GEN_BX;
-    const int gx = ((MIRROR ? g.N / 2 + 1 : g.N) + XW - 1) / XW, gy = L / ZR;
+    const int gx = ((XMIR ? g.N / 2 + 1 : g.N) + XW - 1) / XW, gy = KZ ? kz_chunks(L, ZR) : L / ZR;
     const int gz = BLK ? nky / FIELD_RB : nrows;  // row groups of the whole slab (lanes of rows < kyl0 idle), or rows
     const unsigned ntiles = (unsigned) (gx * gy * gz);
     double vsum = 0.0;
@@ -1309,7 +1478,9 @@ void k_genf(GenConst g, GenJumps J, StoreLayout S, int zW, int ky0, int kyl0, in
         const unsigned tile = *slot;
         if (tile >= ntiles) break;
         const int bx = tile % gx, by = (tile / gx) % gy, bz = tile / (gx * gy);
-        if constexpr (MIRROR)
+        if constexpr (KZ)
+            vsum += genf_tile_kz<ZR, KIND, PLAW>(g, J, S, T, zW, ky0, BLK ? bz : kyl0 + bz, kyl0, nky, L, residue, bx, by, twN, Y);
+        else if constexpr (MIRROR)
             vsum += genf_tile_mirror<ZR, KIND, PLAW>(g, J, S, T, zW, ky0, BLK ? bz : kyl0 + bz, kyl0, nky, L, residue, residue2, bx, by,
                                                      twN, Y);
         else
@@ -2456,6 +2627,15 @@ static int launch_gen_t(const GenConst &g, const GenJumps &J, const JobList &job
     }
     return 2;
 }
+// (tuning library: ZD_GEN_NO_KZPAIR=1 keeps the unpaired PLT generator for A/B timings)
+static bool kz_pair_off() {
+#ifdef ZD_TUNING
+    static const bool off = getenv("ZD_GEN_NO_KZPAIR") != nullptr;
+    return off;
+#else
+    return false;
+#endif
+}
 template <int ZR, int KIND, bool PLAW>
 static int launch_genf_z(const GenConst &g, const GenJumps &J, const StoreLayout &S, int ky0, int kyl0, int nky, int nrows,
                          int L, int residue, int residue2, const void *twN, void *Y, unsigned *tile_ctr, int max_wgs,
@@ -2473,7 +2653,11 @@ static int launch_genf_z(const GenConst &g, const GenJumps &J, const StoreLayout
     const bool blk = (mirror && (KIND == GENF_ZAF || KIND == GENF_ZAFD)) || KIND == GENF_PLTF;
     const int xw = blk ? GEN_BX / FIELD_RB : GEN_BX;
     const int gx = ((mirror ? N / 2 + 1 : N) + xw - 1) / xw;
-    const long long ntiles = (long long) gx * (L / ZR) * (blk ? nky / FIELD_RB : nrows);
+    // PLT kinds: the kz mirror folded in (genf_tile_kz, k_genf<.., true>) where the generator paces the Z stage — more than two
+    // passes.  At R <= 2 (PPD = 2048 PLT, BASELINE C3) the stage is bound by HBM bytes and the unpaired kernel, three workgroups per
+    // CU, is the faster one (Z stage 241 against 250 ms)
+    const int kzpair = (!mirror && (KIND == GENF_PLTN || KIND == GENF_PLTF) && kz_chunks(L, ZR) > 0 && N / L > 2 && !kz_pair_off()) ? 1 : 0;
+    const long long ntiles = (long long) gx * (kzpair ? kz_chunks(L, ZR) : L / ZR) * (blk ? nky / FIELD_RB : nrows);
     dim3 grid((unsigned) std::min<long long>(ntiles, max_wgs)), block(GEN_BX);
     const size_t shmem = sizeof(double) * (size_t) (g.genf_n + 2);
     if constexpr (za) {
@@ -2481,6 +2665,15 @@ static int launch_genf_z(const GenConst &g, const GenJumps &J, const StoreLayout
             hipLaunchKernelGGL((k_genf<ZR, KIND, PLAW, true>), grid, block, shmem, st, g, J, S,
                                (KIND == GENF_ZAF || KIND == GENF_ZAFD) ? zfft_fields_tile_columns(L) : zfft_tile_width(L), ky0, kyl0,
                                nky, nrows, L, residue, residue2, (const cplx *) twN, (cplx *) Y, tile_ctr);
+            ZD_LAUNCH_CHECK();
+            return 0;
+        }
+    }
+    if constexpr (KIND == GENF_PLTN || KIND == GENF_PLTF) {
+        if (kzpair) {
+            hipLaunchKernelGGL((k_genf<ZR, KIND, PLAW, true>), grid, block, shmem, st, g, J, S,
+                               KIND == GENF_PLTF ? zfft_fields_tile_columns(L) : zfft_tile_width(L), ky0, kyl0, nky,
+                               nrows, L, residue, residue2, (const cplx *) twN, (cplx *) Y, tile_ctr);
             ZD_LAUNCH_CHECK();
             return 0;
         }
