@@ -3,6 +3,8 @@
 Tolerances (BASELINE.json north_star): displacements / velocities <= 1e-10 relative to the field's
 maximum (double precision); integer record fields exact; raw RNG draws bit-exact.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -389,6 +391,8 @@ def test_parseval_oversampling_property(zd, ps):
     assert abs(b["density_variance"] / a["density_variance"] - 8.0) < 1e-12
 
 
+@pytest.mark.skipif(not os.environ.get("ZD_RUN_SLOW"), reason="16 s; superseded by test_oversampled_planes_exact_at_full_size[2048] (records of "
+                    "three planes, exact) and the direct sums of test_gpu_direct_sum.py: run with ZD_RUN_SLOW=1")
 def test_full_size_properties_ppd4096_vs_2048(zd, ps):
     """BASELINE sizes through size-independent properties (no oracle run is feasible at 6.9e10 particles):
     PPD=4096 with k_cutoff=2 is phase-matched to PPD=2048 (README :52-54 of the reference) -> exactly 8x the sum of

@@ -9,6 +9,7 @@
 //              (src/output.cpp:86-203)
 // HBM-bound design notes are in DESIGN.md; LDS/register structure of the FFT in zd_fft.h.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdio.h>
 #include <algorithm>
@@ -1108,6 +1109,10 @@ __device__ __forceinline__ double genf_tile_kz(const GenConst &g, const GenJumps
         double aAr[6], aAi[6], aBr[6], aBi[6];
 #pragma unroll
         for (int j = 0; j < 6; j++) aAr[j] = aAi[j] = aBr[j] = aBi[j] = 0.0;
+        // the fold terms of the line; PAIR (compile time) = the mirror line rides along.  Two copies of the loop so that the paired
+        // one has no branch between the two modes' Box-Muller chains: the scheduler interleaves them (two waves per SIMD only)
+        auto fold = [&](auto pair_c) {
+            constexpr bool PAIR = decltype(pair_c)::value;
 #pragma unroll 1
         for (int k1 = 0; k1 < R; k1++) {
             const int z  = k2 + L * k1, zm = N - z;  // zm: the mirror position (paired lines: 0 < z < N, z != N/2)
@@ -1128,7 +1133,7 @@ __device__ __forceinline__ double genf_tile_kz(const GenConst &g, const GenJumps
             }
             if (!any) {  // all 64 columns zeroed at this |kz|: only the walks move on
                 sA = zdpcg::apply(mA, sA);
-                if (pair) sB = zdpcg::apply(mB, sB);
+                if constexpr (PAIR) sB = zdpcg::apply(mB, sB);
                 continue;
             }
             const uint64_t r1A = zdpcg::output(sA);
@@ -1136,7 +1141,7 @@ __device__ __forceinline__ double genf_tile_kz(const GenConst &g, const GenJumps
             const uint64_t r2A = zdpcg::output(tA);
             sA = zdpcg::apply(mA, tA);
             uint64_t r1B = 0, r2B = 0;
-            if (pair) {
+            if constexpr (PAIR) {
                 r1B = zdpcg::output(sB);
                 const u128 tB = zdpcg::step(sB);
                 r2B = zdpcg::output(tB);
@@ -1182,8 +1187,13 @@ __device__ __forceinline__ double genf_tile_kz(const GenConst &g, const GenJumps
                 cmac(ar[5], ai[5], f * szs, dr, di);
             };
             one(r1A, r2A, k1, sz, aAr, aAi);
-            if (pair) one(r1B, r2B, R - 1 - k1, -sz, aBr, aBi);
+            if constexpr (PAIR) one(r1B, r2B, R - 1 - k1, -sz, aBr, aBi);
         }
+        };
+        if (pair)
+            fold(std::true_type{});
+        else
+            fold(std::false_type{});
         // ---- outputs of line k2 (and of its mirror line k2m) from the six sums, times W_N^{line r} ----
         auto emit = [&](int line, const double (&ar)[6], const double (&ai)[6]) {
             double pr = 1.0, pi = 0.0;
