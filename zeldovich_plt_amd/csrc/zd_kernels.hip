@@ -2387,12 +2387,56 @@ __global__ __launch_bounds__(N / E, (N / E <= 512 ? 4 : 1)) void k_xfft_two(Stor
     if (!emit) {
 #pragma unroll
         for (int e = 0; e < E; e++) self[t2 + T * e] = cplx{re[e], im[e]};
+        // max_disp of the displacement component(s) this launch holds in registers (launch 1 reads them back from the ring row and
+        // tracks only its own two: tracking inside its record loop cost 40 spilled registers): PLT array 0 = qx + i vx -> axis 0;
+        // ZA array 2 = qz_r0 + i qz_r1 -> axis 2 of the two planes of the pair
+        if (!plt || a == 0) {
+            MaxAbs32 m0, m1;
+            constexpr int J = plt ? 0 : 2;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const int xx = t2 + T * e;
+                const bool g0 = fabs(re[e]) > fabs(m0.v[J]);
+                m0.v[J]   = g0 ? re[e] : m0.v[J];
+                m0.tag[J] = g0 ? xx : m0.tag[J];
+                if constexpr (!plt) {
+                    const bool g1 = fabs(im[e]) > fabs(m1.v[J]);
+                    m1.v[J]   = g1 ? im[e] : m1.v[J];
+                    m1.tag[J] = g1 ? xx : m1.tag[J];
+                }
+            }
+            const int z0 = z_first + z_step * (int) blockIdx.y;
+            MaxAbs mg;
+            mg.v[J]   = m0.v[J];
+            mg.lin[J] = ((unsigned long long) z0 * N + (unsigned long long) y) * N + (unsigned) m0.tag[J];
+            if constexpr (!plt) {  // the plane of the second residue: z0 + z_pair (later in z: it only wins with a larger magnitude)
+                const unsigned long long l1 = ((unsigned long long) (z0 + ec.z_pair) * N + (unsigned long long) y) * N + (unsigned) m1.tag[J];
+                if (max_better(m1.v[J], l1, mg.v[J], mg.lin[J])) {
+                    mg.v[J]   = m1.v[J];
+                    mg.lin[J] = l1;
+                }
+            }
+            __syncthreads();
+            xfft_reduce<NT, 3>(lds, red, 0.0, mg);
+        }
         return;
     }
     const int z = z_first + z_step * (int) blockIdx.y + (plt ? 0 : a * ec.z_pair);
     MaxAbs32 mx;
     const long long rec0 = plt ? (long long) blockIdx.y * N * N + (long long) y * N
                                : 2 * (long long) blockIdx.y * N * N + (long long) a * N * N + (long long) y * N;
+    // max_disp: the two components this thread holds in registers, in a loop of their own in front of the records (registers only; the
+    // third component was tracked by launch 0, which held it in registers)
+    constexpr int JA = plt ? 1 : 0, JB = plt ? 2 : 1;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int xx = t2 + T * e;
+        const bool ga = fabs(re[e]) > fabs(mx.v[JA]), gb = fabs(im[e]) > fabs(mx.v[JB]);
+        mx.v[JA]   = ga ? re[e] : mx.v[JA];
+        mx.tag[JA] = ga ? xx : mx.tag[JA];
+        mx.v[JB]   = gb ? im[e] : mx.v[JB];
+        mx.tag[JB] = gb ? xx : mx.tag[JB];
+    }
 #pragma unroll
     for (int e = 0; e < E; e++) {
         const int xx = t2 + T * e;
@@ -2407,20 +2451,6 @@ __global__ __launch_bounds__(N / E, (N / E <= 512 ? 4 : 1)) void k_xfft_two(Stor
             vel[0] = pos[0] * ec.vnorm; vel[1] = pos[1] * ec.vnorm; vel[2] = pos[2] * ec.vnorm;
         }
         if (records) emit_record(records, rec0 + xx, ec, z, y, xx, pos, vel);
-    }
-    // max_disp in a loop of its own (the displacement component that comes from the other ring row is read again: an L2 hit):
-    // tracked inside the record loop it cost 40 spilled registers in this 128-register kernel
-#pragma unroll
-    for (int e = 0; e < E; e++) {
-        const int xx = t2 + T * e;
-        double pos[3];
-        if constexpr (plt) {
-            pos[0] = row0[xx].x; pos[1] = re[e]; pos[2] = im[e];
-        } else {
-            const cplx c2 = row2[xx];
-            pos[0] = re[e]; pos[1] = im[e]; pos[2] = a ? c2.y : c2.x;
-        }
-        max_track(mx, pos, xx);  // (column only: one row per thread; the row's base is added below)
     }
     __syncthreads();
     MaxAbs mg;

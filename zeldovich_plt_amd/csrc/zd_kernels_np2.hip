@@ -312,12 +312,60 @@ __global__ __launch_bounds__(Q *P / E, 4) void k_xfft_seq_q(EpiConst ec, const c
     if (!emit) {
 #pragma unroll
         for (int e = 0; e < E; e++) src[(t + T * e) + P * n2] = cplx{re[e], im[e]};
+        // max_disp of the displacement component(s) this launch holds in registers (see k_xfft_two): PLT array 0 = qx + i vx ->
+        // axis 0; ZA array 2 = qz_r0 + i qz_r1 -> axis 2 of the two planes of the pair
+        if (!PLT || a == 0) {
+            constexpr int J = PLT ? 0 : 2;
+            double v0 = 0.0, v1 = 0.0;
+            int t0 = 0, t1 = 0;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const int xx = (t + T * e) + P * n2;
+                const bool g0 = fabs(re[e]) > fabs(v0);
+                v0 = g0 ? re[e] : v0;
+                t0 = g0 ? xx : t0;
+                if constexpr (!PLT) {
+                    const bool g1 = fabs(im[e]) > fabs(v1);
+                    v1 = g1 ? im[e] : v1;
+                    t1 = g1 ? xx : t1;
+                }
+            }
+            const int z0 = z_first + z_step * (int) blockIdx.y;
+            MaxAbs mg;
+            mg.v[J]   = v0;
+            mg.lin[J] = ((unsigned long long) z0 * N + (unsigned long long) y) * N + (unsigned) t0;
+            if constexpr (!PLT) {
+                const unsigned long long l1 = ((unsigned long long) (z0 + ec.z_pair) * N + (unsigned long long) y) * N + (unsigned) t1;
+                if (max_better(v1, l1, mg.v[J], mg.lin[J])) {
+                    mg.v[J]   = v1;
+                    mg.lin[J] = l1;
+                }
+            }
+            max_reduce_lds<NT>(lds, red, mg);
+        }
         return;
     }
     const int z = z_first + z_step * (int) blockIdx.y + (PLT ? 0 : a * ec.z_pair);
     MaxAbs mx;
     const long long rec0 = PLT ? (long long) blockIdx.y * N * N + (long long) y * N
                                : 2 * (long long) blockIdx.y * N * N + (long long) a * N * N + (long long) y * N;
+    // max_disp: the two components held in registers, in a loop of their own in front of the records (the third one: launch 0)
+    {
+        constexpr int JA = PLT ? 1 : 0, JB = PLT ? 2 : 1;
+        const unsigned long long rowbase = ((unsigned long long) z * N + (unsigned long long) y) * N;
+        int ta = 0, tb = 0;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int xx = (t + T * e) + P * n2;
+            const bool ga = fabs(re[e]) > fabs(mx.v[JA]), gb = fabs(im[e]) > fabs(mx.v[JB]);
+            mx.v[JA] = ga ? re[e] : mx.v[JA];
+            ta       = ga ? xx : ta;
+            mx.v[JB] = gb ? im[e] : mx.v[JB];
+            tb       = gb ? xx : tb;
+        }
+        mx.lin[JA] = rowbase + (unsigned) ta;
+        mx.lin[JB] = rowbase + (unsigned) tb;
+    }
 #pragma unroll
     for (int e = 0; e < E; e++) {
         const int xx = (t + T * e) + P * n2;
@@ -331,7 +379,6 @@ __global__ __launch_bounds__(Q *P / E, 4) void k_xfft_seq_q(EpiConst ec, const c
             pos[0] = re[e]; pos[1] = im[e]; pos[2] = a ? c2.y : c2.x;
             vel[0] = pos[0] * ec.vnorm; vel[1] = pos[1] * ec.vnorm; vel[2] = pos[2] * ec.vnorm;
         }
-        max_track(mx, pos, ((unsigned long long) z * N + (unsigned long long) y) * N + (unsigned long long) xx);
         if (records) emit_record(records, rec0 + xx, ec, z, y, xx, pos, vel);
     }
     // workgroup reduction through LDS (the workgroup is N/16 threads per line: not a whole number of waves, so no wave shuffles)
