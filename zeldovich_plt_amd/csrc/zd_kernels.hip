@@ -794,6 +794,64 @@ __global__ __launch_bounds__(256) void k_eig_lines(GenConst g, int ky0, int ky_s
     out[i + 1] = double2{e2, e3};
 }
 
+// the two (x, y)-interpolated entries a mode blends along z, as loaded (genf_tile_kz requests the NEXT fold term's entries before it
+// works on the current one: at two waves per SIMD a PLT generator otherwise waits for these loads in every iteration)
+struct EigRaw {
+    double2 a0, a1, b0, b1;
+    double wl, wh;
+};
+__device__ __forceinline__ EigRaw eig_lines_load(const GenConst &g, int kz, int row, int x) {
+    const EigAxis az = eig_axis(g, eig_index_z(g, kz));
+    const double2 *V = reinterpret_cast<const double2 *>(g.eig_lines);
+    EigRaw r;
+    r.wl = 1 - az.f;
+    r.wh = az.f;
+    r.a0 = r.a1 = r.b0 = r.b1 = double2{0.0, 0.0};
+    if (r.wl != 0) {
+        const size_t il = (((size_t) az.l * g.eig_rows + row) * g.N + x) * 2;
+        r.a0 = V[il];
+        r.a1 = V[il + 1];
+    }
+    if (r.wh != 0) {  // wave-uniform: kz is
+        const size_t ih = (((size_t) az.h * g.eig_rows + row) * g.N + x) * 2;
+        r.b0 = V[ih];
+        r.b1 = V[ih + 1];
+    }
+    return r;
+}
+// eigenmode_lines from loaded entries (same arithmetic, same order)
+__device__ __forceinline__ void eig_lines_finish(int kx, int ky, int kz, const EigRaw &r, double (&out)[4]) {
+    double eh[4] = {0.0, 0.0, 0.0, 0.0};
+    if (r.wl != 0) {
+        eh[0] = r.wl * r.a0.x;
+        eh[1] = r.wl * r.a0.y;
+        eh[2] = r.wl * r.a1.x;
+        eh[3] = r.wl * r.a1.y;
+    }
+    if (r.wh != 0) {
+        eh[0] += r.wh * r.b0.x;
+        eh[1] += r.wh * r.b0.y;
+        eh[2] += r.wh * r.b1.x;
+        eh[3] += r.wh * r.b1.y;
+    }
+    eh[2] *= (kz < 0 ? -1.0 : 1.0);
+    const double n2 = eh[0] * eh[0] + eh[1] * eh[1] + eh[2] * eh[2];
+    double rr = trans_rsq(n2);
+    rr = rr * fma(-0.5 * n2, rr * rr, 1.5);
+    rr = rr * fma(-0.5 * n2, rr * rr, 1.5);
+    eh[0] *= rr;
+    eh[1] *= rr;
+    eh[2] *= rr;
+    const double k2  = (double) (kx * kx + ky * ky + kz * kz);
+    const double dot = kx * eh[0] + ky * eh[1] + kz * eh[2];
+    double norm = k2 * frcp(dot);
+    if (k2 == 0.0 || !isfinite(norm)) norm = 0.0;
+    out[0] = norm * eh[0];
+    out[1] = norm * eh[1];
+    out[2] = norm * eh[2];
+    out[3] = eh[3];
+}
+
 // eigenmode_fast from the slab's (x, y)-interpolated lines (k_eig_lines); `row` = row of the slab
 __device__ __forceinline__ void eigenmode_lines(const GenConst &g, int kx, int ky, int kz, int row, int x, const EigAxis &az, double (&out)[4]) {
     const double2 *V = reinterpret_cast<const double2 *>(g.eig_lines);
@@ -1113,10 +1171,17 @@ __device__ __forceinline__ double genf_tile_kz(const GenConst &g, const GenJumps
         // one has no branch between the two modes' Box-Muller chains: the scheduler interleaves them (two waves per SIMD only)
         auto fold = [&](auto pair_c) {
             constexpr bool PAIR = decltype(pair_c)::value;
+        EigRaw enext = {};
+        if (g.eig_lines) enext = eig_lines_load(g, k2 > half ? k2 - N : k2, kyl, x);  // the entries of the first fold term
 #pragma unroll 1
         for (int k1 = 0; k1 < R; k1++) {
             const int z  = k2 + L * k1, zm = N - z;  // zm: the mirror position (paired lines: 0 < z < N, z != N/2)
             const int kz = z > half ? z - N : z;
+            const EigRaw ecur = enext;
+            if (g.eig_lines && k1 + 1 < R) {  // request the next fold term's entries now: they arrive while this mode is computed
+                const int zq = z + L;
+                enext = eig_lines_load(g, zq > half ? zq - N : zq, kyl, x);
+            }
             const int k2i = kxy2 + kz * kz;
             const bool live = !dead && (kz < 0 ? -kz : kz) != g.kmax && (g.corner_modes || k2i < g.k2i_cut);
             const bool last = k1 + 1 >= R;
@@ -1152,8 +1217,8 @@ __device__ __forceinline__ double genf_tile_kz(const GenConst &g, const GenJumps
             const double P   = genf_power<PLAW>(g, T, k2v);
             const double ik2 = frcp(k2v);
             double e[4];
-            if (g.eig_lines)  // (uniform) the slab's (x, y)-interpolated lines
-                eigenmode_lines(g, kx, ky, kz, kyl, x, eig_axis(g, eig_index_z(g, kz)), e);
+            if (g.eig_lines)  // (uniform) the slab's (x, y)-interpolated lines, requested one fold term ahead
+                eig_lines_finish(kx, ky, kz, ecur, e);
             else
                 eigenmode_fast(g, kx, ky, kz, exy, eig_axis(g, eig_index_z(g, kz)), e);
             const double f = (sqrt_pos(1. + 24 * e[3] * g.f_cluster) - 1) * .25;
