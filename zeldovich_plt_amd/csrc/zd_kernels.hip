@@ -1172,15 +1172,18 @@ __device__ __forceinline__ double genf_tile_kz(const GenConst &g, const GenJumps
         auto fold = [&](auto pair_c) {
             constexpr bool PAIR = decltype(pair_c)::value;
         EigRaw enext = {};
-        if (g.eig_lines) enext = eig_lines_load(g, k2 > half ? k2 - N : k2, kyl, x);  // the entries of the first fold term
+        if (g.eig_lines) enext = eig_lines_load(g, k2 > half ? k2 - N : k2, kyl, x);  // the entries of the first fold term (k2 <= L/2)
 #pragma unroll 1
         for (int k1 = 0; k1 < R; k1++) {
             const int z  = k2 + L * k1, zm = N - z;  // zm: the mirror position (paired lines: 0 < z < N, z != N/2)
             const int kz = z > half ? z - N : z;
             const EigRaw ecur = enext;
             if (g.eig_lines && k1 + 1 < R) {  // request the next fold term's entries now: they arrive while this mode is computed
-                const int zq = z + L;
-                enext = eig_lines_load(g, zq > half ? zq - N : zq, kyl, x);
+                const int zq = z + L, kzq = zq > half ? zq - N : zq;
+                // (only if that term has a live mode in this wave — the same test its own iteration makes: at k_cutoff = 2 seven
+                // fold terms in eight are dead, and requesting their entries cost PPD=8192 PLT 1.7 s)
+                const bool liveq = !dead && (kzq < 0 ? -kzq : kzq) != g.kmax && (g.corner_modes || kxy2 + kzq * kzq < g.k2i_cut);
+                if (__any(liveq)) enext = eig_lines_load(g, kzq, kyl, x);
             }
             const int k2i = kxy2 + kz * kz;
             const bool live = !dead && (kz < 0 ? -kz : kz) != g.kmax && (g.corner_modes || k2i < g.k2i_cut);
