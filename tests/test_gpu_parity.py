@@ -772,6 +772,25 @@ def test_density_on_composite_grids_vs_oracle(zd, oracle, ps, opk, n, kw):
     assert sorted(got["planes_seen"]) == list(range(n))
 
 
+def test_density_on_composite_grid_short_z_lines_vs_convolution_path(zd, ps):
+    """PPD = 480 = 32 * 15 with ZD_qdensity = 1 at R = 8: z lines of 60 = 4 * 15, i.e. the generator's short walk (four z rows per
+    thread, `k_genf<4, GENF_ZAFD>`) and the 4-element z transform with six fields — beyond the oracle's O(N^4) plain DFT, so the
+    comparator is the library's OTHER implementation of the same option: the reference arrays through the convolution kernels
+    (`store_mode = reference`), records and density planes"""
+    n = 480
+    a = zd.generate(zd.make_params(n, icformat="RVZel", qdensity=1, stream_factor=8), ps)
+    b = zd.generate(zd.make_params(n, icformat="RVZel", qdensity=1, store_mode="reference"), ps)
+    assert a["stream_factor"] == 8
+    for f in ("d", "v"):
+        scale = np.abs(b["records"][f]).max()
+        assert scale > 0 and np.abs(a["records"][f] - b["records"][f]).max() <= 2e-6 * scale, f  # float32 records
+    assert np.array_equal(a["records"]["ijk"], b["records"]["ijk"])
+    ds = np.abs(b["density"]).max()
+    assert ds > 0 and np.abs(a["density"] - b["density"]).max() <= 2e-6 * ds
+    assert abs(a["density_variance"] - b["density_variance"]) <= 1e-10 * b["density_variance"]
+    assert np.abs(a["max_disp"] - b["max_disp"]).max() <= 1e-10 * np.abs(b["max_disp"]).max()
+
+
 @pytest.mark.parametrize("n", [24, 72, 216, 48, 144, 432, 96, 288, 864, 192, 576, 1728, 384, 1152, 3456, 768, 2304, 6912,
                                1536, 4608, 3072])
 @pytest.mark.parametrize("kind", [0, 1])
