@@ -186,6 +186,14 @@ def test_stream_factor_chooser(zd):
     pr = zd.make_params(4096, store_mode="packed")  # round-1 packing: 3 arrays with Hermitian twins, 8 passes
     assert L.zd_choose_stream_factor(C.byref(pr), 1, 260 * GB) == 16
     assert L.zd_choose_stream_factor(C.byref(p4), 1, 1 * GB) == -1
+    # composite grid (2^7 3^3): four potentials per pass at R = 4; with ZD_qdensity = 1 the six-field store (round 4) needs R = 6 —
+    # still the composite kernels, not the any-divisor factors of the convolution path (reference arrays: 2 x 3456^3 x 16 B = 1.3 TB / R)
+    pc, pcd = zd.make_params(3456), zd.make_params(3456, qdensity=1)
+    assert L.zd_choose_stream_factor(C.byref(pc), 1, 256 * GB) == 4
+    assert L.zd_choose_stream_factor(C.byref(pcd), 1, 256 * GB) == 6
+    # ZD_qdensity = 2 (density only) and PLT with a density stay on the convolution path: one array / four arrays, any divisor
+    pc2 = zd.make_params(3456, qdensity=2)
+    assert L.zd_choose_stream_factor(C.byref(pc2), 1, 256 * GB) == 3
 
 
 # ---- host emulation of the device FFT engine -------------------------------------------------------
