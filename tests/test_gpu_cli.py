@@ -40,7 +40,8 @@ def test_usage_and_bad_file():
 
 @pytest.mark.parametrize("fmt,R,qd,ngpu", [("RVdoubleZel", 1, 0, 1), ("RVZel", 2, 1, 1), ("ZelSimple", 2, 0, 1),
                                           ("Zeldovich", 2, 0, 1), ("RVZel", 2, 0, 2), ("RVdoubleZel", 4, 0, 4),
-                                          ("RVZel", 2, 1, -70)])   # ngpu < 0: one GPU, NP = 70^3 (2 * 5 * 7: the any-PPD kernels)
+                                          ("RVZel", 2, 1, -70),    # ngpu < 0: one GPU, NP = 70^3 (2 * 5 * 7: the any-PPD kernels)
+                                          ("RVZel", 2, 1, -96)])   # NP = 96^3 (2^5 3) with a density file: the six-field store of the composite kernels
 def test_cli_writes_reference_files(tmp_path, oracle, fmt, R, qd, ngpu):
     """ngpu > 1: `ZD_NumGPU` in the parameter file — one host thread per rank inside the library; on this one-GPU box the
     ranks share the device (see test_native_multi_gpu_driver)"""
