@@ -417,13 +417,20 @@ def main():
         modes = {"default": first_name, first_name: mode_summary(main_mode)}
         close_mode(main_mode)
         plan = comm = pipe = None
-        other = run_split(world if first_name == "all_to_all" else 1)  # one GPU per group <-> one group of all GPUs
-        if other is not None and (world == 1 or (other["gsz"] > 1) != (gsz > 1)):
-            modes[other_name] = mode_summary(other)
-        else:
-            modes[other_name] = {"unavailable": "the passes of this workload do not deal out that way on %d GPU(s)" % world}
+        other = None
+        try:  # (the line with `value` must be printed whatever happens to the second measurement)
+            other = run_split(world if first_name == "all_to_all" else 1)  # one GPU per group <-> one group of all GPUs
+            if other is not None and (world == 1 or (other["gsz"] > 1) != (gsz > 1)):
+                modes[other_name] = mode_summary(other)
+            else:
+                modes[other_name] = {"unavailable": "the passes of this workload do not deal out that way on %d GPU(s)" % world}
+        except Exception as e:
+            modes[other_name] = {"error": repr(e)}
         if other is not None:
-            close_mode(other)
+            try:
+                close_mode(other)
+            except Exception:
+                pass
     if rank == 0:
         if modes is not None:
             out["modes"] = modes
