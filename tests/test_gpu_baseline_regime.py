@@ -185,6 +185,32 @@ def test_oversampled_planes_exact_at_full_size(zd, n):
         assert err < (1e-13 if n in (2048, 4096) else 1e-12)  # composite transforms: 27-term outer sums; 1000 / 2000: convolutions
 
 
+@pytest.mark.parametrize("n", [224, 448, 896, 1792, 3584, 336, 672, 1344, 2688, 560, 1120, 2240, 784, 1568, 3136, 2160])
+def test_radix7_oversampled_planes(zd, n):
+    """Every composite grid with a radix-7 outer transform (round 4: Q = 7, 21, 35, 49 and Q = 135; csrc/zd_kernels_np2.hip NP2_SIZES)
+    runs at its own size: PPD = 2n with ZD_k_cutoff = 2 at even sites == PPD = n.  The chains start from a run checked elsewhere:
+    224 against the oracle (test_gpu_parity.py test_radix7_ppd_vs_oracle), 336 / 560 / 784 / 2160 (P = 16: no composite y / x
+    kernels) on the convolution kernels of zd_kernels_any.hip — two transform families against each other.
+    Q = 7: 224 <-> 448 <-> 896 <-> 1792 <-> 3584 <-> 7168;  Q = 21: 336c <-> 672 <-> 1344 <-> 2688 <-> 5376;
+    Q = 35: 560c <-> 1120 <-> 2240 <-> 4480;  Q = 49: 784c <-> 1568 <-> 3136 <-> 6272;  Q = 135: 2160c <-> 4320."""
+    ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
+    zs = [5, n // 2 + 3, n - 2] if n < 1500 else [n // 2 + 3]
+    comp = n not in (336, 560, 784, 2160)
+    lo, ilo = _planes(zd, ps, n, zs, **(dict(stream_factor=2) if comp and n <= 2688 else {}))  # R = 2: the longest z lines one GPU holds
+    hi, ihi = _planes(zd, ps, 2 * n, [2 * z for z in zs], k_cutoff=2.0)
+    print("PPD", n, ilo, "PPD", 2 * n, ihi)
+    assert ihi["narray"] == 3 and (ilo["narray"] == 3) == comp  # field store of the composite kernels / reference arrays of the convolutions
+    for z in zs:
+        a, b = lo[z], hi[2 * z][::2, ::2]
+        assert np.array_equal(b["ijk"][..., 0], np.full((n, n), 2 * z))
+        assert np.array_equal(2 * a["ijk"][..., 1:].astype(np.int64), b["ijk"][..., 1:].astype(np.int64))
+        scale = np.abs(a["d"]).max()
+        assert scale > 0
+        err = np.abs(a["d"] - b["d"]).max() / scale
+        print("  z", z, "max |d(2n, even sites) - d(n)| / max|d| =", err)
+        assert err < 1e-12
+
+
 def test_ppd16384_k_cutoff4_planes_equal_ppd4096(zd):
     """PPD = 16384 (beyond the 8192 of BASELINE C5; MAX_PPD = 65536, include/zeldovich.h:34) with ZD_k_cutoff = 4 at every
     fourth lattice site == PPD = 4096: one plane, records compared exactly"""
@@ -208,6 +234,7 @@ def test_ppd16384_k_cutoff4_planes_equal_ppd4096(zd):
     (6912, 4.0, 8, 16, [(3, 5, -7), (-401, 377, 500)]),                  # composite kernels, x pass in two launches
     (3456, 2.0, 4, 8, [(-3, 5, 7), (401, 377, -500)]),                   # composite kernels, three lines per workgroup
     (6912, 1.0, 64, None, [(-2001, 1777, 1200)]),                        # production Abacus on ONE GPU: z lines of 108 = 4 * 27
+    (3584, 2.0, 8, 16, [(-401, 377, 500)]),                              # radix-7 composite kernels (3584 = 512 * 7) with the PLT field store
 ])
 def test_large_plt_plane_waves_and_stream_invariance(zd, oracle, n, kc, Ra, Rb, modes):
     """PLT + rescale at the sizes that only the PLT FIELD store serves — PPD = 8192 (the y pass at 8192 and the x pass in two

@@ -882,6 +882,42 @@ def test_radix5_ppd_vs_oracle(zd, oracle, ps, opk, n, kw):
     assert sorted(got["planes_seen"]) == list(range(n))
 
 
+@pytest.mark.parametrize("n", [56, 112, 448, 1792, 7168, 336, 2688, 560, 2240, 784, 6272, 2160, 4320])
+@pytest.mark.parametrize("kind", [0, 1])
+def test_fft_lines_radix7_lengths(zd, n, kind):
+    """lengths 2^a * {7, 21, 35, 49} and 2^a * 135 (round 4; the reference plans any length with FFTW, src/zeldovich.cpp:61-66): radix-7
+    stages in the outer transform of csrc/zd_fft_q.h, both LDS layouts, vs numpy"""
+    rng = np.random.default_rng(n + kind)
+    lines = 8
+    x = rng.standard_normal((lines, n)) + 1j * rng.standard_normal((lines, n))
+    got = zd.test_fft(x, kind)
+    ref = np.fft.ifft(x, axis=1) * n
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    assert err < 2e-14, err
+
+
+@pytest.mark.parametrize("n,kw", [
+    (224, dict(stream_factor=2)),                                        # 224 = 32 * 7, z lines of 112 = 16 * 7
+    (224, dict(stream_factor=2, plt=32, fmt="RVZel")),                    # PLT + rescale, interpolated 32^3 table
+    (224, dict(stream_factor=2, qdensity=1, k_cutoff=2.0, fmt="ZelSimple")),  # six-field store: density on the composite kernels
+])
+def test_radix7_ppd_vs_oracle(zd, oracle, ps, opk, n, kw):
+    """PPD = 2^a 7 on the composite-transform kernels (field stores) against the oracle, whose non-power-of-two path is a plain DFT.
+    (The larger radix-7 grids hang off this one through the oversampling links of test_gpu_baseline_regime.py
+    test_radix7_oversampled_planes.)"""
+    kw = dict(kw)
+    fmt = kw.pop("fmt", "RVdoubleZel")
+    eig = None
+    if "plt" in kw:
+        eig = oracle.synthetic_eigenmodes(kw.pop("plt"))
+        kw.update(qPLT=1, qPLTrescale=1, PLT_target_z=5.0, f_cluster=0.97)
+    plan = zd.Plan(zd.make_params(n, icformat=fmt, **kw), ps, eig=eig)
+    assert plan.store_mode == "fields"
+    plan.close()
+    got, _ = _compare(zd, oracle, ps, opk, n, fmt=fmt, eig=eig, **kw)
+    assert sorted(got["planes_seen"]) == list(range(n))
+
+
 def test_radix5_oversampling_and_stream_invariance(zd, ps):
     """5-smooth grids beyond the oracle's reach: 1600 (= 64 * 25, k_cutoff = 2) <-> 800 (= 32 * 25) and 960 (= 64 * 15) <-> 480 through
     the oversampling invariant on sample planes; R-invariance of the reductions at 1280 (= 256 * 5).  (4000 = 32 * 125 against 2000 on

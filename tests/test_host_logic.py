@@ -49,7 +49,7 @@ def _write(tmp_path, text):
 
 
 def test_stream_factor_for_any_even_ppd(zd):
-    """PPD with other prime factors than 2 and 3 (zd_kernels_any.hip): reference arrays on one rank, R any divisor of PPD; a 2^a 3^b size falls back to the same path when its options need the reference arrays (density)"""
+    """PPD with other prime factors than 2 and 3 (zd_kernels_any.hip): reference arrays on one rank, R any divisor of PPD; a 2^a 3^b size falls back to the same path when its options need the reference arrays (ZD_qdensity = 2)"""
     L = zd.load_library()
     GB = 1 << 30
 
@@ -64,8 +64,13 @@ def test_stream_factor_for_any_even_ppd(zd):
     assert R(1001, 250 * GB) == -1         # odd PPD: the reference requires an even one too
     assert R(1000, 250 * GB, nranks=2) == -1
     assert R(1000, 250 * GB, qPLT=1) == 1 and R(1000, 250 * GB, qdensity=2) == 1
-    assert R(96, 250 * GB) == 2 and R(96, 250 * GB, qdensity=1) == 1   # composite kernels / convolution kernels
+    assert R(96, 250 * GB) == 2 and R(96, 250 * GB, qdensity=1) == 2 and R(96, 250 * GB, qdensity=2) == 1   # composite kernels (ZA, also
+    # with a density since round 4) / convolution kernels (density only)
     assert R(1000, 250 * GB, f_NL=1.0, n_s=0.96, Omega_M=0.3) == 1
+    # radix-7 composite grids (round 4): 7168 = 1024 * 7 with z lines of 112 = 16 * 7; 3584 = 512 * 7, z lines of 448; 4320 = 32 * 135
+    # has no z kernel of 16 * 135 (1080 threads): z lines of 432 = 16 * 27
+    assert R(7168, 250 * GB) == 64 and R(3584, 250 * GB) == 8 and R(2688, 250 * GB) == 2 and R(4320, 250 * GB) == 10
+    assert R(7168, 250 * GB, nranks=8) == 8 and R(6272, 250 * GB, qPLT=1) == 56
 
 
 def test_params_from_file(zd, tmp_path):

@@ -54,6 +54,54 @@ EXPECTED = [
     ("4000 ZA", "launch_yfft_fq_t", "Q = 125"),
     ("6912 ZA one GPU", "launch_genf_z", "ZR = 4, KIND = 5"),
     ("6912 PLT", "launch_genf_z", "ZR = 4, KIND = 6"),
+    # radix-7 composite grids (round 4): every (P, Q) of NP2_SIZES with a factor 7, and 4320 = 32 * 135
+    ("224 ZA", "launch_yfft_fq_t", "P = 32, E = 16, Q = 7,"),
+    ("224 ZA", "launch_xfft_q_t", "P = 32, E = 16, Q = 7, PLT = false"),
+    ("448 ZA", "launch_yfft_fq_t", "P = 64, E = 16, Q = 7,"),
+    ("448 ZA", "launch_xfft_q_t", "P = 64, E = 16, Q = 7, PLT = false"),
+    ("896 ZA", "launch_yfft_fq_t", "P = 128, E = 16, Q = 7,"),
+    ("896 ZA", "launch_xfft_q_t", "P = 128, E = 16, Q = 7, PLT = false"),
+    ("1792 ZA", "launch_yfft_fq_t", "P = 256, E = 16, Q = 7,"),
+    ("1792 ZA", "launch_xfft_q_t", "P = 256, E = 16, Q = 7, PLT = false"),
+    ("3584 ZA", "launch_yfft_fq_t", "P = 512, E = 16, Q = 7,"),
+    ("3584 ZA", "launch_xfft_q_t", "P = 512, E = 16, Q = 7, PLT = false"),
+    ("7168 ZA", "launch_yfft_fq_t", "P = 1024, E = 16, Q = 7,"),
+    ("7168 ZA", "launch_xfft_q_t", "P = 1024, E = 16, Q = 7, PLT = false"),
+    ("672 ZA", "launch_yfft_fq_t", "P = 32, E = 16, Q = 21,"),
+    ("672 ZA", "launch_xfft_q_t", "P = 32, E = 16, Q = 21, PLT = false"),
+    ("1344 ZA", "launch_yfft_fq_t", "P = 64, E = 16, Q = 21,"),
+    ("1344 ZA", "launch_xfft_q_t", "P = 64, E = 16, Q = 21, PLT = false"),
+    ("2688 ZA", "launch_yfft_fq_t", "P = 128, E = 16, Q = 21,"),
+    ("2688 ZA", "launch_xfft_q_t", "P = 128, E = 16, Q = 21, PLT = false"),
+    ("5376 ZA", "launch_yfft_fq_t", "P = 256, E = 16, Q = 21,"),
+    ("5376 ZA", "launch_xfft_q_t", "P = 256, E = 16, Q = 21, PLT = false"),
+    ("1120 ZA", "launch_yfft_fq_t", "P = 32, E = 16, Q = 35,"),
+    ("1120 ZA", "launch_xfft_q_t", "P = 32, E = 16, Q = 35, PLT = false"),
+    ("2240 ZA", "launch_yfft_fq_t", "P = 64, E = 16, Q = 35,"),
+    ("2240 ZA", "launch_xfft_q_t", "P = 64, E = 16, Q = 35, PLT = false"),
+    ("4480 ZA", "launch_yfft_fq_t", "P = 128, E = 16, Q = 35,"),
+    ("4480 ZA", "launch_xfft_q_t", "P = 128, E = 16, Q = 35, PLT = false"),
+    ("1568 ZA", "launch_yfft_fq_t", "P = 32, E = 16, Q = 49,"),
+    ("1568 ZA", "launch_xfft_q_t", "P = 32, E = 16, Q = 49, PLT = false"),
+    ("3136 ZA", "launch_yfft_fq_t", "P = 64, E = 16, Q = 49,"),
+    ("3136 ZA", "launch_xfft_q_t", "P = 64, E = 16, Q = 49, PLT = false"),
+    ("6272 ZA", "launch_yfft_fq_t", "P = 128, E = 16, Q = 49,"),
+    ("6272 ZA", "launch_xfft_q_t", "P = 128, E = 16, Q = 49, PLT = false"),
+    ("4320 ZA", "launch_yfft_fq_t", "P = 32, E = 16, Q = 135,"),
+    ("4320 ZA", "launch_xfft_q_t", "P = 32, E = 16, Q = 135, PLT = false"),
+    ("3584 PLT", "launch_xfft_q_t", "P = 512, E = 16, Q = 7, PLT = true"),
+    # ... and their z lines (L = 1792 and 1568 need a store beyond one GPU's memory: several GPUs only; same LineQ engine, tested by
+    # test_fft_lines_radix7_lengths)
+    ("z lines of 112", "launch_zfft_fq_t", "P = 16, E = 16, Q = 7,"),
+    ("z lines of 224", "launch_zfft_fq_t", "P = 32, E = 16, Q = 7,"),
+    ("z lines of 448", "launch_zfft_fq_t", "P = 64, E = 16, Q = 7,"),
+    ("z lines of 896", "launch_zfft_fq_t", "P = 128, E = 16, Q = 7,"),
+    ("z lines of 336", "launch_zfft_fq_t", "P = 16, E = 16, Q = 21,"),
+    ("z lines of 672", "launch_zfft_fq_t", "P = 32, E = 16, Q = 21,"),
+    ("z lines of 1344", "launch_zfft_fq_t", "P = 64, E = 16, Q = 21,"),
+    ("z lines of 560", "launch_zfft_fq_t", "P = 16, E = 16, Q = 35,"),
+    ("z lines of 1120", "launch_zfft_fq_t", "P = 32, E = 16, Q = 35,"),
+    ("z lines of 784", "launch_zfft_fq_t", "P = 16, E = 16, Q = 49,"),
     # any even PPD (zd_kernels_any.hip)
     ("1000/2000 any", "launch_any_cols_t", ""),
     ("1000/2000 any", "launch_any_lines_t", ""),

@@ -287,7 +287,7 @@ zdpcg::Affine row_jump_full(long long drows) {  // 2*65536*drows draws
 
 extern "C" {
 
-// ZD_qdensity = 1 on the composite grids (PPD = 2^a 3^b 5^c; round 4): the ZA field store carries two more half-space sums — the
+// ZD_qdensity = 1 on the composite grids (PPD = 2^a 3^b 5^c 7^d; round 4): the ZA field store carries two more half-space sums — the
 // density D of the two residues of a pass — and the y / x stages add one array, delta_r0 + i delta_r1 (zd_kernels_np2.hip).  The
 // power-of-two grids keep the reference's arrays for ZD_qdensity (their kernels exist); ZD_qdensity = 2 (density only), PLT and
 // f_NL with a density stay on the convolution path for composite PPDs.
@@ -398,7 +398,7 @@ static int field_ring_planes(int64_t N, int64_t Zq) {
     return (int) std::max<int64_t>(1, std::min<int64_t>(Zq, ((int64_t) 6 << 30) / plane_b));
 }
 
-// stream factors the composite (2^a 3^b 5^c) kernels take: any EVEN divisor of PPD (two residues r, r + R/2 share a ZA pass) — or
+// stream factors the composite (2^a 3^b 5^c 7^d) kernels take: any EVEN divisor of PPD (two residues r, r + R/2 share a ZA pass) — or
 // 1 — whose z lines have a composite transform.  R = 36 gives PPD = 6912 z lines of 192 = 64 * 3 and 18 passes where the powers of two
 // offer 64 (z lines of 108) and 32 passes: the store of a pass must fit, and between 128 GB and 260 GB there was nothing.
 static bool np2_stream_factor_ok(int64_t N, int R) {
@@ -1871,7 +1871,7 @@ static int test_fft_composite(int32_t n, int64_t lines, int32_t axis_kind, const
     int P = 0, Q = 0;
     const int W = zd::test_fftq_tile_width(n);
     if (!zd::np2_split(n, &P, &Q) || W == 0 || lines % W) {
-        fprintf(stderr, "zd_test_fft: n=%d is not 2^a 3^b (b <= 3), or lines %% %d != 0\n", n, W);
+        fprintf(stderr, "zd_test_fft: n=%d is not 2^a * {3, 9, 27, 5, 15, 25, 45, 75, 125, 135, 7, 21, 35, 49}, or lines %% %d != 0\n", n, W);
         return 1;
     }
     std::vector<cplx> twP = make_twiddles(P), twN = make_twiddles(n), twQ = make_twiddles(Q);

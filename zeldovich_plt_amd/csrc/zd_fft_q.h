@@ -1,12 +1,12 @@
-// zd_fft_q.h — line lengths N = P * Q with P a power of two and Q = 3^a 5^b (3, 9, 27, 5, 25, 125, 15, 45, 75; PPD = 6912 = 256 * 27,
-// 4000 = 32 * 125, ...), on
+// zd_fft_q.h — line lengths N = P * Q with P a power of two and Q = 3^a 5^b 7^c (3, 9, 27, 5, 25, 125, 15, 45, 75, 135, 7, 21, 35, 49;
+// PPD = 6912 = 256 * 27, 4000 = 32 * 125, 7168 = 1024 * 7, ...), on
 // top of the register-resident power-of-two engine of zd_fft.h.
 //
 // The reference plans any length with FFTW (src/zeldovich.cpp:61-66).  Here a line is split into its Q decimated
 // sub-sequences x[Q n1 + n2] (n2 < Q), each of length P:
 //     X[k1 + P k2] = sum_{n2 < Q}  ( W_N^{n2 k1}  F_{n2}[k1] )  W_Q^{n2 k2},      F_{n2} = DFT_P of sub-sequence n2
 // The Q sub-transforms are just Q more "columns" for the existing engine (threads (t, n2) hold 16 elements each, radix-16
-// butterflies in registers, exchanges through LDS); the outer Q-point transforms are a + b radix-3 / radix-5 stages on an LDS
+// butterflies in registers, exchanges through LDS); the outer Q-point transforms are a + b + c radix-3 / radix-5 / radix-7 stages on an LDS
 // staging buffer (the power-of-two sizes never come here).  Thread (t, w, n2) enters with elements  x[Q (t + T e) + n2]  of line w and leaves with  X[(t + T e) + P n2].
 #pragma once
 #include <type_traits>
@@ -24,14 +24,14 @@ struct pick<false, A, B> {
     using type = B;
 };
 
-// Q = 3^a 5^b: digit j of an index below Q has radix 3 for j < a and 5 above
+// Q = 3^a 5^b 7^c: digit j of an index below Q has radix 3 for j < a, 5 for the next b digits and 7 above
 template <int Q>
 struct QFactors {
     static constexpr int count(int q, int r) { return q % r == 0 ? 1 + count(q / r, r) : 0; }
-    static constexpr int A = count(Q, 3), B = count(Q, 5), S = A + B;
+    static constexpr int A = count(Q, 3), B = count(Q, 5), C = count(Q, 7), S = A + B + C;
     static constexpr int ipow(int b, int e) { return e == 0 ? 1 : b * ipow(b, e - 1); }
-    static_assert(ipow(3, A) * ipow(5, B) == Q && S >= 1 && S <= 4, "Q = 3^a 5^b with 1 <= a + b <= 4");
-    static constexpr int radix(int j) { return j < A ? 3 : 5; }
+    static_assert(ipow(3, A) * ipow(5, B) * ipow(7, C) == Q && S >= 1 && S <= 4, "Q = 3^a 5^b 7^c with 1 <= a + b + c <= 4");
+    static constexpr int radix(int j) { return j < A ? 3 : (j < A + B ? 5 : 7); }
     static constexpr int stride(int j) { return j == 0 ? 1 : stride(j - 1) * radix(j - 1); }  // S_j
 };
 
@@ -102,7 +102,7 @@ struct LineQ {
             re[e] = a;
             im[e] = b;
         }
-        // Outer Q-point transforms, Q = 3^a 5^b, as a + b stages of radix 3 / 5 on an LDS staging buffer, CH elements per round.
+        // Outer Q-point transforms, Q = 3^a 5^b 7^c, as a + b + c stages of radix 3 / 5 / 7 on an LDS staging buffer, CH elements per round.
         // Input index n = d_0 + r_0 (d_1 + r_1 (d_2 + ...)) (digit j has radix r_j and weight S_j = r_0 ... r_{j-1}), so
         //     X[k] = sum_{d_0} W_Q^{d_0 k}  sum_{d_1} W_{Q/S_1}^{d_1 k}  ...  sum_{d_{S-1}} W_{r_{S-1}}^{d_{S-1} k}
         // and stage s sums over the digit j = S-1-s (the innermost sum first) with the twiddle W_{M_j}^{d_j k}, M_j = Q / S_j,

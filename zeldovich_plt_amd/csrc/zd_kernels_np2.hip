@@ -527,6 +527,12 @@ int launch_zfft_fields_np2(int L, const FieldLayout &F, const StoreLayout &S, in
     ZC(16, 45, 1) ZC(32, 45, 1)
     ZC(16, 75, 1)
     ZC(16, 125, 1)
+    // radix 7 (round 4): 224 ... 7168 (Q = 7), 672 ... 5376 (21), 1120 ... 4480 (35), 1568 ... 6272 (49)  (4320 = 32 * 135 has z lines
+    // of 720, 432, 240, 144 at R = 6, 10, 18, 30: a workgroup of 8 rows x 135 sub-lines would be 1080 threads)
+    ZC(16, 7, 4) ZC(32, 7, 4) ZC(64, 7, 4) ZC(128, 7, 2) ZC(256, 7, 1)
+    ZC(16, 21, 4) ZC(32, 21, 2) ZC(64, 21, 1)
+    ZC(16, 35, 2) ZC(32, 35, 1)
+    ZC(16, 49, 2) ZC(32, 49, 1)
 #undef ZC
     // 4 * Q: four elements per thread, one thread per sub-line — the short z lines of large stream factors (108 = 4 * 27: PPD = 6912
     // at R = 64, the whole grid on ONE GPU; 500 = 4 * 125: PPD = 4000 at R = 8)
@@ -536,14 +542,14 @@ int launch_zfft_fields_np2(int L, const FieldLayout &F, const StoreLayout &S, in
     if (L == 180) return launch_zfft_fq_t<4, 4, 45, 2>(F, S, ky0, kyloc0, nky, Y, (const cplx *) tw, out, st);
     if (L == 100) return launch_zfft_fq_t<4, 4, 25, 4>(F, S, ky0, kyloc0, nky, Y, (const cplx *) tw, out, st);
     if (L == 60) return launch_zfft_fq_t<4, 4, 15, 4>(F, S, ky0, kyloc0, nky, Y, (const cplx *) tw, out, st);
-    fprintf(stderr, "zeldovich_hip: no z transform of length %d (16*2^k * {3, 9, 27, 5, 15, 25, 45, 75, 125})\n", L);
+    fprintf(stderr, "zeldovich_hip: no z transform of length %d (16*2^k * {3, 9, 27, 5, 15, 25, 45, 75, 125, 7, 21, 35, 49})\n", L);
     return 2;
 }
 // columns per z-FFT workgroup (the generator prunes by it) = the NC of the table above
 int zfft_fields_np2_columns(int L) {
     switch (L) {
-        case 48: case 96: case 192: case 144: case 80: case 160: case 240: case 100: case 60: return 4;
-        case 384: case 288: case 432: case 108: case 320: case 480: case 400: case 180: return 2;
+        case 48: case 96: case 192: case 144: case 80: case 160: case 240: case 100: case 60: case 112: case 224: case 448: case 336: return 4;
+        case 384: case 288: case 432: case 108: case 320: case 480: case 400: case 180: case 896: case 672: case 560: case 784: return 2;
         default: return 1;
     }
 }
@@ -621,7 +627,13 @@ static int launch_xfft_q_t(const EpiConst &ec, const cplx *tw, const void *ring,
     X(32, 25, 16) X(64, 25, 8) X(128, 25, 4) X(256, 25, 2)                                                                 \
     X(32, 45, 8) X(64, 45, 4) X(128, 45, 2)                                                                                \
     X(32, 75, 4) X(64, 75, 2)                                                                                              \
-    X(32, 125, 4) X(64, 125, 2)
+    X(32, 125, 4) X(64, 125, 2)                                                                                            \
+    /* radix 7 (round 4): 224 ... 7168, 672 ... 5376, 1120 ... 4480, 1568 ... 6272; 4320 = 32 * 135 */                     \
+    X(32, 7, 16) X(64, 7, 16) X(128, 7, 16) X(256, 7, 8) X(512, 7, 4) X(1024, 7, 2)                                        \
+    X(32, 21, 16) X(64, 21, 8) X(128, 21, 4) X(256, 21, 2)                                                                 \
+    X(32, 35, 8) X(64, 35, 4) X(128, 35, 2)                                                                                \
+    X(32, 49, 8) X(64, 49, 4) X(128, 49, 2)                                                                                \
+    X(32, 135, 2)
 int launch_yfft_fields_np2(const FieldLayout &F, const StoreLayout &S, const void *tw, const void *store, int plane0, int nplanes,
                            int ring_pitch, void *ring, int dens, hipStream_t st) {
 #define YC(p, q, w) \
@@ -663,7 +675,8 @@ bool np2_supported_zlen(int L) {
     if (L == 108 || L == 500 || L == 300 || L == 180 || L == 100 || L == 60) return true;  // 4 * Q (launch_zfft_fields_np2)
     if (!np2_split(L, &P, &Q) || P < 16) return false;
     return (Q == 3 && P <= 512) || (Q == 9 && P <= 128) || (Q == 27 && P <= 64) || (Q == 5 && P <= 256) || (Q == 15 && P <= 128)
-           || (Q == 25 && P <= 64) || (Q == 45 && P <= 32) || (Q == 75 && P <= 16) || (Q == 125 && P <= 16);
+           || (Q == 25 && P <= 64) || (Q == 45 && P <= 32) || (Q == 75 && P <= 16) || (Q == 125 && P <= 16)
+           || (Q == 7 && P <= 256) || (Q == 21 && P <= 64) || (Q == 35 && P <= 32) || (Q == 49 && P <= 32);
 }
 
 #ifdef ZD_TESTING
@@ -689,7 +702,7 @@ static int launch_test_fftq_t(int kind, const void *twP, const void *twN, const 
 }
 #endif  // ZD_TESTING
 
-// n = P*Q -> (P, Q): Q = the whole power of three in n (3, 9 or 27), P the power of two
+// n = P*Q -> (P, Q): Q = the whole odd part of n (3^a 5^b 7^c, one of the products below), P the power of two
 bool np2_split(int n, int *P, int *Q) {
     int q = 1, p = n;
     while (p % 3 == 0) {
@@ -700,7 +713,12 @@ bool np2_split(int n, int *P, int *Q) {
         p /= 5;
         q *= 5;
     }
-    const bool known = q == 3 || q == 9 || q == 27 || q == 5 || q == 15 || q == 25 || q == 45 || q == 75 || q == 125;
+    while (p % 7 == 0) {
+        p /= 7;
+        q *= 7;
+    }
+    const bool known = q == 3 || q == 9 || q == 27 || q == 5 || q == 15 || q == 25 || q == 45 || q == 75 || q == 125 || q == 135 || q == 7
+                       || q == 21 || q == 35 || q == 49;
     if (!known || p < 4 || (p & (p - 1)) != 0) return false;
     *P = p;
     *Q = q;
@@ -727,6 +745,8 @@ int launch_test_fftq(int n, int kind, const void *twP, const void *twN, const vo
     TC(16, 16, 5, 4) TC(32, 16, 5, 4) TC(256, 16, 5, 4) TC(1024, 16, 5, 2)
     TC(16, 16, 15, 4) TC(64, 16, 15, 4) TC(16, 16, 25, 4) TC(128, 16, 25, 4) TC(16, 16, 45, 4) TC(32, 16, 75, 4) TC(16, 16, 125, 4) TC(32, 16, 125, 4)
     TC(8, 8, 5, 4) TC(8, 8, 25, 4) TC(8, 8, 125, 4)
+    TC(8, 8, 7, 4) TC(16, 16, 7, 4) TC(64, 16, 7, 4) TC(256, 16, 7, 4) TC(1024, 16, 7, 2) TC(16, 16, 21, 4) TC(128, 16, 21, 4) TC(16, 16, 35, 4)
+    TC(64, 16, 35, 4) TC(16, 16, 49, 4) TC(128, 16, 49, 2) TC(16, 16, 135, 4) TC(32, 16, 135, 2)
     TC(1024, 16, 3, 4)
 #undef TC
     fprintf(stderr, "zeldovich_hip: no composite FFT for length %d\n", n);
