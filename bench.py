@@ -267,6 +267,7 @@ def main():
         m["pipe"] = m["plan"] = m["comm"] = None
         torch.cuda.empty_cache()
 
+    t_start = time.perf_counter()
     main_mode = run_split(args.groups)
     if main_mode is None:
         raise SystemExit("PPD=%d does not fit %d GPU(s)" % (N, world))
@@ -418,6 +419,20 @@ def main():
         close_mode(main_mode)
         plan = comm = pipe = None
         other = None
+        # ... also when it never returns (a collective that hangs): every rank arms the same deadline, rank 0 prints the line it has
+        import threading
+        deadline = 60.0 + 6.0 * (time.perf_counter() - t_start)
+
+        def give_up():
+            if rank == 0:
+                modes[other_name] = {"error": "no result within %.0f s of starting it; the process was ended" % deadline}
+                out["modes"] = modes
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(deadline, give_up)
+        watchdog.daemon = True
+        watchdog.start()
         try:  # (the line with `value` must be printed whatever happens to the second measurement)
             other = run_split(world if first_name == "all_to_all" else 1)  # one GPU per group <-> one group of all GPUs
             if other is not None and (world == 1 or (other["gsz"] > 1) != (gsz > 1)):
@@ -426,6 +441,7 @@ def main():
                 modes[other_name] = {"unavailable": "the passes of this workload do not deal out that way on %d GPU(s)" % world}
         except Exception as e:
             modes[other_name] = {"error": repr(e)}
+        watchdog.cancel()
         if other is not None:
             try:
                 close_mode(other)
