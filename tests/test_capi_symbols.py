@@ -54,6 +54,20 @@ def test_every_build_target_has_a_recipe():
         assert "-c zd_kernels.hip" in plan, tgt
 
 
+def test_built_libraries_carry_the_sha_of_these_sources():
+    """every library build() left in csrc/build says which sources it was linked from (<lib>.srcsha = one line, the sha-256 of
+    conftest.source_sha): the GPU suite refuses a stale libzeldovich_hip_nofma.so by it and bench.py a stale PMC figure.  (`make -C`
+    from build() once wrote make's "Entering directory" lines into these files.)"""
+    import glob
+    from conftest import source_sha
+    libs = sorted(glob.glob(os.path.join(ROOT, "zeldovich_plt_amd", "csrc", "build", "libzeldovich_hip*.so")))
+    assert any(l.endswith("libzeldovich_hip.so") for l in libs)
+    for lib in libs:
+        txt = open(lib + ".srcsha").read()
+        assert re.fullmatch(r"[0-9a-f]{64}\n", txt), (lib, txt[:200])
+        assert txt.strip() == source_sha(), "%s was built from other sources: run build()" % lib
+
+
 def test_struct_layouts_match_header():
     """sizes the C compiler gives the ABI structs == the ctypes mirrors"""
     import subprocess
