@@ -222,7 +222,9 @@ int zd_plan_run_pass(zd_plan *plan, zd_comm *comm, int pass, void *d_store, void
 /* The passes first, first + step, ... of this rank (step = number of pass groups, first = this rank's group) in one call.
  * d_store2 (optional, as large as d_store): with a communicator of several ranks the passes are then PIPELINED — the Z stage of
  * the next pass runs into the other store while the planes of the current pass are exchanged and transformed; a store is
- * rewritten only after its sends have completed.  cb additionally receives the pass. */
+ * rewritten only after its sends have completed.  With ONE rank (comm == NULL) and a second store the Z stage of the next pass is
+ * issued beside the y / x stages of the current one (measured slower than one store at PPD=4096 on an MI355X — DESIGN.md §8 —
+ * and therefore not what zd_generate does; kept for A/B runs, bench.py --two-stores).  cb additionally receives the pass. */
 typedef int (*zd_pass_cb)(void *user, int pass, int64_t first_local_plane, int64_t nplanes, const void *d_records, void *hip_stream);
 int zd_plan_run_passes(zd_plan *plan, zd_comm *comm, int first, int step, void *d_store, void *d_store2, void *d_records,
                        int64_t rec_planes, zd_pass_cb cb, void *user, void *hip_stream);

@@ -185,14 +185,14 @@ def test_oversampled_planes_exact_at_full_size(zd, n):
         assert err < (1e-13 if n in (2048, 4096) else 1e-12)  # composite transforms: 27-term outer sums; 1000 / 2000: convolutions
 
 
-@pytest.mark.parametrize("n", [224, 448, 896, 1792, 3584, 336, 672, 1344, 2688, 560, 1120, 2240, 784, 1568, 3136, 2160])
+@pytest.mark.parametrize("n", [224, 448, 896, 1792, 3584, 336, 672, 1344, 2688, 560, 1120, 2240, 784, 1568, 3136, 2160, 4320])
 def test_radix7_oversampled_planes(zd, n):
     """Every composite grid with a radix-7 outer transform (round 4: Q = 7, 21, 35, 49 and Q = 135; csrc/zd_kernels_np2.hip NP2_SIZES)
     runs at its own size: PPD = 2n with ZD_k_cutoff = 2 at even sites == PPD = n.  The chains start from a run checked elsewhere:
     224 against the oracle (test_gpu_parity.py test_radix7_ppd_vs_oracle), 336 / 560 / 784 / 2160 (P = 16: no composite y / x
     kernels) on the convolution kernels of zd_kernels_any.hip — two transform families against each other.
     Q = 7: 224 <-> 448 <-> 896 <-> 1792 <-> 3584 <-> 7168;  Q = 21: 336c <-> 672 <-> 1344 <-> 2688 <-> 5376;
-    Q = 35: 560c <-> 1120 <-> 2240 <-> 4480;  Q = 49: 784c <-> 1568 <-> 3136 <-> 6272;  Q = 135: 2160c <-> 4320."""
+    Q = 35: 560c <-> 1120 <-> 2240 <-> 4480;  Q = 49: 784c <-> 1568 <-> 3136 <-> 6272;  Q = 135: 2160c <-> 4320 <-> 8640 (= 64 * 135: beyond 8192, y tiles one column wide)."""
     ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
     zs = [5, n // 2 + 3, n - 2] if n < 800 else [n // 2 + 3]
     comp = n not in (336, 560, 784, 2160)

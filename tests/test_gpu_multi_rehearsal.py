@@ -136,3 +136,57 @@ def test_pipelined_passes_on_the_loopback_emulation(zd, oracle, ngpu, n, kw):
         kw.update(qPLT=1, qPLTrescale=1, PLT_target_z=5.0, z_initial=49.0)
     got, _ = _compare(zd, oracle, ps, opk, n, eig=eig, ngpu=ngpu, pass_groups=1, loopback=True, **kw)
     assert sorted(got["planes_seen"]) == list(range(n)) and got["bytes_sent"] > 0
+
+
+@pytest.mark.parametrize("kw", [
+    dict(stream_factor=8),                                   # ZA field store: 4 passes of two residues
+    dict(stream_factor=4, plt=True, fmt="RVdoubleZel"),      # PLT: 4 passes
+    dict(stream_factor=4, store_mode="reference"),           # reference arrays
+])
+def test_one_rank_two_stores_equal_one_store(zd, oracle, kw):
+    """ONE rank, zd_plan_run_passes with a second store (the branch behind `bench.py --two-stores`): the Z stage of pass p + 1 is
+    issued beside the y / x stages of pass p, on its own stream into the other store.  Every record and the reductions must equal
+    the one-store run of the same plan exactly (same kernels, same order of the sums), and the records those of zd_generate."""
+    import torch
+    kw = dict(kw)
+    n, fmt = 128, kw.pop("fmt", "RVZel")
+    ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
+    eig = None
+    if kw.pop("plt", False):
+        eig = oracle.synthetic_eigenmodes(32)
+        kw.update(qPLT=1, qPLTrescale=1, PLT_target_z=5.0, z_initial=49.0)
+    p = zd.make_params(n, icformat=fmt, **kw)
+    dt = zd.RECORD_DTYPES[fmt]
+
+    def run(two):
+        plan = zd.Plan(p, ps, eig=eig)
+        assert plan.passes >= 4
+        store = torch.empty(plan.exchange_bytes, dtype=torch.uint8, device="cuda")
+        store2 = torch.empty_like(store) if two else None
+        chunk = plan.plane_step * 3  # several record chunks per pass, the last one short
+        rec = torch.empty(chunk * n * n * dt.itemsize, dtype=torch.uint8, device="cuda")
+        out = {}
+
+        def consume(pass_, first, cnt, ptr, st):
+            assert ptr == rec.data_ptr()
+            torch.cuda.synchronize()  # the planes come from work still queued on the library's stream
+            host = rec[:cnt * n * n * dt.itemsize].cpu().numpy().view(dt).reshape(cnt, n, n)
+            for i in range(cnt):
+                out[plan.plane_z(pass_, first + i)] = host[i].copy()
+            return 0
+
+        plan.run_passes(0, 1, store.data_ptr(), None if store2 is None else store2.data_ptr(), rec.data_ptr(), chunk, consume=consume)
+        torch.cuda.synchronize()
+        st = plan.stats()
+        plan.close()
+        return out, st
+
+    a, sa = run(False)
+    b, sb = run(True)
+    assert sorted(a) == sorted(b) == list(range(n))
+    for z in range(n):
+        assert a[z].tobytes() == b[z].tobytes(), z
+    assert sa["density_variance"] == sb["density_variance"] and np.array_equal(sa["max_disp"], sb["max_disp"])
+    ref = zd.generate(p, ps, eig=eig)
+    for z in range(n):
+        assert ref["records"][z].reshape(n, n).tobytes() == b[z].tobytes(), z

@@ -882,7 +882,7 @@ def test_radix5_ppd_vs_oracle(zd, oracle, ps, opk, n, kw):
     assert sorted(got["planes_seen"]) == list(range(n))
 
 
-@pytest.mark.parametrize("n", [56, 112, 448, 1792, 7168, 336, 2688, 560, 2240, 784, 6272, 2160, 4320])
+@pytest.mark.parametrize("n", [56, 112, 448, 1792, 7168, 336, 2688, 560, 2240, 784, 6272, 2160, 4320, 8640])
 @pytest.mark.parametrize("kind", [0, 1])
 def test_fft_lines_radix7_lengths(zd, n, kind):
     """lengths 2^a * {7, 21, 35, 49} and 2^a * 135 (round 4; the reference plans any length with FFTW, src/zeldovich.cpp:61-66): radix-7

@@ -89,6 +89,8 @@ EXPECTED = [
     ("6272 ZA", "launch_xfft_q_t", "P = 128, E = 16, Q = 49, PLT = false"),
     ("4320 ZA", "launch_yfft_fq_t", "P = 32, E = 16, Q = 135,"),
     ("4320 ZA", "launch_xfft_q_t", "P = 32, E = 16, Q = 135, PLT = false"),
+    ("8640 ZA", "launch_yfft_fq_t", "P = 64, E = 16, Q = 135,"),
+    ("8640 ZA", "launch_xfft_q_t", "P = 64, E = 16, Q = 135, PLT = false"),
     ("3584 PLT", "launch_xfft_q_t", "P = 512, E = 16, Q = 7, PLT = true"),
     # ... and their z lines (L = 1792 and 1568 need a store beyond one GPU's memory: several GPUs only; same LineQ engine, tested by
     # test_fft_lines_radix7_lengths)

@@ -411,6 +411,7 @@ int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes
     int R0 = 1;
     if (!p->qPLT && pack_mode(p, 2) != zd::PACK_NONE && N / 2 >= 32 && (N / 2) % nranks == 0) R0 = 2;
     const bool np2 = !is_pow2(N);
+    if (N > 8192 && pack_mode(p, 2) != zd::PACK_ZAFIELD) return -1;  // 16384, 8640: only the ZA field store has kernels (plan_create_ex)
     // any other even PPD (or a 2^a 3^b one whose options the composite kernels lack): reference arrays on one rank, see
     // plan_create_ex; R any divisor of N
     auto any_factor = [&]() -> int {
@@ -692,7 +693,7 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
     pl->any = any_path;
     if (zd::pack_is_fields(pl->pack) && ((pl->half / nranks) % zd::FIELD_RB || N / R > 2048))  // row blocks of 8, z FFT <= 2048
         pl->pack = N > 4096 ? zd::PACK_NONE : (pl->pack == zd::PACK_PLTFIELD ? zd::PACK_PLT3 : zd::PACK_ZAPAIR);
-    if (N > 8192 && pl->pack != zd::PACK_ZAFIELD) {  // a 16384-point line fills a workgroup: only the field store's kernels exist
+    if (N > 8192 && pl->pack != zd::PACK_ZAFIELD) {  // a 16384-point line fills a workgroup: only the field store's kernels exist (also 8640 = 64 * 135: ZA)
         fprintf(stderr, "zeldovich_hip: PPD = %lld runs on the ZA field store only (ZD_StreamFactor >= 16, no ZD_qdensity / ZD_qPLT / ZD_f_NL)\n",
                 (long long) N);
         delete pl;

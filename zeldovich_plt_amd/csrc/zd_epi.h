@@ -129,15 +129,23 @@ __device__ __forceinline__ void max_commit(Reduce *__restrict__ red, int j, int 
     // (pair read without the lock: the key of a given magnitude only decreases, and a larger magnitude beats this candidate anyway)
     if (myabs == cur && mykey >= ld_agent(&red->maxkey[j][slot])) return;
     // (bounded: a holder is a running wave a few memory operations from its release, so the bound is never reached; if it ever
-    // were, an unlocked update — possibly torn against a concurrent one — is preferred to a wave that never finishes)
-    for (unsigned spin = 0; atomicCAS(&red->lock[slot], 0u, 1u) != 0u && spin < (1u << 22); spin++) __builtin_amdgcn_s_sleep(2);
+    // were, an unlocked update — possibly torn against a concurrent one — is preferred to a wave that never finishes; such a
+    // wave leaves the lock word alone, it belongs to the holder)
+    bool held = false;
+    for (unsigned spin = 0; spin < (1u << 22); spin++) {
+        if (atomicCAS(&red->lock[slot], 0u, 1u) == 0u) {
+            held = true;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
     const unsigned long long a = ld_agent(&red->maxabs[j][slot]), k = ld_agent(&red->maxkey[j][slot]);
     if (myabs > a || (myabs == a && mykey < k)) {
         __hip_atomic_store(&red->maxkey[j][slot], mykey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&red->maxabs[j][slot], myabs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __threadfence();
-    atomicExch(&red->lock[slot], 0u);
+    if (held) atomicExch(&red->lock[slot], 0u);
 }
 
 // workgroup reduction of the epilogue -> one atomic per quantity into a replicated slot

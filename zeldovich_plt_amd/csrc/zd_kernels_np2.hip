@@ -527,8 +527,8 @@ int launch_zfft_fields_np2(int L, const FieldLayout &F, const StoreLayout &S, in
     ZC(16, 45, 1) ZC(32, 45, 1)
     ZC(16, 75, 1)
     ZC(16, 125, 1)
-    // radix 7 (round 4): 224 ... 7168 (Q = 7), 672 ... 5376 (21), 1120 ... 4480 (35), 1568 ... 6272 (49)  (4320 = 32 * 135 has z lines
-    // of 720, 432, 240, 144 at R = 6, 10, 18, 30: a workgroup of 8 rows x 135 sub-lines would be 1080 threads)
+    // radix 7 (round 4): 224 ... 7168 (Q = 7), 672 ... 5376 (21), 1120 ... 4480 (35), 1568 ... 6272 (49)  (4320 = 32 * 135 and 8640 have z lines
+    // of 720, 432, 240, 180, 144: a workgroup of 8 rows x 135 sub-lines would be 1080 threads)
     ZC(16, 7, 4) ZC(32, 7, 4) ZC(64, 7, 4) ZC(128, 7, 2) ZC(256, 7, 1)
     ZC(16, 21, 4) ZC(32, 21, 2) ZC(64, 21, 1)
     ZC(16, 35, 2) ZC(32, 35, 1)
@@ -628,12 +628,12 @@ static int launch_xfft_q_t(const EpiConst &ec, const cplx *tw, const void *ring,
     X(32, 45, 8) X(64, 45, 4) X(128, 45, 2)                                                                                \
     X(32, 75, 4) X(64, 75, 2)                                                                                              \
     X(32, 125, 4) X(64, 125, 2)                                                                                            \
-    /* radix 7 (round 4): 224 ... 7168, 672 ... 5376, 1120 ... 4480, 1568 ... 6272; 4320 = 32 * 135 */                     \
+    /* radix 7 (round 4): 224 ... 7168, 672 ... 5376, 1120 ... 4480, 1568 ... 6272; 4320, 8640 = 2^a * 135 */                   \
     X(32, 7, 16) X(64, 7, 16) X(128, 7, 16) X(256, 7, 8) X(512, 7, 4) X(1024, 7, 2)                                        \
     X(32, 21, 16) X(64, 21, 8) X(128, 21, 4) X(256, 21, 2)                                                                 \
     X(32, 35, 8) X(64, 35, 4) X(128, 35, 2)                                                                                \
     X(32, 49, 8) X(64, 49, 4) X(128, 49, 2)                                                                                \
-    X(32, 135, 2)
+    X(32, 135, 2) X(64, 135, 1)
 int launch_yfft_fields_np2(const FieldLayout &F, const StoreLayout &S, const void *tw, const void *store, int plane0, int nplanes,
                            int ring_pitch, void *ring, int dens, hipStream_t st) {
 #define YC(p, q, w) \
@@ -746,7 +746,7 @@ int launch_test_fftq(int n, int kind, const void *twP, const void *twN, const vo
     TC(16, 16, 15, 4) TC(64, 16, 15, 4) TC(16, 16, 25, 4) TC(128, 16, 25, 4) TC(16, 16, 45, 4) TC(32, 16, 75, 4) TC(16, 16, 125, 4) TC(32, 16, 125, 4)
     TC(8, 8, 5, 4) TC(8, 8, 25, 4) TC(8, 8, 125, 4)
     TC(8, 8, 7, 4) TC(16, 16, 7, 4) TC(64, 16, 7, 4) TC(256, 16, 7, 4) TC(1024, 16, 7, 2) TC(16, 16, 21, 4) TC(128, 16, 21, 4) TC(16, 16, 35, 4)
-    TC(64, 16, 35, 4) TC(16, 16, 49, 4) TC(128, 16, 49, 2) TC(16, 16, 135, 4) TC(32, 16, 135, 2)
+    TC(64, 16, 35, 4) TC(16, 16, 49, 4) TC(128, 16, 49, 2) TC(16, 16, 135, 4) TC(32, 16, 135, 2) TC(64, 16, 135, 1)
     TC(1024, 16, 3, 4)
 #undef TC
     fprintf(stderr, "zeldovich_hip: no composite FFT for length %d\n", n);
