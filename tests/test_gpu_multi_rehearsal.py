@@ -140,7 +140,7 @@ def test_pipelined_passes_on_the_loopback_emulation(zd, oracle, ngpu, n, kw):
 
 @pytest.mark.parametrize("kw", [
     dict(stream_factor=8),                                   # ZA field store: 4 passes of two residues
-    dict(stream_factor=4, plt=True, fmt="RVdoubleZel"),      # PLT: 4 passes
+    dict(stream_factor=4, plt=True),                         # PLT: 4 passes
     dict(stream_factor=4, store_mode="reference"),           # reference arrays
 ])
 def test_one_rank_two_stores_equal_one_store(zd, oracle, kw):
@@ -149,7 +149,7 @@ def test_one_rank_two_stores_equal_one_store(zd, oracle, kw):
     the one-store run of the same plan exactly (same kernels, same order of the sums), and the records those of zd_generate."""
     import torch
     kw = dict(kw)
-    n, fmt = 128, kw.pop("fmt", "RVZel")
+    n, fmt = 256, kw.pop("fmt", "RVZel")
     ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
     eig = None
     if kw.pop("plt", False):
