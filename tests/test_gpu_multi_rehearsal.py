@@ -145,8 +145,8 @@ def test_pipelined_passes_on_the_loopback_emulation(zd, oracle, ngpu, n, kw):
 ])
 def test_one_rank_two_stores_equal_one_store(zd, oracle, kw):
     """ONE rank, zd_plan_run_passes with a second store (the branch behind `bench.py --two-stores`): the Z stage of pass p + 1 is
-    issued beside the y / x stages of pass p, on its own stream into the other store.  Every record and the reductions must equal
-    the one-store run of the same plan exactly (same kernels, same order of the sums), and the records those of zd_generate."""
+    issued beside the y / x stages of pass p, on its own stream into the other store.  Every record and max_disp must equal
+    the one-store run of the same plan exactly (same kernels), and the records those of zd_generate."""
     import torch
     kw = dict(kw)
     n, fmt = 256, kw.pop("fmt", "RVZel")
@@ -186,7 +186,8 @@ def test_one_rank_two_stores_equal_one_store(zd, oracle, kw):
     assert sorted(a) == sorted(b) == list(range(n))
     for z in range(n):
         assert a[z].tobytes() == b[z].tobytes(), z
-    assert sa["density_variance"] == sb["density_variance"] and np.array_equal(sa["max_disp"], sb["max_disp"])
+    assert abs(sa["density_variance"] - sb["density_variance"]) <= 1e-13 * sa["density_variance"]  # (atomic adds: the order of the sum is free)
+    assert np.array_equal(sa["max_disp"], sb["max_disp"])
     ref = zd.generate(p, ps, eig=eig)
     for z in range(n):
         assert ref["records"][z].reshape(n, n).tobytes() == b[z].tobytes(), z
