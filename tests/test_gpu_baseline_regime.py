@@ -120,6 +120,42 @@ def test_table_generator_arithmetic_vs_oracle(zd, oracle, n, box, fix):
 
 
 # ---- (b) full-size exact checks through the oversampling invariant ------------------------------------------------
+# One block store for the runs of _planes, kept from test to test: hipMalloc + hipFree of a 140-236 GB store cost 5-10 s per run, more than
+# the kernels of the one or two passes a test executes (the suite has ~60 such runs).  It grows when a plan needs more, and is
+# released before every test of this module that does not go through _planes (those allocate inside the library) and at the end.
+_STORE = {"t": None}
+_STORE_USERS = {"test_oversampled_planes_exact_at_full_size", "test_radix7_oversampled_planes", "test_ppd16384_k_cutoff4_planes_equal_ppd4096",
+                "test_large_plt_plane_waves_and_stream_invariance", "test_ppd6912_on_one_gpu_plane_waves"}
+
+
+def _drop_store():
+    if _STORE["t"] is not None:
+        import torch
+        _STORE["t"] = None
+        torch.cuda.empty_cache()
+
+
+def _store_tensor(nbytes):
+    import torch
+    if _STORE["t"] is None or _STORE["t"].numel() < nbytes:
+        _drop_store()
+        _STORE["t"] = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    return _STORE["t"]
+
+
+@pytest.fixture(autouse=True)
+def _store_cache_guard(request):
+    if request.node.originalname not in _STORE_USERS:
+        _drop_store()
+    yield
+
+
+@pytest.fixture(autouse=True, scope="module")
+def _store_cache_end():
+    yield
+    _drop_store()
+
+
 def _planes(zd, ps, n, zs, stride=1, eig=None, fmt="Zeldovich", **kw):
     """records of the z planes `zs` of a PPD = n run: only the passes that hold them are executed; stride > 1: only every
     stride-th lattice site of a plane leaves the GPU (a PPD = 16384 plane of records is 8.6 GB)"""
@@ -127,10 +163,11 @@ def _planes(zd, ps, n, zs, stride=1, eig=None, fmt="Zeldovich", **kw):
     p = zd.make_params(n, icformat=fmt, **kw)
     if p.stream_factor <= 0:
         free_b, _ = torch.cuda.mem_get_info()
-        p.stream_factor = zd.load_library().zd_choose_stream_factor(C.byref(p), 1, int(free_b) - (24 << 30))
+        held = 0 if _STORE["t"] is None else _STORE["t"].numel()  # (the cached store is this run's to use)
+        p.stream_factor = zd.load_library().zd_choose_stream_factor(C.byref(p), 1, int(free_b) + held - (24 << 30))
         assert p.stream_factor > 0
     plan = zd.Plan(p, ps, eig=eig)
-    store = torch.empty(plan.exchange_bytes, dtype=torch.uint8, device="cuda")
+    store = _store_tensor(plan.exchange_bytes)
     dt = zd.RECORD_DTYPES[fmt]
     step = plan.plane_step
     out = torch.empty(step * n * n * dt.itemsize, dtype=torch.uint8, device="cuda")
@@ -153,7 +190,6 @@ def _planes(zd, ps, n, zs, stride=1, eig=None, fmt="Zeldovich", **kw):
     info = dict(R=plan.R, passes=plan.passes, narray=plan.narray)
     plan.close()
     del store, out
-    torch.cuda.empty_cache()
     return res, info
 
 
@@ -163,13 +199,13 @@ def test_oversampled_planes_exact_at_full_size(zd, n):
     4096 <-> 2048: C3 size; 6912 <-> 3456: the production Abacus size 6912 = 2^8 3^3 on the composite-transform kernels;
     2000 <-> 1000: the any-PPD convolution kernels, zd_kernels_any.hip; 4000 (= 32 * 125: radix-5 composite kernels, round 3) <-> 2000
     (convolution kernels): two transform families against each other),
-    records compared exactly (1e-13 of the field maximum) on planes of different passes.
+    records compared exactly (1e-13 of the field maximum) on planes of three different passes.
     The links 2048 <-> 1024 <-> 512 <-> 256 close the chain: PPD = 512 and 256 are compared with the ORACLE record by record
     on the same default store (test_ppd512_za_default_store_vs_oracle, test_za_extrapolated_pk_vs_oracle), so every BASELINE
     size is tied to an oracle-checked run through exact links of HIP runs at different sizes (different z / y / x kernels
     and stream factors at each size)"""
     ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
-    zs = [5, n // 2 + 3, n - 2] if n < 2000 else [5, n // 2 + 3]  # (planes of different passes; two of them at the big sizes: suite time)
+    zs = [5, n // 2 + 3, n - 2]
     lo, ilo = _planes(zd, ps, n, zs)
     hi, ihi = _planes(zd, ps, 2 * n, [2 * z for z in zs], k_cutoff=2.0)
     print("PPD", n, ilo, "PPD", 2 * n, ihi)
@@ -194,7 +230,7 @@ def test_radix7_oversampled_planes(zd, n):
     Q = 7: 224 <-> 448 <-> 896 <-> 1792 <-> 3584 <-> 7168;  Q = 21: 336c <-> 672 <-> 1344 <-> 2688 <-> 5376;
     Q = 35: 560c <-> 1120 <-> 2240 <-> 4480;  Q = 49: 784c <-> 1568 <-> 3136 <-> 6272;  Q = 135: 2160c <-> 4320 <-> 8640 (= 64 * 135: beyond 8192, y tiles one column wide)."""
     ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
-    zs = [5, n // 2 + 3, n - 2] if n < 800 else [n // 2 + 3]
+    zs = [5, n // 2 + 3, n - 2] if n < 3000 else [5, n // 2 + 3]
     comp = n not in (336, 560, 784, 2160)
     lo, ilo = _planes(zd, ps, n, zs, **(dict(stream_factor=2) if comp and n <= 2688 else {}))  # R = 2: the longest z lines one GPU holds
     hi, ihi = _planes(zd, ps, 2 * n, [2 * z for z in zs], k_cutoff=2.0)
@@ -228,8 +264,8 @@ def test_ppd16384_k_cutoff4_planes_equal_ppd4096(zd):
 
 
 @pytest.mark.parametrize("n,kc,Ra,Rb,modes", [
-    (2048, 1.0, 2, 4, [(-401, 577, 600), (0, 2, 0)]),                    # BASELINE C3: packed PLT arrays (k_genf PLTN / k_zfft / k_yfft / k_xfft)
-    (4096, 1.0, 16, 32, [(3, 5, -7), (-1001, 777, 1200)]),              # PLT at the headline grid: k_genf PLTN + k_eig_lines at 4096 / k_zfft<256|128> / k_yfft<4096> / k_xfft_seq_plt<4096,16,true>
+    (2048, 1.0, 2, 4, [(3, 5, -7), (-401, 577, 600), (0, 2, 0)]),          # BASELINE C3: packed PLT arrays (k_genf PLTN / k_zfft / k_yfft / k_xfft)
+    (4096, 1.0, 16, 32, [(3, 5, -7), (-1001, 777, 1200), (0, 2, 0)]),    # PLT at the headline grid: k_genf PLTN + k_eig_lines at 4096 / k_zfft<256|128> / k_yfft<4096> / k_xfft_seq_plt<4096,16,true>
     (8192, 2.0, 64, 128, [(3, 5, -7), (-1001, 777, 1200), (0, 2, 0)]),   # k_xfft_two<8192, PLT>
     (6912, 4.0, 8, 16, [(3, 5, -7), (-401, 377, 500)]),                  # composite kernels, x pass in two launches
     (3456, 2.0, 4, 8, [(-3, 5, 7), (401, 377, -500)]),                   # composite kernels, three lines per workgroup
