@@ -124,7 +124,8 @@ def test_table_generator_arithmetic_vs_oracle(zd, oracle, n, box, fix):
 # the kernels of the one or two passes a test executes (the suite has ~60 such runs).  It grows when a plan needs more, and is
 # released before every test of this module that does not go through _planes (those allocate inside the library) and at the end.
 _STORE = {"t": None}
-_STORE_USERS = {"test_oversampled_planes_exact_at_full_size", "test_radix7_oversampled_planes", "test_ppd16384_k_cutoff4_planes_equal_ppd4096",
+_STORE_USERS = {"test_oversampled_planes_exact_at_full_size", "test_radix7_oversampled_planes", "test_smooth_sizes_oversampled_planes",
+                "test_plt_one_mode_at_every_composite_size", "test_ppd16384_k_cutoff4_planes_equal_ppd4096",
                 "test_large_plt_plane_waves_and_stream_invariance", "test_ppd6912_on_one_gpu_plane_waves"}
 
 
@@ -245,6 +246,77 @@ def test_radix7_oversampled_planes(zd, n):
         err = np.abs(a["d"] - b["d"]).max() / scale
         print("  z", z, "max |d(2n, even sites) - d(n)| / max|d| =", err)
         assert err < 1e-12
+
+
+@pytest.mark.parametrize("n", [192, 384, 768, 1536, 1152, 2304, 320, 1280, 2560, 960, 1920, 3840, 1600, 3200, 720, 1440, 2880, 1200, 2400, 4000])
+def test_smooth_sizes_oversampled_planes(zd, n):
+    """The 3- and 5-smooth composite grids of rounds 2 and 3 that had no run AT their size in the suite (found with zd_dispatch_report:
+    384, 640, 768, 1440, 1536, 1920, 2304, 2400, 2560, 2880, 3072, 3200, 3840, 4608, 4800, 5120, 5760, 6400, 7680, 8000 — their
+    (P, Q) engines were covered by test_fft_lines_*, their y / x / z kernels were not): PPD = 2n with ZD_k_cutoff = 2 at even sites
+    == PPD = n, as test_radix7_oversampled_planes.  The lower ends hang on runs checked elsewhere: 192, 320 against the oracle, 960,
+    1152, 1280, 1600, 4000 through links of test_gpu_parity.py / test_oversampled_planes_exact_at_full_size, 720 and 1200 on the
+    convolution kernels (P = 16)."""
+    ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
+    zs = [5, n // 2 + 3, n - 2] if n < 3000 else [5, n // 2 + 3]
+    comp = n not in (720, 1200)
+    lo, ilo = _planes(zd, ps, n, zs)
+    hi, ihi = _planes(zd, ps, 2 * n, [2 * z for z in zs], k_cutoff=2.0)
+    print("PPD", n, ilo, "PPD", 2 * n, ihi)
+    assert ihi["narray"] == 3 and (ilo["narray"] == 3) == comp
+    for z in zs:
+        a, b = lo[z], hi[2 * z][::2, ::2]
+        assert np.array_equal(b["ijk"][..., 0], np.full((n, n), 2 * z))
+        assert np.array_equal(2 * a["ijk"][..., 1:].astype(np.int64), b["ijk"][..., 1:].astype(np.int64))
+        scale = np.abs(a["d"]).max()
+        assert scale > 0
+        err = np.abs(a["d"] - b["d"]).max() / scale
+        print("  z", z, "max |d(2n, even sites) - d(n)| / max|d| =", err)
+        assert err < 1e-12
+
+
+def _np2_sizes():
+    """the (P, Q) of csrc/zd_kernels_np2.hip NP2_SIZES = every PPD the composite kernels are instantiated for"""
+    import re
+    src = open(os.path.join(ROOT, "zeldovich_plt_amd", "csrc", "zd_kernels_np2.hip")).read()
+    body = re.search(r"#define NP2_SIZES\(X\)(.*?)\nint launch_yfft_fields_np2", src, re.S).group(1)
+    return sorted(int(p_) * int(q) for p_, q, _w in re.findall(r"X\((\d+), (\d+), (\d+)\)", body))
+
+
+@pytest.mark.parametrize("n", [n for n in _np2_sizes() if n <= 8192])
+def test_plt_one_mode_at_every_composite_size(zd, oracle, n):
+    """PLT + rescale on EVERY composite grid the library has kernels for (the PLT field store's x kernels k_xfft_q3<.., true> /
+    k_xfft_seq_q<.., true> are separate instantiations per size; until round 4 only 96 ... 288, 160, 3456 and 6912 ran with PLT):
+    a one-mode run against the closed form built from the ORACLE's per-mode pieces, every displacement and velocity component of a
+    plane at every 8th site (see test_large_plt_plane_waves_and_stream_invariance), at the stream factor the library chooses."""
+    ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
+    opk = oracle.pk_from_file(WMAP, 720.0)
+    eig = oracle.synthetic_eigenmodes(32)
+    z = n // 2 + 3
+    fc, ztar, zini = 0.97, 5.0, 49.0
+    kw = dict(qPLT=1, qPLTrescale=1, PLT_target_z=ztar, z_initial=zini, f_cluster=fc, fmt="RVdoubleZel", eig=eig)
+    op = oracle.make_params(n, qPLT=1, qPLTrescale=1, PLT_target_z=ztar, z_initial=zini, f_cluster=fc)
+    L = oracle.lib()
+    fund = 2 * np.pi / 720.0
+    mode = (-(n // 5) - 1, n // 7 + 2, n // 3 + 1)
+    yy, xx = np.meshgrid(np.arange(0, n, 8), np.arange(0, n, 8), indexing="ij")
+    got, info = _planes(zd, ps, n, [z], stride=8, qonemode=1, one_mode=mode, **kw)
+    assert info["narray"] == 3  # the PLT field store of the composite kernels
+    r, D, e = (C.c_uint64 * 2)(), (C.c_double * 2)(), (C.c_double * 4)()
+    L.zdo_mode_draw(C.byref(op), C.byref(opk), mode[0], mode[1], mode[2], r, D)
+    L.zdo_get_eigenmode(eig.ctypes.data, eig.shape[0], mode[0], mode[1], mode[2], n, 1, e)
+    f = (np.sqrt(1 + 24 * e[3] * fc) - 1) / 4
+    target_f = (np.sqrt(1 + 24 * fc) - 1) / 4
+    rescale = ((1 / (1 + ztar)) / (1 / (1 + zini))) ** (target_f - f)
+    k2 = sum(m * m for m in mode) * fund * fund
+    t = 2 * np.pi * ((mode[0] * xx + mode[1] * yy + mode[2] * z) % n) / n
+    wave = -2.0 * (D[0] * np.sin(t) + D[1] * np.cos(t))
+    rec = got[z]
+    scale = max(abs(rescale * e[j] * fund / k2) for j in range(3)) * np.abs(wave).max()
+    assert scale > 0
+    for j in range(3):
+        want = rescale * e[j] * fund / k2 * wave
+        assert np.abs(rec["d"][..., 2 - j] - want).max() <= 1e-12 * scale, (mode, j)
+        assert np.abs(rec["v"][..., 2 - j] - f * want).max() <= 1e-12 * f * scale, (mode, j)
 
 
 def test_ppd16384_k_cutoff4_planes_equal_ppd4096(zd):
