@@ -140,7 +140,11 @@ def _store_tensor(nbytes):
     import torch
     if _STORE["t"] is None or _STORE["t"].numel() < nbytes:
         _drop_store()
-        _STORE["t"] = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        size = nbytes
+        if nbytes > (64 << 30):  # a big store: take at once what the following big runs will ask for, leaving 28 GB to the plans themselves
+            free_b, _ = torch.cuda.mem_get_info()
+            size = max(nbytes, min(236 << 30, int(free_b) - (28 << 30)))
+        _STORE["t"] = torch.empty(size, dtype=torch.uint8, device="cuda")
     return _STORE["t"]
 
 
