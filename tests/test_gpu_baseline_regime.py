@@ -125,7 +125,7 @@ def test_table_generator_arithmetic_vs_oracle(zd, oracle, n, box, fix):
 # released before every test of this module that does not go through _planes (those allocate inside the library) and at the end.
 _STORE = {"t": None}
 _STORE_USERS = {"test_oversampled_planes_exact_at_full_size", "test_radix7_oversampled_planes", "test_smooth_sizes_oversampled_planes",
-                "test_plt_one_mode_at_every_composite_size", "test_ppd16384_k_cutoff4_planes_equal_ppd4096",
+                "test_plt_one_mode_at_every_composite_size", "test_z_lines_of_180", "test_ppd16384_k_cutoff4_planes_equal_ppd4096",
                 "test_large_plt_plane_waves_and_stream_invariance", "test_ppd6912_on_one_gpu_plane_waves"}
 
 
@@ -276,6 +276,20 @@ def test_smooth_sizes_oversampled_planes(zd, n):
         err = np.abs(a["d"] - b["d"]).max() / scale
         print("  z", z, "max |d(2n, even sites) - d(n)| / max|d| =", err)
         assert err < 1e-12
+
+
+def test_z_lines_of_180(zd):
+    """z lines of 180 = 4 * 45 (the one 4 * Q form of launch_zfft_fields_np2 no other test reaches; PPD = 8640 takes it at R = 48):
+    PPD = 1440 at R = 8 against R = 2 (z lines of 720 = 16 * 45) on sample planes"""
+    ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
+    n, zs = 1440, [3, 725, 1438]
+    a, ia = _planes(zd, ps, n, zs, stream_factor=2)
+    b, ib = _planes(zd, ps, n, zs, stream_factor=8)
+    assert ia["R"] == 2 and ib["R"] == 8 and ia["narray"] == ib["narray"] == 3
+    for z in zs:
+        assert np.array_equal(a[z]["ijk"], b[z]["ijk"])
+        assert np.abs(a[z]["d"]).max() > 0
+        assert np.abs(a[z]["d"] - b[z]["d"]).max() <= 1e-12 * np.abs(a[z]["d"]).max(), z
 
 
 def _np2_sizes():

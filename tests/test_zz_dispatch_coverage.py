@@ -92,8 +92,7 @@ EXPECTED = [
     ("8640 ZA", "launch_yfft_fq_t", "P = 64, E = 16, Q = 135,"),
     ("8640 ZA", "launch_xfft_q_t", "P = 64, E = 16, Q = 135, PLT = false"),
     ("3584 PLT", "launch_xfft_q_t", "P = 512, E = 16, Q = 7, PLT = true"),
-    # ... and their z lines (L = 1792 and 1568 need a store beyond one GPU's memory: several GPUs only; same LineQ engine, tested by
-    # test_fft_lines_radix7_lengths)
+    # ... and their z lines (all of launch_zfft_fields_np2's table is checked below)
     ("z lines of 112", "launch_zfft_fq_t", "P = 16, E = 16, Q = 7,"),
     ("z lines of 224", "launch_zfft_fq_t", "P = 32, E = 16, Q = 7,"),
     ("z lines of 448", "launch_zfft_fq_t", "P = 64, E = 16, Q = 7,"),
@@ -144,3 +143,22 @@ def test_every_shipped_kernel_variant_was_launched_by_the_suite():
     for N, E, W in re.findall(r"YCASE\((\d+), (\d+), (\d+)\)", table):
         want = "N = %s, E = %s, W = %s," % (N, E, W)
         assert any("launch_yfft_f_t" in name and want in name for (name, _l) in rep), "k_yfft_f<%s> never launched" % want
+    # ... and the composite tables of zd_kernels_np2.hip in full (round 4: the report showed 20 sizes of rounds 2-3 that no test ran at
+    # their size, and PLT at almost none): every (P, Q) of NP2_SIZES through the y launcher and both x launchers (PLT only up to 8192:
+    # beyond, the plan takes the ZA field store alone), every z length of launch_zfft_fields_np2
+    txt = open(os.path.join(ROOT, "zeldovich_plt_amd", "csrc", "zd_kernels_np2.hip")).read()
+    body = re.search(r"#define NP2_SIZES\(X\)(.*?)\nint launch_yfft_fields_np2", txt, re.S).group(1)
+    sizes = [(int(p_), int(q), int(w)) for p_, q, w in re.findall(r"X\((\d+), (\d+), (\d+)\)", body)]
+    assert len(sizes) >= 55
+    names = [name for (name, _l), cnt in rep.items() if cnt > 0]
+    for p_, q, w in sizes:
+        assert any("launch_yfft_fq_t" in nm and "[P = %d, E = 16, Q = %d, W = %d]" % (p_, q, w) in nm for nm in names), ("y", p_ * q)
+        assert any("launch_xfft_q_t" in nm and "[P = %d, E = 16, Q = %d, PLT = false]" % (p_, q) in nm for nm in names), ("x ZA", p_ * q)
+        if p_ * q <= 8192:
+            assert any("launch_xfft_q_t" in nm and "[P = %d, E = 16, Q = %d, PLT = true]" % (p_, q) in nm for nm in names), ("x PLT", p_ * q)
+    ztab = re.search(r"int launch_zfft_fields_np2\(.*?\n}\n", txt, re.S).group(0)
+    zl = [(int(p_), 16, int(q), int(nc)) for p_, q, nc in re.findall(r"ZC\((\d+), (\d+), (\d+)\)", ztab)]
+    zl += [(int(p_), int(e), int(q), int(nc)) for p_, e, q, nc in re.findall(r"launch_zfft_fq_t<(\d+), (\d+), (\d+), (\d+)>\(F, S", ztab)]
+    assert len(zl) >= 45
+    for p_, e, q, nc in zl:
+        assert any("launch_zfft_fq_t" in nm and "[P = %d, E = %d, Q = %d, NC = %d]" % (p_, e, q, nc) in nm for nm in names), ("z", p_ * q)
