@@ -125,7 +125,8 @@ def test_table_generator_arithmetic_vs_oracle(zd, oracle, n, box, fix):
 # released before every test of this module that does not go through _planes (those allocate inside the library) and at the end.
 _STORE = {"t": None}
 _STORE_USERS = {"test_oversampled_planes_exact_at_full_size", "test_radix7_oversampled_planes", "test_smooth_sizes_oversampled_planes",
-                "test_plt_one_mode_at_every_composite_size", "test_z_lines_of_180", "test_ppd16384_k_cutoff4_planes_equal_ppd4096",
+                "test_plt_one_mode_at_every_composite_size", "test_z_lines_of_180", "test_density_one_mode_at_every_composite_size",
+                "test_reference_and_packed_arrays_at_large_sizes", "test_ppd16384_k_cutoff4_planes_equal_ppd4096",
                 "test_large_plt_plane_waves_and_stream_invariance", "test_ppd6912_on_one_gpu_plane_waves"}
 
 
@@ -161,9 +162,10 @@ def _store_cache_end():
     _drop_store()
 
 
-def _planes(zd, ps, n, zs, stride=1, eig=None, fmt="Zeldovich", **kw):
+def _planes(zd, ps, n, zs, stride=1, eig=None, fmt="Zeldovich", want_density=False, **kw):
     """records of the z planes `zs` of a PPD = n run: only the passes that hold them are executed; stride > 1: only every
-    stride-th lattice site of a plane leaves the GPU (a PPD = 16384 plane of records is 8.6 GB)"""
+    stride-th lattice site of a plane leaves the GPU (a PPD = 16384 plane of records is 8.6 GB).  want_density (ZD_qdensity = 1):
+    the float32 density planes too, as res["density"][z]"""
     import torch
     p = zd.make_params(n, icformat=fmt, **kw)
     if p.stream_factor <= 0:
@@ -176,6 +178,7 @@ def _planes(zd, ps, n, zs, stride=1, eig=None, fmt="Zeldovich", **kw):
     dt = zd.RECORD_DTYPES[fmt]
     step = plan.plane_step
     out = torch.empty(step * n * n * dt.itemsize, dtype=torch.uint8, device="cuda")
+    dens = torch.empty(step * n * n, dtype=torch.float32, device="cuda") if want_density else None
     where = {}
     for ps_ in range(plan.passes):
         for lp in range(plan.local_planes):
@@ -188,13 +191,15 @@ def _planes(zd, ps, n, zs, stride=1, eig=None, fmt="Zeldovich", **kw):
         plan.stage_z(pass_, store.data_ptr())
         plan.stage_y(store.data_ptr())
         first = lp // step * step
-        plan.stage_x(pass_, store.data_ptr(), first, step, out.data_ptr())
+        plan.stage_x(pass_, store.data_ptr(), first, step, out.data_ptr(), d_density=None if dens is None else dens.data_ptr())
         torch.cuda.synchronize()
         sel = out.view(step, n, n, dt.itemsize)[lp - first, ::stride, ::stride].contiguous()
         res[z] = sel.cpu().numpy().view(dt).reshape(n // stride, n // stride).copy()
+        if dens is not None:
+            res.setdefault("density", {})[z] = dens.view(step, n, n)[lp - first, ::stride, ::stride].cpu().numpy().copy()
     info = dict(R=plan.R, passes=plan.passes, narray=plan.narray)
     plan.close()
-    del store, out
+    del store, out, dens
     return res, info
 
 
@@ -335,6 +340,104 @@ def test_plt_one_mode_at_every_composite_size(zd, oracle, n):
         want = rescale * e[j] * fund / k2 * wave
         assert np.abs(rec["d"][..., 2 - j] - want).max() <= 1e-12 * scale, (mode, j)
         assert np.abs(rec["v"][..., 2 - j] - f * want).max() <= 1e-12 * f * scale, (mode, j)
+
+
+@pytest.mark.parametrize("n", _np2_sizes())
+def test_density_one_mode_at_every_composite_size(zd, oracle, n):
+    """ZA with ZD_qdensity = 1 on EVERY composite grid (six-field store: generator kind ZAFD, the density call of the y kernel and
+    k_xdens_q<P, 16, Q> are instantiated per size; round 4 tested them at 96 ... 480 only): a one-mode run against the closed forms
+    q_j(x) = -2 (k_j fund / k^2) (Re D sin t + Im D cos t), v = vnorm q and delta(x) = 2 (Re D cos t - Im D sin t) = -div q, with D(k)
+    from the oracle's per-mode draw; the density plane is float32 (src/output.cpp:217-224).  (The small sizes of the list also run
+    against the oracle with random fields: test_density_on_composite_grids_vs_oracle — which pins these closed forms.)"""
+    ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
+    opk = oracle.pk_from_file(WMAP, 720.0)
+    fc = 0.93
+    op = oracle.make_params(n, f_cluster=fc)
+    fund = 2 * np.pi / 720.0
+    vnorm = (np.sqrt(1 + 24 * fc) - 1) / 4
+    z = n // 2 + 3
+    mode = (n // 7 + 1, -(n // 5) - 2, -(n // 3) + 1)
+    yy, xx = np.meshgrid(np.arange(0, n, 8), np.arange(0, n, 8), indexing="ij")
+    got, info = _planes(zd, ps, n, [z], stride=8, fmt="RVdoubleZel", f_cluster=fc, qonemode=1, one_mode=mode, qdensity=1, want_density=True)
+    assert info["narray"] == 3  # the six-field store of the composite kernels, not the reference arrays of the convolution path
+    r, D = (C.c_uint64 * 2)(), (C.c_double * 2)()
+    oracle.lib().zdo_mode_draw(C.byref(op), C.byref(opk), mode[0], mode[1], mode[2], r, D)
+    k2 = sum(m * m for m in mode) * fund * fund
+    t = 2 * np.pi * ((mode[0] * xx + mode[1] * yy + mode[2] * z) % n) / n
+    wave = -2.0 * (D[0] * np.sin(t) + D[1] * np.cos(t))
+    scale = max(abs(m) for m in mode) * fund / k2 * np.abs(wave).max()
+    rec = got[z]
+    for j in range(3):
+        want = mode[j] * fund / k2 * wave
+        assert np.abs(rec["d"][..., 2 - j] - want).max() <= 1e-12 * scale, (mode, j)
+        assert np.abs(rec["v"][..., 2 - j] - vnorm * want).max() <= 1e-12 * vnorm * scale, (mode, j)
+    delta = 2.0 * (D[0] * np.cos(t) - D[1] * np.sin(t))
+    assert np.abs(delta).max() > 0
+    assert np.abs(got["density"][z] - delta).max() <= 2e-7 * np.abs(delta).max()  # float32 planes
+
+
+@pytest.mark.parametrize("n,kc,base,other", [
+    (2048, 1.0, dict(), dict(store_mode="reference")),                                     # k_xfft<2048,16,2,.>, k_yfft<2048>, k_zfft<1024>
+    (2048, 1.0, dict(), dict(store_mode="packed")),                                        # ZA pairs: k_xfft<2048,16,3,.>
+    (4096, 1.0, dict(), dict(store_mode="reference", stream_factor=16)),                   # the reference's two arrays at the headline size
+    (4096, 1.0, dict(), dict(store_mode="packed", stream_factor=16)),
+    (4096, 1.0, dict(plt=True), dict(plt=True, store_mode="reference", stream_factor=32)),  # four arrays at 4096
+    (8192, 2.0, dict(), dict(store_mode="reference", stream_factor=128)),                  # k_yfft<8192>, k_xfft<8192,16,2,1>
+])
+def test_reference_and_packed_arrays_at_large_sizes(zd, oracle, n, kc, base, other):
+    """The reference's own block-array layout (`ZD_StoreMode = reference`: what ZD_qdensity, ZD_f_NL and the any-PPD path use) and the
+    round-1 packings at the sizes of BASELINE's configurations: the launchers launch_zfft_t / launch_yfft_t / launch_xfft_t<N, 16, NA>
+    had no run above PPD = 1024 except NA = 4 at 2048 (zd_dispatch_report).  A random plane must equal the default store's (field
+    stores / PLT3), which the oversampling chain and the direct sums tie to the oracle."""
+    ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
+    eig = oracle.synthetic_eigenmodes(128)
+    z = n // 2 + 3
+
+    def run(kw):
+        kw = dict(kw)
+        e = None
+        if kw.pop("plt", False):
+            e = eig
+            kw.update(qPLT=1, qPLTrescale=1, PLT_target_z=5.0, z_initial=49.0)
+        return _planes(zd, ps, n, [z], stride=4, fmt="RVdoubleZel", eig=e, k_cutoff=kc, **kw)
+
+    a, ia = run(base)
+    b, ib = run(other)
+    print(ia, ib)
+    assert ia["narray"] == 3 and ib["narray"] == (4 if other.get("plt") else (3 if other["store_mode"] == "packed" else 2))
+    assert np.array_equal(a[z]["ijk"], b[z]["ijk"])
+    for f_ in ("d", "v"):
+        assert np.abs(a[z][f_]).max() > 0
+        assert np.abs(a[z][f_] - b[z][f_]).max() <= 1e-12 * np.abs(a[z][f_]).max(), f_
+
+
+@pytest.mark.parametrize("n", [512, 1024, 2048, 4096])
+def test_density_only_runs_at_large_sizes(zd, n):
+    """ZD_qdensity = 2 (one array, no records: launch_xfft_t<N, 16, 1, .>) at the large powers of two: the variance of the density
+    planes it writes must equal the generator's sum of |D|^2 of the default ZA run (Parseval; src/output.cpp:225-228 sums the planes)"""
+    ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
+    a = zd.generate(zd.make_params(n, icformat="RVZel"), ps, collect=False)
+    b = zd.generate(zd.make_params(n, icformat="RVZel", qdensity=2), ps, collect=False)
+    assert a["density_variance"] > 0
+    assert abs(a["density_variance"] - b["density_variance"]) <= 2e-6 * a["density_variance"]  # float32 planes summed in double
+
+
+@pytest.mark.parametrize("n,R", [(256, 2), (1024, 4), (2048, 8)])
+def test_fnl_round_trip_identity_at_large_sizes(zd, n, R):
+    """The phi round of ZD_f_NL (inverse z / y / x transforms of phi = D / M, phi + f_NL phi^2, forward x / y / z transforms, D = phi M:
+    k_xphi / k_yfwd / k_zfwd, launch_fnl_t<N>) at sizes the oracle cannot run: with f_NL = 1e-300 the nonlinear term vanishes and
+    the second pass must reproduce the ordinary run — every record of sample planes to 1e-10 (src/zeldovich.cpp:699-790, 945-960).
+    PPD = 2048 is the largest size whose phi field (137 GB) fits one GPU."""
+    ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
+    zs = [3, n // 2 + 1]
+    kw = dict(fmt="RVdoubleZel", stream_factor=R, n_s=0.96, Omega_M=0.31)
+    a, ia = _planes(zd, ps, n, zs, stride=2, store_mode="reference", **kw)
+    b, ib = _planes(zd, ps, n, zs, stride=2, f_NL=1e-300, **kw)
+    assert ia["narray"] == ib["narray"] == 2
+    for z in zs:
+        for f_ in ("d", "v"):
+            assert np.abs(a[z][f_]).max() > 0
+            assert np.abs(a[z][f_] - b[z][f_]).max() <= 1e-10 * np.abs(a[z][f_]).max(), (z, f_)
 
 
 def test_ppd16384_k_cutoff4_planes_equal_ppd4096(zd):
