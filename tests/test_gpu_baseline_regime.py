@@ -356,7 +356,7 @@ def test_density_one_mode_at_every_composite_size(zd, oracle, n):
     fund = 2 * np.pi / 720.0
     vnorm = (np.sqrt(1 + 24 * fc) - 1) / 4
     z = n // 2 + 3
-    mode = (n // 7 + 1, -(n // 5) - 2, -(n // 3) + 1)
+    mode = (n // 7 + 1, n // 5 + 2, -(n // 3) + 1)  # (ky >= 0: the mode loop runs over the half space, src/zeldovich.cpp:333-340)
     yy, xx = np.meshgrid(np.arange(0, n, 8), np.arange(0, n, 8), indexing="ij")
     got, info = _planes(zd, ps, n, [z], stride=8, fmt="RVdoubleZel", f_cluster=fc, qonemode=1, one_mode=mode, qdensity=1, want_density=True)
     assert info["narray"] == 3  # the six-field store of the composite kernels, not the reference arrays of the convolution path
