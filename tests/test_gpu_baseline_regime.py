@@ -126,7 +126,7 @@ def test_table_generator_arithmetic_vs_oracle(zd, oracle, n, box, fix):
 _STORE = {"t": None}
 _STORE_USERS = {"test_oversampled_planes_exact_at_full_size", "test_radix7_oversampled_planes", "test_smooth_sizes_oversampled_planes",
                 "test_plt_one_mode_at_every_composite_size", "test_z_lines_of_180", "test_density_one_mode_at_every_composite_size",
-                "test_reference_and_packed_arrays_at_large_sizes", "test_ppd16384_k_cutoff4_planes_equal_ppd4096",
+                "test_reference_and_packed_arrays_at_large_sizes", "test_density_planes_of_the_reference_arrays_at_4096", "test_ppd16384_k_cutoff4_planes_equal_ppd4096",
                 "test_large_plt_plane_waves_and_stream_invariance", "test_ppd6912_on_one_gpu_plane_waves"}
 
 
@@ -411,7 +411,24 @@ def test_reference_and_packed_arrays_at_large_sizes(zd, oracle, n, kc, base, oth
         assert np.abs(a[z][f_] - b[z][f_]).max() <= 1e-12 * np.abs(a[z][f_]).max(), f_
 
 
-@pytest.mark.parametrize("n", [512, 1024, 2048, 4096])
+def test_density_planes_of_the_reference_arrays_at_4096(zd):
+    """ZD_qdensity at the headline size: the reference's two arrays + the density array (ZD_qdensity = 1: k_xfft<4096, 16, 2, .> with the
+    density epilogue) and the density array alone (ZD_qdensity = 2: k_xfft<4096, 16, 1, .>) must write the same float32 density plane,
+    and the records of the former must equal the default store's"""
+    ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
+    n, z = 4096, 4096 // 2 + 3
+    base, _ = _planes(zd, ps, n, [z], stride=4, fmt="RVZel")
+    a, ia = _planes(zd, ps, n, [z], stride=4, fmt="RVZel", qdensity=1, want_density=True)
+    b, ib = _planes(zd, ps, n, [z], stride=4, fmt="RVZel", qdensity=2, want_density=True)
+    assert ia["narray"] == 2 and ib["narray"] == 1
+    for f_ in ("d", "v"):
+        assert np.abs(base[z][f_]).max() > 0
+        assert np.abs(a[z][f_] - base[z][f_]).max() <= 1e-6 * np.abs(base[z][f_]).max()  # (RVZel: float32 records)
+    da, db = a["density"][z], b["density"][z]
+    assert np.abs(da).max() > 0 and np.abs(da - db).max() <= 2e-7 * np.abs(da).max()
+
+
+@pytest.mark.parametrize("n", [512, 1024, 2048])
 def test_density_only_runs_at_large_sizes(zd, n):
     """ZD_qdensity = 2 (one array, no records: launch_xfft_t<N, 16, 1, .>) at the large powers of two: the variance of the density
     planes it writes must equal the generator's sum of |D|^2 of the default ZA run (Parseval; src/output.cpp:225-228 sums the planes)"""

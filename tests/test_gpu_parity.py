@@ -812,8 +812,7 @@ def test_fft_lines_composite_lengths(zd, n, kind):
     (192, dict(stream_factor=4, k_cutoff=2.0)),
     (288, dict(stream_factor=2)),                              # 288 = 32 * 9
     (96, dict(stream_factor=2, fmt="Zeldovich", k_cutoff=1.5)),
-    (288, dict(stream_factor=6)),                              # a stream factor that is not a power of two: z lines of 48, 3 passes
-    (288, dict(stream_factor=6, ngpu=2, fmt="RVZel")),          # ... on two ranks that exchange (24 planes per rank and pass)
+    (288, dict(stream_factor=6, ngpu=2, fmt="RVZel")),          # a stream factor that is not a power of two (z lines of 48, 3 passes), on two ranks that exchange (24 planes per rank and pass)
     (288, dict(stream_factor=2, k_cutoff=2.0, fmt="ZelSimple")),  # (Q = 27 sizes start at 864: beyond the oracle's O(N^4) plain DFT;
                                                                   # covered by test_non_power_of_two_oversampling_invariance and test_non_power_of_two_short_z_lines)
 ])
