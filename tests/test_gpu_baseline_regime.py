@@ -377,6 +377,7 @@ def test_density_one_mode_at_every_composite_size(zd, oracle, n):
 
 
 @pytest.mark.parametrize("n,kc,base,other", [
+    (512, 1.0, dict(plt=True), dict(plt=True, store_mode="reference")),                     # k_xfft<512,16,4,.>
     (2048, 1.0, dict(), dict(store_mode="reference")),                                     # k_xfft<2048,16,2,.>, k_yfft<2048>, k_zfft<1024>
     (2048, 1.0, dict(), dict(store_mode="packed")),                                        # ZA pairs: k_xfft<2048,16,3,.>
     (4096, 1.0, dict(), dict(store_mode="reference", stream_factor=16)),                   # the reference's two arrays at the headline size
@@ -411,15 +412,16 @@ def test_reference_and_packed_arrays_at_large_sizes(zd, oracle, n, kc, base, oth
         assert np.abs(a[z][f_] - b[z][f_]).max() <= 1e-12 * np.abs(a[z][f_]).max(), f_
 
 
-def test_density_planes_of_the_reference_arrays_at_4096(zd):
-    """ZD_qdensity at the headline size: the reference's two arrays + the density array (ZD_qdensity = 1: k_xfft<4096, 16, 2, .> with the
-    density epilogue) and the density array alone (ZD_qdensity = 2: k_xfft<4096, 16, 1, .>) must write the same float32 density plane,
-    and the records of the former must equal the default store's"""
+@pytest.mark.parametrize("n,kc", [(4096, 1.0), (8192, 2.0)])
+def test_density_planes_of_the_reference_arrays_at_4096(zd, n, kc):
+    """ZD_qdensity at the headline size (and at 8192, BASELINE C5's grid): the reference's two arrays + the density array (ZD_qdensity = 1:
+    k_xfft<N, 16, 2, .> with the density epilogue) and the density array alone (ZD_qdensity = 2: k_xfft<N, 16, 1, .>) must write the same
+    float32 density plane, and the records of the former must equal the default store's"""
     ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
-    n, z = 4096, 4096 // 2 + 3
-    base, _ = _planes(zd, ps, n, [z], stride=4, fmt="RVZel")
-    a, ia = _planes(zd, ps, n, [z], stride=4, fmt="RVZel", qdensity=1, want_density=True)
-    b, ib = _planes(zd, ps, n, [z], stride=4, fmt="RVZel", qdensity=2, want_density=True)
+    z = n // 2 + 3
+    base, _ = _planes(zd, ps, n, [z], stride=4, fmt="RVZel", k_cutoff=kc)
+    a, ia = _planes(zd, ps, n, [z], stride=4, fmt="RVZel", qdensity=1, want_density=True, k_cutoff=kc)
+    b, ib = _planes(zd, ps, n, [z], stride=4, fmt="RVZel", qdensity=2, want_density=True, k_cutoff=kc)
     assert ia["narray"] == 2 and ib["narray"] == 1
     for f_ in ("d", "v"):
         assert np.abs(base[z][f_]).max() > 0

@@ -226,6 +226,24 @@ def test_density_only(zd, oracle, ps, opk):
     _compare(zd, oracle, ps, opk, 64, qdensity=2)
 
 
+@pytest.mark.parametrize("kw", [dict(qdensity=2), dict(store_mode="packed"), dict(plt=True, store_mode="reference"), dict(plt=True),
+                                dict(f_NL=2.0e4)])
+def test_smallest_grid_every_store(zd, oracle, ps, opk, wmap_path, kw):
+    """PPD = 32, the smallest grid of the dispatch tables (launch_xfft_t<32, 16, 1 | 3 | 4, .>, launch_fnl_t<32>: no other test ran
+    them at this size): density only, the packed stores, PLT on the reference's four arrays, f_NL — against the oracle"""
+    import ctypes as C
+    kw = dict(kw)
+    eig = None
+    if kw.pop("plt", False):
+        eig = oracle.synthetic_eigenmodes(16)
+        kw.update(qPLT=1, qPLTrescale=1, PLT_target_z=5.0, f_cluster=0.97)
+    if "f_NL" in kw:
+        kw.update(n_s=0.96, Omega_M=0.31)
+        opk = oracle.pk_from_file(wmap_path, 720.0)
+        oracle.lib().zdo_pk_set_primordial(C.byref(opk), 0.96)
+    _compare(zd, oracle, ps, opk, 32, eig=eig, **kw)
+
+
 def test_one_mode_and_fixed_power(zd, oracle, wmap_path):
     ps2 = zd.PowerSpectrum.from_file(wmap_path, 720.0, fix_to_mean=1)
     opk2 = oracle.pk_from_file(wmap_path, 720.0, fix_to_mean=1)
