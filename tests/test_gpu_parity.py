@@ -226,6 +226,23 @@ def test_density_only(zd, oracle, ps, opk):
     _compare(zd, oracle, ps, opk, 64, qdensity=2)
 
 
+def test_ppd8192_on_four_reference_arrays_is_refused_at_plan_creation(zd, oracle, ps):
+    """PPD = 8192 with PLT and an option that needs the reference's arrays (ZD_qdensity, ZD_f_NL, ZD_StoreMode = reference): the x pass
+    of four lines of 512 threads does not exist.  The plan must say so when it is created — not after the Z and y stages of the first
+    pass (launch_xfft_t's own check) — and the stream-factor chooser must offer nothing."""
+    import ctypes as C
+    eig = oracle.synthetic_eigenmodes(16)
+    for kw in (dict(qdensity=1), dict(store_mode="reference")):
+        p = zd.make_params(8192, k_cutoff=2.0, qPLT=1, qPLTrescale=1, PLT_target_z=5.0, stream_factor=256, **kw)
+        with pytest.raises(RuntimeError):
+            zd.Plan(p, ps, eig=eig)
+        p.stream_factor = 0
+        assert zd.load_library().zd_choose_stream_factor(C.byref(p), 1, 250 << 30) == -1
+    plan = zd.Plan(zd.make_params(8192, k_cutoff=2.0, store_mode="reference", stream_factor=128), ps)  # two arrays: 1024 threads
+    assert plan.narray == 2
+    plan.close()
+
+
 @pytest.mark.parametrize("kw", [dict(qdensity=2), dict(store_mode="packed"), dict(plt=True, store_mode="reference"), dict(plt=True),
                                 dict(f_NL=2.0e4)])
 def test_smallest_grid_every_store(zd, oracle, ps, opk, wmap_path, kw):

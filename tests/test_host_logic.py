@@ -71,6 +71,7 @@ def test_stream_factor_for_any_even_ppd(zd):
     # has no z kernel of 16 * 135 (1080 threads): z lines of 432 = 16 * 27
     assert R(7168, 250 * GB) == 64 and R(3584, 250 * GB) == 8 and R(2688, 250 * GB) == 2 and R(4320, 250 * GB) == 10
     assert R(7168, 250 * GB, nranks=8) == 8 and R(6272, 250 * GB, qPLT=1) == 56
+    assert R(8192, 250 * GB, qPLT=1, k_cutoff=2.0) > 0 and R(8192, 250 * GB, qPLT=1, qdensity=1) == -1   # four reference arrays at 8192: a row of the x pass is 2048 threads
     assert R(8640, 250 * GB) == 80 and R(8640, 250 * GB, qPLT=1) == -1   # 64 * 135: z lines of 108 = 4 * 27; beyond 8192 only the ZA field store
 
 

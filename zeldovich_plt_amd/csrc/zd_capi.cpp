@@ -412,6 +412,7 @@ int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes
     if (!p->qPLT && pack_mode(p, 2) != zd::PACK_NONE && N / 2 >= 32 && (N / 2) % nranks == 0) R0 = 2;
     const bool np2 = !is_pow2(N);
     if (N > 8192 && pack_mode(p, 2) != zd::PACK_ZAFIELD) return -1;  // 16384, 8640: only the ZA field store has kernels (plan_create_ex)
+    if (!np2 && pack_mode(p, 2) == zd::PACK_NONE && (p->qdensity == 2 ? 1 : (p->qPLT ? 4 : 2)) * (N / 16) > 1024) return -1;  // 8192 on four arrays: no x pass
     // any other even PPD (or a 2^a 3^b one whose options the composite kernels lack): reference arrays on one rank, see
     // plan_create_ex; R any divisor of N
     auto any_factor = [&]() -> int {
@@ -696,6 +697,13 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
     if (N > 8192 && pl->pack != zd::PACK_ZAFIELD) {  // a 16384-point line fills a workgroup: only the field store's kernels exist (also 8640 = 64 * 135: ZA)
         fprintf(stderr, "zeldovich_hip: PPD = %lld runs on the ZA field store only (ZD_StreamFactor >= 16, no ZD_qdensity / ZD_qPLT / ZD_f_NL)\n",
                 (long long) N);
+        delete pl;
+        return 1;
+    }
+    if (pl->pack == zd::PACK_NONE && pow2 && (int64_t) pl->narray * (N / 16) > 1024) {
+        // (launch_xfft_t would say so only after the Z and y stages of the first pass had run)
+        fprintf(stderr, "zeldovich_hip: PPD = %lld on the reference's %d arrays (PLT with ZD_qdensity, ZD_f_NL or ZD_StoreMode = reference) has no "
+                        "x pass: the lines of a row are %lld threads\n", (long long) N, pl->narray, (long long) pl->narray * (N / 16));
         delete pl;
         return 1;
     }
