@@ -433,7 +433,33 @@ def main():
         watchdog = threading.Timer(deadline, give_up)
         watchdog.daemon = True
         watchdog.start()
+        # ... and when the process is killed inside it (a fault in a collective that has never run on this hardware, or the launcher's
+        # SIGTERM after another rank died): rank 0 leaves the line it has from a C-level signal handler — a Python-level one would not
+        # run while the main thread sits in a C call
+        last_words = None
+        if rank == 0:
+            import ctypes
+            import signal
+            libc = ctypes.CDLL(None)
+            libc.signal.restype = ctypes.c_void_p
+            libc.signal.argtypes = [ctypes.c_int, ctypes.c_void_p]
+            fatal = (signal.SIGSEGV, signal.SIGABRT, signal.SIGBUS, signal.SIGTERM)
+
+            def _last_words(sig):
+                try:
+                    modes[other_name] = {"error": "the process received signal %d while measuring this split" % sig}
+                    out["modes"] = modes
+                    os.write(1, (json.dumps(out) + "\n").encode())
+                finally:
+                    os._exit(0)
+
+            last_words = ctypes.CFUNCTYPE(None, ctypes.c_int)(_last_words)
+            for sg in fatal:
+                libc.signal(int(sg), ctypes.cast(last_words, ctypes.c_void_p))
         try:  # (the line with `value` must be printed whatever happens to the second measurement)
+            if os.environ.get("ZD_BENCH_SELFTEST_SIGNAL"):  # tests/test_gpu_multi_rehearsal.py: what the launcher's SIGTERM would do here
+                os.kill(os.getpid(), int(os.environ["ZD_BENCH_SELFTEST_SIGNAL"]))
+                time.sleep(30)
             other = run_split(world if first_name == "all_to_all" else 1)  # one GPU per group <-> one group of all GPUs
             if other is not None and (world == 1 or (other["gsz"] > 1) != (gsz > 1)):
                 modes[other_name] = mode_summary(other)
@@ -442,6 +468,9 @@ def main():
         except Exception as e:
             modes[other_name] = {"error": repr(e)}
         watchdog.cancel()
+        if last_words is not None:
+            for sg in fatal:
+                libc.signal(int(sg), None)  # SIG_DFL
         if other is not None:
             try:
                 close_mode(other)

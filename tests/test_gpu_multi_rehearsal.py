@@ -59,6 +59,25 @@ def test_bench_distributed_code_path_on_one_gpu():
     assert abs(m[m["default"]]["particles_per_s"] - d["value"]) <= 1e-9 * d["value"]
 
 
+def test_bench_keeps_its_line_when_the_second_split_is_killed():
+    """the N > 1 path of bench.py measures the library's default split, then the other one (on 8 GPUs: the RCCL all-to-all, which has
+    never run on hardware).  If the process is killed there — a fault inside a collective, or the launcher's SIGTERM after another rank
+    died — rank 0 must still leave the JSON line of the first measurement, with the reason in `modes`"""
+    import signal
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", ZD_BENCH_SELFTEST_SIGNAL=str(int(signal.SIGTERM)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--ppd", "256",
+           "--dist", "--no-cpu-baseline", "--no-isolated"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["value"] > 1e7 and d["modes"]["default"] in ("pass_groups", "all_to_all")
+    other = "all_to_all" if d["modes"]["default"] == "pass_groups" else "pass_groups"
+    assert "signal %d" % int(signal.SIGTERM) in d["modes"][other]["error"]
+    assert d["modes"][d["modes"]["default"]]["s_per_step"] > 0
+
+
 def test_failing_consumer_returns_an_error_instead_of_hanging(zd):
     """two and four ranks (threads sharing the device, local transport): the consumer fails on its third plane; zd_generate must
     come back with an error from EVERY rank thread within seconds (a rank that only broke its own loop used to leave the
