@@ -203,19 +203,20 @@ def _planes(zd, ps, n, zs, stride=1, eig=None, fmt="Zeldovich", want_density=Fal
     return res, info
 
 
-@pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096, 3456, 1000, 2000])
+@pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096, 3456, 1000, 2000, 2500])
 def test_oversampled_planes_exact_at_full_size(zd, n):
     """PPD = 2n, ZD_k_cutoff = 2 at even lattice sites == PPD = n, ZD_k_cutoff = 1 (8192 <-> 4096: BASELINE C5 / C4,
     4096 <-> 2048: C3 size; 6912 <-> 3456: the production Abacus size 6912 = 2^8 3^3 on the composite-transform kernels;
     2000 <-> 1000: the any-PPD convolution kernels, zd_kernels_any.hip; 4000 (= 32 * 125: radix-5 composite kernels, round 3) <-> 2000
-    (convolution kernels): two transform families against each other),
+    (convolution kernels): two transform families against each other; 5000 <-> 2500: the convolution engines of 16384 and 8192 points,
+    the former reached by no other test),
     records compared exactly (1e-13 of the field maximum) on planes of different passes.
     The links 2048 <-> 1024 <-> 512 <-> 256 close the chain: PPD = 512 and 256 are compared with the ORACLE record by record
     on the same default store (test_ppd512_za_default_store_vs_oracle, test_za_extrapolated_pk_vs_oracle), so every BASELINE
     size is tied to an oracle-checked run through exact links of HIP runs at different sizes (different z / y / x kernels
     and stream factors at each size)"""
     ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
-    zs = [5, n // 2 + 3, n - 2] if n < 3000 else [5, n // 2 + 3]  # (planes of different passes; two of them at 3456 / 4096: suite time)
+    zs = [5, n // 2 + 3, n - 2] if n < 2500 else ([5, n // 2 + 3] if n > 2500 else [n // 2 + 3])  # (planes of different passes; fewer at the big sizes: suite time)
     lo, ilo = _planes(zd, ps, n, zs)
     hi, ihi = _planes(zd, ps, 2 * n, [2 * z for z in zs], k_cutoff=2.0)
     print("PPD", n, ilo, "PPD", 2 * n, ihi)
