@@ -580,15 +580,14 @@ def test_ppd6912_on_one_gpu_plane_waves(zd, oracle, n, R, modes):
 
 
 def test_ppd2048_plt_store_and_stream_invariance(zd, oracle):
-    """C3 (PPD = 2048, PLT + rescale): the packed store, the reference's four arrays and two stream factors give the
-    same reductions (size-independent property; the oracle cannot run 8.6e9 particles)"""
+    """C3 (PPD = 2048, PLT + rescale): the packed store and the reference's four arrays give the same reductions over all 8.6e9
+    particles (size-independent property; the oracle cannot run that many)"""
     ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
     eig = oracle.synthetic_eigenmodes(128)
     kw = dict(qPLT=1, qPLTrescale=1, PLT_target_z=5.0, z_initial=49.0, icformat="RVZel")
     a = zd.generate(zd.make_params(2048, **kw), ps, eig=eig, collect=False)
     b = zd.generate(zd.make_params(2048, store_mode="reference", **kw), ps, eig=eig, collect=False)
-    c = zd.generate(zd.make_params(2048, stream_factor=4, **kw), ps, eig=eig, collect=False)
-    for o in (b, c):
+    for o in (b,):  # (R = 2 against R = 4: test_large_plt_plane_waves_and_stream_invariance[2048...], on a random plane)
         assert abs(a["density_variance"] - o["density_variance"]) <= 1e-11 * a["density_variance"]
         assert np.abs(a["max_disp"] - o["max_disp"]).max() <= 1e-11 * np.abs(a["max_disp"]).max()
     assert np.abs(a["max_disp"]).max() < 20.0  # well-conditioned eigenmodes: displacements O(1) Mpc/h, as for ZA
