@@ -53,8 +53,12 @@ int64_t zd_dispatch_report(char *buf, int64_t cap) {
     int64_t need = 0;
     for (zd::DispatchSite *s = zd::g_dispatch_head.load(std::memory_order_acquire); s; s = s->next) {
         char line[1024];
-        const int n = snprintf(line, sizeof line, "%lld\t%d\t%s\n", s->count.load(std::memory_order_relaxed), s->line, s->func);
+        int n = snprintf(line, sizeof line, "%lld\t%d\t%s\n", s->count.load(std::memory_order_relaxed), s->line, s->func);
         if (n <= 0) continue;
+        if (n >= (int) sizeof line) {  // (a launcher name longer than the line: snprintf returns what it WOULD have written)
+            n = (int) sizeof line - 1;
+            line[n - 1] = '\n';
+        }
         if (buf && need + n < cap) memcpy(buf + need, line, (size_t) n);
         need += n;
     }
