@@ -476,7 +476,9 @@ def test_fnl_end_to_end(zd, oracle, ps, wmap_path, n, kw):
 
 
 @pytest.mark.parametrize("n,kw", [(128, dict(k_cutoff=2.0)), (128, dict(k_cutoff=2.0, ngpu=2)), (64, dict(k_cutoff=2.0, stream_factor=2)),
-                                  (128, dict()), (128, dict(k_cutoff=2.0, f_NL=0.0)), (64, dict(f_NL=0.0, qPLT=1))])
+                                  (128, dict()), (128, dict(k_cutoff=2.0, f_NL=0.0)), (64, dict(f_NL=0.0, qPLT=1)),
+                                  (192, dict(k_cutoff=2.0, f_NL=0.0, qdensity=1, stream_factor=4)),   # composite grid, six-field store: the density ring
+                                  (160, dict(k_cutoff=4.0, f_NL=0.0, qdensity=1, stream_factor=2))])
 def test_poisoned_buffers(zd, oracle, ps, wmap_path, n, kw):
     """with ZD_k_cutoff = 2 half of the phi store's column tiles are dead under the zero rule; the z stage
     never writes them and the y stage of the phi round must still deliver zeros there, because k_xphi / k_yfwd / k_zfwd read
@@ -497,12 +499,15 @@ def test_poisoned_buffers(zd, oracle, ps, wmap_path, n, kw):
         T.zd_test_poison(0)
     okw = {k: v for k, v in kw.items() if k not in ("stream_factor", "ngpu")}
     ref = oracle.run(oracle.make_params(n, numblock=2, icformat="RVdoubleZel", f_NL=fnl, n_s=ns, Omega_M=om, **okw), opk,
-                     eig=eig, eig_ppd=0 if eig is None else eig.shape[0])
+                     eig=eig, eig_ppd=0 if eig is None else eig.shape[0], want_density=bool(kw.get("qdensity")))
     for f in ("d", "v"):
         assert np.isfinite(got["records"][f]).all(), f
         for c in range(3):
             assert _rel(got["records"][f][..., c], ref["records"][f][..., c]) < TOL, (f, c)
     assert abs(got["density_variance"] - ref["density_variance"]) <= TOL * ref["density_variance"]
+    if kw.get("qdensity"):  # round 4: the y stage skipped the dead column tiles of the density ring too, and k_xdens_q reads every column
+        assert np.isfinite(got["density"]).all()
+        assert _rel(got["density"], ref["density"]) < 1e-6
 
 
 @pytest.mark.parametrize("ngpu,n,kw", [(2, 64, dict()), (4, 128, dict(stream_factor=2, exchange_planes=3)), (2, 64, dict(plt=True))])

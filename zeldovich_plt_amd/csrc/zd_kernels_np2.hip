@@ -136,7 +136,9 @@ __global__ __launch_bounds__(W *Q *P / E) void k_yfft_fq(FieldLayout F, StoreLay
     const int x = tile * W + w, xm = x ? N - x : 0;
     const int zl = plane0 + blockIdx.z;
     const int kx = x > N / 2 ? x - N : x;
-    if ((S.prune & PRUNE_YTILE) && __syncthreads_and(column_is_zero(S, kx, 0))) return;  // a tile without a live row: see k_yfft_f
+    // a tile without a live row: see k_yfft_f.  Not for the density array: k_xdens_q reads every column of its ring (it has no
+    // xdead_lo / hi), so its dead tiles must arrive as zeros — which the `skip` of every row below makes them, without a load
+    if (!dens && (S.prune & PRUNE_YTILE) && __syncthreads_and(column_is_zero(S, kx, 0))) return;
     // ZA: E_a alone (a < 2) or (Z_0, Z_1); PLT: the pairs (X, fX), (Y, Z), (fY, fZ) of the six sums — see k_yfft_f
     const bool plt = F.nfield == 6 && !F.ndens, two = plt || a == 2 || dens;
     const int f0 = dens ? 4 : (plt ? (a == 0 ? 0 : (a == 1 ? 1 : 4)) : (a == 2 ? 1 : 2 * a));
