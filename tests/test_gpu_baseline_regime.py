@@ -175,6 +175,7 @@ def _planes(zd, ps, n, zs, stride=1, eig=None, fmt="Zeldovich", want_density=Fal
         assert p.stream_factor > 0
     plan = zd.Plan(p, ps, eig=eig)
     store = _store_tensor(plan.exchange_bytes)
+    store[:plan.exchange_bytes].fill_(0xFF)  # NaN bytes: a kernel that reads store elements no kernel wrote (pruned column tiles) shows up
     dt = zd.RECORD_DTYPES[fmt]
     step = plan.plane_step
     out = torch.empty(step * n * n * dt.itemsize, dtype=torch.uint8, device="cuda")

@@ -558,6 +558,44 @@ def test_fnl_on_any_even_ppd(zd, oracle, ps, wmap_path, n, kw):
     assert abs(got["density_variance"] - ref["density_variance"]) <= TOL * ref["density_variance"]
 
 
+@pytest.mark.parametrize("n,kw", [
+    (128, dict(k_cutoff=2.0)), (128, dict(k_cutoff=4.0, stream_factor=4)), (128, dict(k_cutoff=2.0, plt=True)),
+    (128, dict(k_cutoff=2.0, store_mode="packed")), (128, dict(k_cutoff=2.0, store_mode="packed", plt=True)),
+    (128, dict(k_cutoff=2.0, qdensity=1)), (128, dict(k_cutoff=2.0, qdensity=2)), (128, dict(k_cutoff=2.0, store_mode="reference", plt=True)),
+    (128, dict(k_cutoff=2.0, ngpu=2, exchange_planes=3)), (128, dict(k_cutoff=2.0, ngpu=2, plt=True)),
+    (96, dict(k_cutoff=2.0, stream_factor=2)), (160, dict(k_cutoff=2.0, stream_factor=2, plt=True)), (224, dict(k_cutoff=4.0, stream_factor=2)),
+    (192, dict(k_cutoff=2.0, stream_factor=2, ngpu=2)), (192, dict(k_cutoff=2.0, stream_factor=2, ngpu=2, qdensity=1)),
+    (100, dict(k_cutoff=2.0)), (100, dict(k_cutoff=2.0, qdensity=1)), (100, dict(k_cutoff=2.0, plt=True)),
+    (64, dict(k_cutoff=2.0, version=1, numblock=4)),
+])
+def test_poison_sweep_of_the_stores(zd, oracle, ps, n, kw):
+    """Every store / packing / transform family with ZD_k_cutoff > 1 (pruned columns: the z stage leaves the dead column tiles of the
+    stores unwritten) in the -DZD_TESTING library with all stores, rings and phi fields starting as NaN bytes (zd_test_poison): the
+    records and density planes must be finite and equal to the product library's ordinary run.  (Round 4 found the density ring of
+    the six-field store this way; ADVICE r3 the phi store.)"""
+    kw = dict(kw)
+    eig = None
+    if kw.pop("plt", False):
+        eig = oracle.synthetic_eigenmodes(32)
+        kw.update(qPLT=1, qPLTrescale=1, PLT_target_z=5.0, f_cluster=0.97)
+    p = zd.make_params(n, icformat="RVdoubleZel", **kw)
+    base = zd.generate(p, ps, eig=eig)
+    T = zd.load_testing_library()
+    T.zd_test_poison(1)
+    try:
+        got = zd.generate(p, ps, eig=eig, testing=True)
+    finally:
+        T.zd_test_poison(0)
+    if base["records"] is not None:
+        for f in ("d", "v"):
+            assert np.isfinite(got["records"][f]).all(), f
+            assert _rel(got["records"][f], base["records"][f]) < 1e-13, f
+    if kw.get("qdensity"):
+        assert np.isfinite(got["density"]).all()
+        assert _rel(got["density"], base["density"]) < 1e-6
+    assert abs(got["density_variance"] - base["density_variance"]) <= 1e-12 * base["density_variance"]
+
+
 def test_fnl_several_ranks_equal_one_rank_at_512(zd, ps):
     """ZD_f_NL at PPD = 512: four ranks (several plane groups both ways) against the single-GPU path, records of sample planes"""
     n, zs = 512, (3, 259, 510)
