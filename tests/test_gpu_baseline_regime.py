@@ -126,7 +126,8 @@ def test_table_generator_arithmetic_vs_oracle(zd, oracle, n, box, fix):
 _STORE = {"t": None}
 _STORE_USERS = {"test_oversampled_planes_exact_at_full_size", "test_radix7_oversampled_planes", "test_smooth_sizes_oversampled_planes",
                 "test_plt_one_mode_at_every_composite_size", "test_z_lines_of_180", "test_density_one_mode_at_every_composite_size",
-                "test_reference_and_packed_arrays_at_large_sizes", "test_density_planes_of_the_reference_arrays_at_4096", "test_ppd16384_k_cutoff4_planes_equal_ppd4096",
+                "test_reference_and_packed_arrays_at_large_sizes", "test_density_planes_of_the_reference_arrays_at_4096",
+                "test_pruned_columns_at_every_tile_width_from_poisoned_memory", "test_ppd16384_k_cutoff4_planes_equal_ppd4096",
                 "test_large_plt_plane_waves_and_stream_invariance", "test_ppd6912_on_one_gpu_plane_waves"}
 
 
@@ -162,7 +163,7 @@ def _store_cache_end():
     _drop_store()
 
 
-def _planes(zd, ps, n, zs, stride=1, eig=None, fmt="Zeldovich", want_density=False, **kw):
+def _planes(zd, ps, n, zs, stride=1, eig=None, fmt="Zeldovich", want_density=False, poison=False, **kw):
     """records of the z planes `zs` of a PPD = n run: only the passes that hold them are executed; stride > 1: only every
     stride-th lattice site of a plane leaves the GPU (a PPD = 16384 plane of records is 8.6 GB).  want_density (ZD_qdensity = 1):
     the float32 density planes too, as res["density"][z]"""
@@ -173,7 +174,15 @@ def _planes(zd, ps, n, zs, stride=1, eig=None, fmt="Zeldovich", want_density=Fal
         held = 0 if _STORE["t"] is None else _STORE["t"].numel()  # (the cached store is this run's to use)
         p.stream_factor = zd.load_library().zd_choose_stream_factor(C.byref(p), 1, int(free_b) + held - (24 << 30))
         assert p.stream_factor > 0
-    plan = zd.Plan(p, ps, eig=eig)
+    if poison:  # the -DZD_TESTING library with its rings (allocated by the plan) starting as NaN bytes, like the store below
+        T = zd.load_testing_library()
+        T.zd_test_poison(1)
+        try:
+            plan = zd.Plan(p, ps, eig=eig, testing=True)
+        finally:
+            T.zd_test_poison(0)
+    else:
+        plan = zd.Plan(p, ps, eig=eig)
     store = _store_tensor(plan.exchange_bytes)
     store[:plan.exchange_bytes].fill_(0xFF)  # NaN bytes: a kernel that reads store elements no kernel wrote (pruned column tiles) shows up
     dt = zd.RECORD_DTYPES[fmt]
@@ -459,6 +468,34 @@ def test_fnl_round_trip_identity_at_large_sizes(zd, n, R):
         for f_ in ("d", "v"):
             assert np.abs(a[z][f_]).max() > 0
             assert np.abs(a[z][f_] - b[z][f_]).max() <= 1e-10 * np.abs(a[z][f_]).max(), (z, f_)
+
+
+@pytest.mark.parametrize("n,kc,kw", [
+    (1024, 2.0, dict()), (2048, 2.0, dict()), (4096, 2.0, dict()), (8192, 2.0, dict(stream_factor=128)), (16384, 4.0, dict(stream_factor=256)),
+    (2048, 2.0, dict(plt=True)), (4096, 2.0, dict(plt=True, stream_factor=64)), (8192, 2.0, dict(plt=True, stream_factor=256)),
+    (3456, 2.0, dict(stream_factor=24)), (6912, 2.0, dict(stream_factor=48)), (7168, 2.0, dict(stream_factor=64)), (8640, 2.0, dict(stream_factor=80)),
+    (3456, 2.0, dict(stream_factor=24, qdensity=1)), (6912, 2.0, dict(plt=True, stream_factor=64)),
+])
+def test_pruned_columns_at_every_tile_width_from_poisoned_memory(zd, oracle, n, kc, kw):
+    """ZD_k_cutoff > 1 leaves column tiles of the stores and of the y -> x rings unwritten; which tiles depends on the tile widths, and
+    those follow the grid size (32 columns at PPD = 128 ... 1 at 16384 / 8640; 8 / 4 / 2 on the composite grids).  The small sizes are
+    swept by test_poison_sweep_of_the_stores; here one short pass of every width class at full size runs in the -DZD_TESTING library with
+    its rings and the block store starting as NaN bytes: a plane that is not finite shows a kernel reading what no kernel wrote."""
+    ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
+    kw = dict(kw)
+    eig = None
+    if kw.pop("plt", False):
+        eig = oracle.synthetic_eigenmodes(32)
+        kw.update(qPLT=1, qPLTrescale=1, PLT_target_z=5.0, z_initial=49.0)
+    z = n // 2 + 6
+    dens = bool(kw.get("qdensity"))
+    got, info = _planes(zd, ps, n, [z], stride=2 if n < 8000 else 4, fmt="RVdoubleZel", eig=eig, k_cutoff=kc, poison=True, want_density=dens, **kw)
+    assert info["narray"] == 3
+    for f_ in ("d", "v"):
+        assert np.isfinite(got[z][f_]).all(), f_
+        assert np.abs(got[z][f_]).max() > 0
+    if dens:
+        assert np.isfinite(got["density"][z]).all()
 
 
 def test_ppd16384_k_cutoff4_planes_equal_ppd4096(zd):

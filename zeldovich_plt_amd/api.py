@@ -376,8 +376,8 @@ def generate_planes(params, ps, on_plane, eig=None):
 class Plan:
     """Staged API: one rank's share of the Z and XY stages on device pointers (see the header)."""
 
-    def __init__(self, params, ps, eig=None, rank=0, nranks=1):
-        self.L = load_library()
+    def __init__(self, params, ps, eig=None, rank=0, nranks=1, testing=False):
+        self.L = load_testing_library() if testing else load_library()  # testing: the -DZD_TESTING build (zd_test_poison), tests only
         self.params = params
         self._eig = None if eig is None else np.ascontiguousarray(eig, dtype=np.float64)
         h = C.c_void_p()
