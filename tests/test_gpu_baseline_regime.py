@@ -174,15 +174,23 @@ def _planes(zd, ps, n, zs, stride=1, eig=None, fmt="Zeldovich", want_density=Fal
         held = 0 if _STORE["t"] is None else _STORE["t"].numel()  # (the cached store is this run's to use)
         p.stream_factor = zd.load_library().zd_choose_stream_factor(C.byref(p), 1, int(free_b) + held - (24 << 30))
         assert p.stream_factor > 0
-    if poison:  # the -DZD_TESTING library with its rings (allocated by the plan) starting as NaN bytes, like the store below
-        T = zd.load_testing_library()
+    def make_plan():
+        if not poison:
+            return zd.Plan(p, ps, eig=eig)
+        T = zd.load_testing_library()  # the -DZD_TESTING library with its rings (allocated by the plan) starting as NaN bytes, like the store below
         T.zd_test_poison(1)
         try:
-            plan = zd.Plan(p, ps, eig=eig, testing=True)
+            return zd.Plan(p, ps, eig=eig, testing=True)
         finally:
             T.zd_test_poison(0)
-    else:
-        plan = zd.Plan(p, ps, eig=eig)
+
+    try:
+        plan = make_plan()
+    except RuntimeError:
+        if _STORE["t"] is None:
+            raise
+        _drop_store()  # the plan's own buffers (folded-input slabs, rings: up to ~40 GB at PPD = 16384) did not fit beside the cached store
+        plan = make_plan()
     store = _store_tensor(plan.exchange_bytes)
     store[:plan.exchange_bytes].fill_(0xFF)  # NaN bytes: a kernel that reads store elements no kernel wrote (pruned column tiles) shows up
     dt = zd.RECORD_DTYPES[fmt]
