@@ -143,9 +143,9 @@ def _store_tensor(nbytes):
     if _STORE["t"] is None or _STORE["t"].numel() < nbytes:
         _drop_store()
         size = nbytes
-        if nbytes > (64 << 30):  # a big store: take at once what the following big runs will ask for, leaving 28 GB to the plans themselves
+        if nbytes > (64 << 30):  # a big store: take at once what the following big runs will ask for
             free_b, _ = torch.cuda.mem_get_info()
-            size = max(nbytes, min(236 << 30, int(free_b) - (28 << 30)))
+            size = max(nbytes, min(224 << 30, int(free_b) - (40 << 30)))  # (40 GB: the next plans' slabs and rings, kernel scratch)
         _STORE["t"] = torch.empty(size, dtype=torch.uint8, device="cuda")
     return _STORE["t"]
 
@@ -191,12 +191,12 @@ def _planes(zd, ps, n, zs, stride=1, eig=None, fmt="Zeldovich", want_density=Fal
             raise
         _drop_store()  # the plan's own buffers (folded-input slabs, rings: up to ~40 GB at PPD = 16384) did not fit beside the cached store
         plan = make_plan()
-    store = _store_tensor(plan.exchange_bytes)
-    store[:plan.exchange_bytes].fill_(0xFF)  # NaN bytes: a kernel that reads store elements no kernel wrote (pruned column tiles) shows up
     dt = zd.RECORD_DTYPES[fmt]
     step = plan.plane_step
-    out = torch.empty(step * n * n * dt.itemsize, dtype=torch.uint8, device="cuda")
+    out = torch.empty(step * n * n * dt.itemsize, dtype=torch.uint8, device="cuda")  # (before the store: it sizes itself by what is left)
     dens = torch.empty(step * n * n, dtype=torch.float32, device="cuda") if want_density else None
+    store = _store_tensor(plan.exchange_bytes)
+    store[:plan.exchange_bytes].fill_(0xFF)  # NaN bytes: a kernel that reads store elements no kernel wrote (pruned column tiles) shows up
     where = {}
     for ps_ in range(plan.passes):
         for lp in range(plan.local_planes):
