@@ -478,7 +478,8 @@ def test_fnl_end_to_end(zd, oracle, ps, wmap_path, n, kw):
 @pytest.mark.parametrize("n,kw", [(128, dict(k_cutoff=2.0)), (128, dict(k_cutoff=2.0, ngpu=2)), (64, dict(k_cutoff=2.0, stream_factor=2)),
                                   (128, dict()), (128, dict(k_cutoff=2.0, f_NL=0.0)), (64, dict(f_NL=0.0, qPLT=1)),
                                   (192, dict(k_cutoff=2.0, f_NL=0.0, qdensity=1, stream_factor=4)),   # composite grid, six-field store: the density ring
-                                  (160, dict(k_cutoff=4.0, f_NL=0.0, qdensity=1, stream_factor=2))])
+                                  (160, dict(k_cutoff=4.0, f_NL=0.0, qdensity=1, stream_factor=2)),
+                                  (100, dict(k_cutoff=2.0))])   # f_NL on the convolution kernels (launch_any_phi_nl / launch_any_phik)
 def test_poisoned_buffers(zd, oracle, ps, wmap_path, n, kw):
     """with ZD_k_cutoff = 2 half of the phi store's column tiles are dead under the zero rule; the z stage
     never writes them and the y stage of the phi round must still deliver zeros there, because k_xphi / k_yfwd / k_zfwd read
