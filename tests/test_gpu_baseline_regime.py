@@ -234,7 +234,7 @@ def test_oversampled_planes_exact_at_full_size(zd, n):
     size is tied to an oracle-checked run through exact links of HIP runs at different sizes (different z / y / x kernels
     and stream factors at each size)"""
     ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
-    zs = [5, n // 2 + 3, n - 2] if n < 2500 else ([5, n // 2 + 3] if n > 2500 else [n // 2 + 3])  # (planes of different passes; fewer at the big sizes: suite time)
+    zs = [5, n // 2 + 3, n - 2] if n < 2500 else ([5, n // 2 + 3] if n == 4096 else [n // 2 + 3])  # (planes of different passes; fewer at the big sizes: suite time)
     lo, ilo = _planes(zd, ps, n, zs)
     hi, ihi = _planes(zd, ps, 2 * n, [2 * z for z in zs], k_cutoff=2.0)
     print("PPD", n, ilo, "PPD", 2 * n, ihi)

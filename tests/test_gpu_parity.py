@@ -810,10 +810,10 @@ def test_two_ranks_equal_one_rank_at_1024(zd, ps):
 
 def test_eight_ranks_equal_one_rank(zd, ps):
     """the geometry the 8-GPU scaling run uses (8 ranks: rows ky = rank mod 8, Zq = L/8 planes per rank, plane-group exchange),
-    with the ranks as threads sharing this one GPU (local transport): PPD = 2048 — records of sample planes equal to the
+    with the ranks as threads sharing this one GPU (local transport): PPD = 1024 — records of sample planes equal to the
     single-rank run; PPD = 4096 (BASELINE C4's size; R = 32 so that eight stores fit one GPU) — the reductions over every
     particle (max_disp per component, sum delta^2) equal to the single-rank run"""
-    n, zs = 2048, (5, 1029, 2046)
+    n, zs = 1024, (5, 517, 1022)  # (PPD = 2048 until round 4: 200 GB of records over PCIe for three sample planes)
     got = {}
     for ngpu in (1, 8):
         planes = {}
