@@ -566,6 +566,7 @@ def test_fnl_on_any_even_ppd(zd, oracle, ps, wmap_path, n, kw):
     (128, dict(k_cutoff=2.0, ngpu=2, exchange_planes=3)), (128, dict(k_cutoff=2.0, ngpu=2, plt=True)),
     (96, dict(k_cutoff=2.0, stream_factor=2)), (160, dict(k_cutoff=2.0, stream_factor=2, plt=True)), (224, dict(k_cutoff=4.0, stream_factor=2)),
     (192, dict(k_cutoff=2.0, stream_factor=2, ngpu=2)), (192, dict(k_cutoff=2.0, stream_factor=2, ngpu=2, qdensity=1)),
+    (192, dict(k_cutoff=2.0, stream_factor=2, ngpu=2, plt=True)), (256, dict(k_cutoff=4.0, ngpu=4, exchange_planes=2)),
     (100, dict(k_cutoff=2.0)), (100, dict(k_cutoff=2.0, qdensity=1)), (100, dict(k_cutoff=2.0, plt=True)),
     (64, dict(k_cutoff=2.0, version=1, numblock=4)),
 ])
