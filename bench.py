@@ -103,6 +103,35 @@ def cpu_baseline(ppd, plt, fmt, eig):
                                           time.time() - t0)}
 
 
+def arm_last_words(make_line):
+    """C-level handlers for SIGSEGV / SIGABRT / SIGBUS / SIGTERM that write make_line(signal) to stdout and end the process with
+    status 0.  A Python-level handler would not run while the main thread sits inside a C call (a collective, a kernel wait);
+    this one is a ctypes callback installed with signal(2), entered on the interrupted thread, which takes the GIL the call had
+    released.  Returns (callback to keep alive, disarm())."""
+    import ctypes
+    import signal
+    libc = ctypes.CDLL(None)
+    libc.signal.restype = ctypes.c_void_p
+    libc.signal.argtypes = [ctypes.c_int, ctypes.c_void_p]
+    fatal = (signal.SIGSEGV, signal.SIGABRT, signal.SIGBUS, signal.SIGTERM)
+
+    def _handler(sig):
+        try:
+            os.write(1, (make_line(sig) + "\n").encode())
+        finally:
+            os._exit(0)
+
+    cb = ctypes.CFUNCTYPE(None, ctypes.c_int)(_handler)
+    for sg in fatal:
+        libc.signal(int(sg), ctypes.cast(cb, ctypes.c_void_p))
+
+    def disarm():
+        for sg in fatal:
+            libc.signal(int(sg), None)  # SIG_DFL
+
+    return cb, disarm
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -438,24 +467,12 @@ def main():
         # run while the main thread sits in a C call
         last_words = None
         if rank == 0:
-            import ctypes
-            import signal
-            libc = ctypes.CDLL(None)
-            libc.signal.restype = ctypes.c_void_p
-            libc.signal.argtypes = [ctypes.c_int, ctypes.c_void_p]
-            fatal = (signal.SIGSEGV, signal.SIGABRT, signal.SIGBUS, signal.SIGTERM)
+            def line_for(sig):
+                modes[other_name] = {"error": "the process received signal %d while measuring this split" % sig}
+                out["modes"] = modes
+                return json.dumps(out)
 
-            def _last_words(sig):
-                try:
-                    modes[other_name] = {"error": "the process received signal %d while measuring this split" % sig}
-                    out["modes"] = modes
-                    os.write(1, (json.dumps(out) + "\n").encode())
-                finally:
-                    os._exit(0)
-
-            last_words = ctypes.CFUNCTYPE(None, ctypes.c_int)(_last_words)
-            for sg in fatal:
-                libc.signal(int(sg), ctypes.cast(last_words, ctypes.c_void_p))
+            last_words = arm_last_words(line_for)
         try:  # (the line with `value` must be printed whatever happens to the second measurement)
             if os.environ.get("ZD_BENCH_SELFTEST_SIGNAL"):  # tests/test_gpu_multi_rehearsal.py: what the launcher's SIGTERM would do here
                 os.kill(os.getpid(), int(os.environ["ZD_BENCH_SELFTEST_SIGNAL"]))
@@ -469,8 +486,7 @@ def main():
             modes[other_name] = {"error": repr(e)}
         watchdog.cancel()
         if last_words is not None:
-            for sg in fatal:
-                libc.signal(int(sg), None)  # SIG_DFL
+            last_words[1]()
         if other is not None:
             try:
                 close_mode(other)

@@ -278,3 +278,25 @@ def test_parseheader_vector_vcounter_mapvar(zd, tmp_path):
     fails("mapvar ZD_Seed s1\nmapvar BoxSize s1\n")              # already mapped (phDriver.cc:442-446)
     fails("BoxSize 720\n")                                       # statement without '=' (phParser.yy:95-99)
     fails("vcounter n\nvector a\n1\n\n2\n")                    # a blank line ends the block: the next row is a syntax error
+
+
+@pytest.mark.parametrize("how", ["segv", "abort", "term"])
+def test_bench_last_words_handler(how):
+    """bench.py's arm_last_words: a process that dies inside a C call (a fault, abort(), the launcher's SIGTERM while it sits in a
+    blocking call with the GIL released) still writes its line to stdout and exits 0"""
+    import subprocess
+    import sys
+    import time
+    code = ("import bench, ctypes\n"
+            "keep = bench.arm_last_words(lambda s: 'LAST WORDS %d' % s)\n"
+            + {"segv": "ctypes.string_at(0)\n", "abort": "ctypes.CDLL(None).abort()\n",
+               "term": "print('ready', flush=True)\nctypes.CDLL(None).sleep(60)\n"}[how])
+    p = subprocess.Popen([sys.executable, "-c", code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    if how == "term":
+        assert p.stdout.readline().strip() == "ready"
+        time.sleep(0.3)
+        p.terminate()
+    out, _ = p.communicate(timeout=60)
+    import signal
+    want = {"segv": signal.SIGSEGV, "abort": signal.SIGABRT, "term": signal.SIGTERM}[how]
+    assert ("LAST WORDS %d" % int(want)) in out and p.returncode == 0
