@@ -157,6 +157,7 @@ def main():
                          "the world size: rehearses it on one GPU under torch.distributed.run --nproc-per-node 1")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: what RCCL between processes needs on this driver; normally exported already)
     import torch
     import zeldovich_plt_amd.api as zd
 
