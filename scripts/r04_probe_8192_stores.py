@@ -1,3 +1,6 @@
+"""Round 4 probe: which store combinations a PPD=8192 plan accepts.  Before the fix the plan of four reference arrays was created and the
+x stage of the first pass failed (2048 threads per workgroup); since then zd_plan_create refuses it (tests/test_gpu_parity.py
+test_ppd8192_on_four_reference_arrays_is_refused_at_plan_creation)."""
 import sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 import zeldovich_plt_amd.api as zd
@@ -15,7 +18,10 @@ for kw, e in ((dict(qPLT=1, qPLTrescale=1, PLT_target_z=5.0, store_mode="referen
         print("REFUSED", kw, ex)
 # does the x stage of four reference arrays launch at 8192?  (4 lines of 512 threads)
 import torch
-pl = zd.Plan(zd.make_params(8192, k_cutoff=2.0, icformat="RVZel", qPLT=1, qPLTrescale=1, PLT_target_z=5.0, store_mode="reference", stream_factor=256), ps, eig=eig)
+try:
+    pl = zd.Plan(zd.make_params(8192, k_cutoff=2.0, icformat="RVZel", qPLT=1, qPLTrescale=1, PLT_target_z=5.0, store_mode="reference", stream_factor=256), ps, eig=eig)
+except RuntimeError as ex:
+    raise SystemExit("REFUSED at plan creation: %s" % ex)
 store = torch.empty(pl.exchange_bytes, dtype=torch.uint8, device="cuda")
 out = torch.empty(8192 * 8192 * 32, dtype=torch.uint8, device="cuda")
 try:
