@@ -39,6 +39,10 @@ CASES = {
     "ppd4096_za": dict(n=4096, kw={}),                     # the bench workload / BASELINE C4's grid
     "ppd4096_plt_rescale": dict(n=4096, kw=PLT, eig=128),
     "ppd8192_kcut2_za": dict(n=8192, kw=dict(k_cutoff=2.0)),  # BASELINE C5's grid
+    "ppd96_za": dict(n=96, kw={}),                         # composite grids, small: re-derived on CPU against the oracle's plain-DFT path
+    "ppd160_plt": dict(n=160, kw=PLT, eig=32),
+    "ppd3456_za": dict(n=3456, kw={}),                     # composite-transform kernels (2^7 3^3)
+    "ppd6912_plt_rescale": dict(n=6912, kw=PLT, eig=128),  # the production Abacus configuration: 2^8 3^3 with PLT + rescale, one GPU
 }
 
 

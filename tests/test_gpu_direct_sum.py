@@ -7,6 +7,9 @@ holds the displacement and velocity at 8 lattice sites on 4 planes of different 
   * PPD = 2048 PLT + rescale — BASELINE C3: k_genf PLTN + k_eig_lines / k_zfft / k_yfft / k_xfft_seq_plt<2048>
   * PPD = 4096 PLT + rescale — k_xfft_seq_plt<4096, 16, true>, R = 16
   * PPD = 8192 ZD_k_cutoff=2 — BASELINE C5's grid on one GPU
+  * PPD = 3456 ZA            — the composite-transform kernels (2^7 3^3: k_zfft_fq / k_yfft_fq / k_xfft_seq1_q)
+  * PPD = 6912 PLT + rescale — the production Abacus configuration (2^8 3^3, 3.3e11 particles, one GPU, R = 48): the kz-paired PLT
+                               generator, the PLT field store and the composite kernels' PLT x stage
 This anchors the random-field path AT the headline sizes to the oracle directly, not through a chain of HIP runs.  The CPU suite
 re-derives the small cases of the same file from a full oracle run (tests/test_oracle_golden.py)."""
 import ctypes as C
@@ -68,7 +71,7 @@ def records_at(zd, ps, n, sites, eig=None, **kw):
 
 
 @pytest.mark.parametrize("case", ["ppd256_za", "ppd256_plt", "ppd2048_plt_rescale", "ppd4096_za", "ppd4096_plt_rescale",
-                                  "ppd8192_kcut2_za"])
+                                  "ppd8192_kcut2_za", "ppd96_za", "ppd160_plt", "ppd3456_za", "ppd6912_plt_rescale"])
 def test_records_at_sites_equal_the_direct_sum_over_all_modes(zd, oracle, case):
     c = FIXTURE[case]
     n = c["ppd"]
