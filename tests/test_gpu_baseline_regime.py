@@ -526,7 +526,8 @@ def test_ppd16384_k_cutoff4_planes_equal_ppd4096(zd):
     (2048, 1.0, 2, 4, [(3, 5, -7), (-401, 577, 600), (0, 2, 0)]),          # BASELINE C3: packed PLT arrays (k_genf PLTN / k_zfft / k_yfft / k_xfft)
     (4096, 1.0, 16, 32, [(3, 5, -7), (-1001, 777, 1200), (0, 2, 0)]),    # PLT at the headline grid: k_genf PLTN + k_eig_lines at 4096 / k_zfft<256|128> / k_yfft<4096> / k_xfft_seq_plt<4096,16,true>
     (8192, 2.0, 64, 128, [(3, 5, -7), (-1001, 777, 1200), (0, 2, 0)]),   # k_xfft_two<8192, PLT>
-    (6912, 4.0, 8, 16, [(3, 5, -7), (-401, 377, 500)]),                  # composite kernels, x pass in two launches
+    # (6912 at k_cutoff = 4, R = 8 / 16, until round 4: PLT at 6912 now has the direct sum over every mode at k_cutoff = 1 —
+    #  tests/test_gpu_direct_sum.py[ppd6912_plt_rescale] — besides the one-mode, poisoned-memory and R = 64 runs)
     (3456, 2.0, 4, 8, [(-3, 5, 7), (401, 377, -500)]),                   # composite kernels, three lines per workgroup
     (6912, 1.0, 64, None, [(-2001, 1777, 1200)]),                        # production Abacus on ONE GPU: z lines of 108 = 4 * 27
     (3584, 2.0, 8, 16, [(-401, 377, 500)]),                              # radix-7 composite kernels (3584 = 512 * 7) with the PLT field store
