@@ -76,50 +76,115 @@ def source_sha():
     return h.hexdigest()
 
 
+def host_memory_available():
+    """bytes this process may still allocate on the host: MemAvailable of /proc/meminfo, capped by the cgroup limit when there is one"""
+    avail = None
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    for lim, cur in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                     ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:
+            v = open(lim).read().strip()
+            if v != "max" and int(v) < (1 << 60):
+                room = int(v) - int(open(cur).read().strip())
+                avail = room if avail is None else min(avail, room)
+        except (OSError, ValueError):
+            pass
+    return avail if avail is not None else 8 << 30
+
+
+def host_threads():
+    """threads the host really gives this process: CPUs of its affinity mask, capped by the cgroup CPU quota (a 1-GPU box shows
+    every core of the machine in os.cpu_count() but may schedule only its share)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline_sample(ppd, plt, recsize, cores, avail, rate):
+    """(n, numblock) of the bounded sample: the largest power-of-two grid <= min(ppd, 1024) that (i) fits half of the host's free memory
+    — the oracle holds the reference's BlockArray (n^3 a Complx), its two generation slabs + one XY slab (3 n^3 a / NumBlock) and the
+    records — and (ii) is at most ~35 s of work at `rate` particles/s (measured by the caller on a PPD=256 probe run on these threads).
+    NumBlock = the largest that still gives every OpenMP loop of ZeldovichZ / ZeldovichXY (src/zeldovich.cpp:572-577,653-658:
+    over the n / NumBlock planes of a block) two iterations per thread, at least 2."""
+    a = 4 if plt else 2
+    n = 1024
+    while n > 64:
+        nb = 2
+        while nb * 2 <= n // 2 and n // (nb * 2) >= 2 * cores:
+            nb *= 2
+        need = n ** 3 * (16.0 * a * (1 + 3.0 / nb) + recsize) * 1.1
+        secs = n ** 3 / rate
+        if n <= ppd and need <= 0.5 * avail and secs <= 35:
+            return n, nb
+        n //= 2
+    return 64, 2
+
+
 def cpu_baseline(ppd, plt, fmt, eig):
     """oracle (CPU port of the reference path) on the host cores, bounded sample of the workload"""
     from oracle import zdo
     zdo.build()
-    cores = os.cpu_count() or 1
-    n = min(ppd, 512 if cores >= 32 else 256)  # bounded sample: ~10-30 s of CPU work
-    while n > 64 and n ** 3 * (64 if plt else 32) * 2.2 > 40e9:
-        n //= 2
+    cores = host_threads()
+    avail = host_memory_available()
     pk = zdo.pk_from_file(WMAP, 720.0)
-    kw = dict(numblock=2, icformat=fmt, nthreads=cores)  # NumBlock=2: widest OpenMP loops (block = n/2 planes)
-    if plt:
-        kw.update(qPLT=1, qPLTrescale=1, PLT_target_z=5.0, z_initial=49.0)
-    p = zdo.make_params(n, **kw)
+    kwp = dict(qPLT=1, qPLTrescale=1, PLT_target_z=5.0, z_initial=49.0) if plt else {}
+
+    def timed(n, nb):
+        p = zdo.make_params(n, numblock=nb, icformat=fmt, nthreads=cores, **kwp)
+        st = zdo.run(p, pk, eig=eig if plt else None, eig_ppd=eig.shape[0] if plt else 0)["stats"]
+        return st, st.t_stage1 + st.t_store + st.t_load + st.t_fft2d + st.t_write
+
     t0 = time.time()
-    out = zdo.run(p, pk, eig=eig if plt else None, eig_ppd=eig.shape[0] if plt else 0)
-    st = out["stats"]
-    t = st.t_stage1 + st.t_store + st.t_load + st.t_fft2d + st.t_write
+    npr = min(256, ppd)
+    _, tp = timed(npr, 2)  # probe: the rate of these threads on a grid that takes about a second (it does not fill many threads yet)
+    n, nb = cpu_baseline_sample(ppd, plt, zdo.RECORD_DTYPES[fmt].itemsize, cores, avail, npr ** 3 / tp)
+    st, t = timed(n, nb)
     fft = zdo.fft_backend()  # "fftw3" when the host has libfftw3.so.3 (the reference's transform), else the oracle's own
-    return {"value": n ** 3 / t, "unit": "particles/s", "cores": cores, "kind": "port", "fft": fft,
+    return {"value": n ** 3 / t, "unit": "particles/s", "cores": cores, "threads": cores, "host_cpus_listed": os.cpu_count(), "ppd": n,
+            "numblock": nb, "kind": "port",
+            "fft": fft, "host_memory_available_GB": avail / 1e9, "timed_seconds": t, "wall_seconds": time.time() - t0,
             "phase_seconds": {"LoadPlane+zFFT": st.t_stage1, "StoreBlock": st.t_store, "LoadBlock": st.t_load,
                               "FFT2D": st.t_fft2d, "WriteParticlesSlab": st.t_write},
-            "sample": "PPD=%d %s %s, full grid->displacements (ZeldovichZ+ZeldovichXY timers), OpenMP on %d threads, "
-                      "%s; wall %.1fs" % (n, "PLT+rescale" if plt else "ZA", fmt, cores,
-                                          "FFTW3 (dlopen)" if fft == "fftw3" else "radix-2 CPU FFT (no libfftw3.so.3 on this host)",
-                                          time.time() - t0)}
+            "sample": "PPD=%d NumBlock=%d %s %s, full grid->displacements (ZeldovichZ+ZeldovichXY timers), OpenMP on %d threads "
+                      "(%d planes per block: every parallel loop has >= %d iterations per thread), %s; wall %.1fs" % (
+                          n, nb, "PLT+rescale" if plt else "ZA", fmt, cores, n // nb, max(1, n // nb // cores),
+                          "FFTW3 (dlopen)" if fft == "fftw3" else "radix-2 CPU FFT (no libfftw3.so.3 on this host)",
+                          time.time() - t0)}
 
 
 def arm_last_words(make_line):
     """C-level handlers for SIGSEGV / SIGABRT / SIGBUS / SIGTERM that write make_line(signal) to stdout and end the process with
-    status 0.  A Python-level handler would not run while the main thread sits inside a C call (a collective, a kernel wait);
-    this one is a ctypes callback installed with signal(2), entered on the interrupted thread, which takes the GIL the call had
-    released.  Returns (callback to keep alive, disarm())."""
+    status 128 + signal: the line survives, and the launcher still sees a failed rank (a faulted run must not read as rc = 0).
+    A Python-level handler would not run while the main thread sits inside a C call (a collective, a kernel wait); this one is a
+    ctypes callback installed with signal(2), entered on the interrupted thread, which takes the GIL the call had released.  The
+    lines are serialised when the handlers are armed, so that the handler itself only writes bytes and exits.
+    Returns (callback to keep alive, disarm())."""
     import ctypes
     import signal
     libc = ctypes.CDLL(None)
     libc.signal.restype = ctypes.c_void_p
     libc.signal.argtypes = [ctypes.c_int, ctypes.c_void_p]
     fatal = (signal.SIGSEGV, signal.SIGABRT, signal.SIGBUS, signal.SIGTERM)
+    lines = {int(sg): (make_line(int(sg)) + "\n").encode() for sg in fatal}
 
     def _handler(sig):
         try:
-            os.write(1, (make_line(sig) + "\n").encode())
+            os.write(1, lines.get(sig, b""))
         finally:
-            os._exit(0)
+            os._exit(128 + sig)
 
     cb = ctypes.CFUNCTYPE(None, ctypes.c_int)(_handler)
     for sg in fatal:
@@ -149,6 +214,9 @@ def main():
                          "one GPU per group while the passes, after at most one doubling of the stream factor, deal out over the N GPUs; else "
                          "one group with the all-to-all exchange)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--store-mode", default=os.environ.get("ZD_BENCH_STORE_MODE", "auto") or "auto",
+                    help="zd_params.store_mode for A/B runs (auto | reference | packed | fields): PLT with `packed` keeps the two-kernel "
+                         "Z stage where `auto` takes the fused generator + z FFT")
     ap.add_argument("--two-stores", action="store_true",
                     help="one GPU: a second block store, the Z stage of pass p + 1 issued beside the y / x stages of pass p "
                          "(zd_plan_run_passes); use with --stream 2R so that two stores fit (A/B measurement, DESIGN §8)")
@@ -180,7 +248,8 @@ def main():
     zd.load_library()
     ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
     eig = synthetic_eigenmodes(128) if plt else None
-    kw = dict(numblock=64 if N >= 4096 else 4, icformat=fmt, profile=1)
+    kw = dict(numblock=64 if N >= 4096 else 4, icformat=fmt, profile=1,
+              store_mode=int(args.store_mode) if args.store_mode.isdigit() else args.store_mode)
     if plt:
         kw.update(qPLT=1, qPLTrescale=1, PLT_target_z=5.0, z_initial=49.0)
     p = zd.make_params(N, **kw)
@@ -195,6 +264,25 @@ def main():
         t = torch.tensor([budget], dtype=torch.int64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         budget = int(t.item())
+    # N > 1: the links are probed before anything is decided — a communicator over ALL ranks, 128 MB to and from every peer at once,
+    # three repetitions (zd_comm_probe); the slowest rank's figure prices the all-to-all in the library's choice between the two
+    # splits (zd_choose_pass_groups_measured) instead of an assumed link rate
+    link = {"GBps_per_peer": 0.0, "bytes_per_peer": 128 << 20, "reps": 3}
+    if multi:
+        def world_id(raw):
+            mine = torch.tensor(list(raw), dtype=torch.uint8, device="cuda")
+            dist.broadcast(mine, src=0)
+            return bytes(mine.cpu().tolist())
+        try:
+            pc = zd.Comm(rank, world, world_id)
+            r = torch.tensor([pc.probe(link["bytes_per_peer"], link["reps"])], dtype=torch.float64, device="cuda")
+            pc.close()
+            dist.all_reduce(r, op=dist.ReduceOp.MIN)
+            link["GBps_per_peer"] = float(r.item())
+        except Exception as e:  # (every rank fails alike: a communicator that does not come up fails on all of them)
+            link["error"] = repr(e)
+    choice_est = {}
+
     def run_split(groups_req):
         """one measurement of the workload with the GPUs split into `groups_req` pass groups (0 = the library's choice): plan,
         communicator, buffers, W warm-up + K timed steps between fences, per-rank spans.  The caller closes what it returns."""
@@ -203,8 +291,12 @@ def main():
         p.stream_factor = args.stream
         p.pass_groups = groups_req
         g_, R_ = ctypes.c_int32(), ctypes.c_int32()
-        if zd.load_library().zd_choose_pass_groups(ctypes.byref(p), world, budget, ctypes.byref(g_), ctypes.byref(R_)):
+        est = (ctypes.c_double * 2)()
+        if zd.load_library().zd_choose_pass_groups_measured(ctypes.byref(p), world, budget, link["GBps_per_peer"], ctypes.byref(g_),
+                                                            ctypes.byref(R_), est):
             return None
+        if groups_req == 0 and est[0] > 0:
+            choice_est.update(pass_groups_s=est[0], all_to_all_s=est[1])
         groups, R = g_.value, R_.value
         p.stream_factor = R
         grp_id, grank, gsz = split_ranks(rank, world, groups)
@@ -408,7 +500,10 @@ def main():
                     if gsz > 1 else ", no exchange"))},
             "hbm_GBps_path": (64.0 * narray + recsize) * value / 1e9,
             "roofline_path_frac": (64.0 * narray + recsize) * value / 1e9 / (HBM_PEAK_GBS * world),
-            "roofline": {"bound": "hbm", "kernel": dom_kernel, "achieved": du["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # `bound`: the y / x stages and the packed-PLT Z stage wait for HBM; the ZA Z stage (generator || z FFT) is bound by
+            # vector instructions (SQ counters of the committed profile: three generator waves per SIMD x 33.5 % issue) — its
+            # `achieved` stays the SURVEY 8d byte figure of merit, `valu_issue` carries the counters when the profile has them
+            "roofline": {"bound": "valu" if (dom == "z_stage" and not plt) else "hbm", "kernel": dom_kernel, "achieved": du["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": du["alg_GBps"] / HBM_PEAK_GBS, "traffic": du.get("pmc_bytes_per_launch"),
                          "avg_launch_ms": du["avg_launch_ms"], "launches": dom_launches,
                          "alg_bytes_per_launch": du["alg_bytes_per_launch"],
@@ -426,6 +521,8 @@ def main():
         }
         if traffic_stale:
             out["roofline"]["traffic_stale"] = traffic_stale
+        if out["roofline"]["bound"] == "valu":
+            out["roofline"]["valu_issue"] = (traffic_file or {}).get("sq")  # per kernel: VALU-issue cycles / wave cycles, waves per SIMD
         if per_rank is not None:
             out["per_rank"] = per_rank
             out["exchange"] = {"transport": "RCCL grouped ncclSend/ncclRecv per plane group (zd_plan_run_pass)",
@@ -445,7 +542,10 @@ def main():
         # a split is named by what happens between its GPUs: ranks of a group exchange (all_to_all) or every GPU is its own group
         first_name = "all_to_all" if gsz > 1 else "pass_groups"
         other_name = "pass_groups" if first_name == "all_to_all" else "all_to_all"
-        modes = {"default": first_name, first_name: mode_summary(main_mode)}
+        modes = {"default": first_name, first_name: mode_summary(main_mode),
+                 # what the default was chosen on: the probed rate of one link (all links of a GPU busy) and the library's estimate
+                 # of a step for both splits at that rate (empty: only one split exists for this job, or nothing was measured)
+                 "link_probe": link, "estimate_at_probed_rate": choice_est}
         close_mode(main_mode)
         plan = comm = pipe = None
         other = None
@@ -457,8 +557,9 @@ def main():
             if rank == 0:
                 modes[other_name] = {"error": "no result within %.0f s of starting it; the process was ended" % deadline}
                 out["modes"] = modes
+                out["aborted"] = True
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(3)  # the line is kept, the status says that this run did not end by itself
 
         watchdog = threading.Timer(deadline, give_up)
         watchdog.daemon = True
@@ -469,9 +570,9 @@ def main():
         last_words = None
         if rank == 0:
             def line_for(sig):
-                modes[other_name] = {"error": "the process received signal %d while measuring this split" % sig}
-                out["modes"] = modes
-                return json.dumps(out)
+                m2 = dict(modes)
+                m2[other_name] = {"error": "the process received signal %d while measuring this split" % sig}
+                return json.dumps(dict(out, modes=m2, aborted=True))
 
             last_words = arm_last_words(line_for)
         try:  # (the line with `value` must be printed whatever happens to the second measurement)

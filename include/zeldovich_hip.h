@@ -145,6 +145,14 @@ int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes
  * for zd_choose_stream_factor).  zd_generate applies it; one-process-per-GPU drivers call it so that every rank arrives at
  * the same split.  Returns non-zero if nothing fits. */
 int zd_choose_pass_groups(const zd_params *p, int ngpu, int64_t budget_bytes, int32_t *groups, int32_t *stream_factor);
+/* The same with a MEASURED link rate (zd_comm_probe: GB/s one link carries per direction while every link of a GPU works; <= 0 = not
+ * measured, i.e. zd_choose_pass_groups).  Where the automatic choice would be one GPU per pass group (no exchange), the time of a
+ * step is estimated for both splits from the per-particle unit times of one MI355X (generation, z FFT, y + x stages)
+ * and the exchange's bytes per link at that rate, and the single group with the all-to-all (block store transposed between the z and
+ * the y / x passes, the reference's StoreBlock / LoadBlock: src/block_array.cpp:387-414,466-504) is taken when it comes out faster —
+ * about 45 GB/s per link at PPD = 4096 on 8 GPUs.  est_seconds (may be NULL): [0] pass groups, [1] all-to-all. */
+int zd_choose_pass_groups_measured(const zd_params *p, int ngpu, int64_t budget_bytes, double link_GBps, int32_t *groups,
+                                   int32_t *stream_factor, double *est_seconds);
 
 /* ---- staged API (device pointers) for one-process-per-GPU drivers and for tests ---------------
  * Rank `rank` of `nranks` (a power of two) owns the half-space rows ky = rank, rank + nranks, ... (H = ppd/2/nranks
@@ -208,6 +216,9 @@ void zd_comm_abort(zd_comm *comm);
 /* bytes this rank has sent to / received from other ranks since the communicator was created (or since the last call with
  * reset != 0) */
 void zd_comm_traffic(zd_comm *comm, int64_t *bytes_sent, int64_t *bytes_received, int reset);
+/* timed probe of the links: bytes_per_peer to and from every peer at once (grouped send / receive), one warm-up + reps repetitions;
+ * *GBps_per_peer = what one link carries per direction meanwhile (0: no peers).  Every rank of the communicator calls it. */
+int zd_comm_probe(zd_comm *comm, int64_t bytes_per_peer, int32_t reps, double *GBps_per_peer);
 /* bytes of the two-slot receive ring zd_plan_run_pass allocates (0 for one rank) and the planes per exchange group */
 int64_t zd_plan_ring_bytes(const zd_plan *plan, int32_t *group_planes);
 /* consumer of finished planes: `nplanes` delivered planes starting at local plane `first_local_plane` of the pass lie

@@ -178,3 +178,49 @@ def test_choose_pass_groups_policy():
     assert choose(6912, 1) == (1, 36) and choose(6912, 2) == (2, 36)
     g, R = choose(6912, 8)
     assert g == 8 and 6912 % R == 0 and (R // 2) % 8 == 0 and R <= 72, (g, R)
+
+
+def test_choose_pass_groups_with_a_measured_link_rate():
+    """VERDICT r4 #3b/c: the split of the GPUs is chosen on the PROBED rate of one link (zd_comm_probe -> zd_choose_pass_groups_measured),
+    not on an assumed one.  Decision table for world 2 / 4 / 8 at PPD 2048 / 4096 / 8192 (ZD_k_cutoff = 2) at 30 / 60 / 120 GB/s per
+    link and direction, 288 GB GPUs: (groups, stream factor); groups = 1 is the all-to-all of BASELINE config 4, groups = world
+    the exchange-free pass groups.  Without a measurement (rate 0) the answer is zd_choose_pass_groups's."""
+    import ctypes as C
+    import zeldovich_plt_amd.api as zd
+    L = zd.load_library()
+    budget = (288 - 32) << 30
+
+    def choose(ppd, ngpu, rate, **kw):
+        p = zd.make_params(ppd, icformat="RVZel", numblock=64, **kw)
+        g, R = C.c_int32(), C.c_int32()
+        est = (C.c_double * 2)()
+        assert L.zd_choose_pass_groups_measured(C.byref(p), ngpu, budget, float(rate), C.byref(g), C.byref(R), est) == 0
+        g0, R0 = C.c_int32(), C.c_int32()
+        assert L.zd_choose_pass_groups(C.byref(p), ngpu, budget, C.byref(g0), C.byref(R0)) == 0
+        if rate <= 0:
+            assert (g.value, R.value) == (g0.value, R0.value) and est[0] == 0.0
+        if est[0] > 0:  # both splits were priced: the faster estimate wins
+            assert (g.value == 1) == (est[1] < est[0]), (ppd, ngpu, rate, est[0], est[1])
+        return g.value, R.value
+
+    plt = dict(qPLT=1, qPLTrescale=1)
+    table = {  # (ppd, world): decisions at 0 (not measured), 30, 60, 120 GB/s
+        ("za", 2048, 2): [(2, 4)] * 4, ("za", 2048, 4): [(1, 8)] * 4, ("za", 2048, 8): [(1, 8)] * 4,
+        # PPD = 4096: two and four GPUs would push their whole stores over one and three links: never; eight GPUs have seven links
+        # each and share the generations: from about 45 GB/s per link
+        ("za", 4096, 2): [(2, 8)] * 4, ("za", 4096, 4): [(4, 8)] * 4, ("za", 4096, 8): [(8, 16), (8, 16), (1, 8), (1, 8)],
+        ("za", 8192, 2): [(2, 16), (2, 16), (2, 16), (1, 8)], ("za", 8192, 4): [(4, 16), (4, 16), (1, 8), (1, 8)],
+        ("za", 8192, 8): [(8, 16), (1, 8), (1, 8), (1, 8)],
+        ("plt", 2048, 2): [(2, 2)] * 4, ("plt", 2048, 4): [(4, 4)] * 4, ("plt", 2048, 8): [(1, 4)] * 4,
+        ("plt", 4096, 2): [(2, 16)] * 4, ("plt", 4096, 4): [(4, 16)] * 4, ("plt", 4096, 8): [(8, 16), (8, 16), (8, 16), (1, 4)],
+        ("plt", 8192, 2): [(2, 32), (2, 32), (2, 32), (1, 16)], ("plt", 8192, 4): [(4, 32), (4, 32), (1, 8), (1, 8)],
+        ("plt", 8192, 8): [(8, 32), (1, 4), (1, 4), (1, 4)],
+    }
+    for (kind, ppd, world), want in table.items():
+        kw = dict(plt) if kind == "plt" else {}
+        if ppd == 8192:
+            kw["k_cutoff"] = 2.0
+        got = [choose(ppd, world, r, **kw) for r in (0, 30, 60, 120)]
+        assert got == want, (kind, ppd, world, got)
+    # an explicit ZD_PassGroups is never overridden by a measurement
+    assert choose(4096, 8, 120, pass_groups=8) == (8, 16) and choose(4096, 8, 30, pass_groups=1)[0] == 1

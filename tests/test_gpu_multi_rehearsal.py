@@ -49,7 +49,8 @@ def test_bench_distributed_code_path_on_one_gpu():
     # both ways of sharing the job are timed in one run: `value` is the library's default split, `modes` holds
     # the exchange-free pass groups AND the slab all-to-all BASELINE C4 names, each with its per-rank spans and bytes
     m = d["modes"]
-    assert m["default"] in ("pass_groups", "all_to_all") and set(m) == {"default", "pass_groups", "all_to_all"}
+    assert m["default"] in ("pass_groups", "all_to_all") and set(m) == {"default", "pass_groups", "all_to_all", "link_probe", "estimate_at_probed_rate"}
+    assert m["link_probe"]["GBps_per_peer"] == 0.0 and "error" not in m["link_probe"]  # one rank: a communicator without peers
     for name in ("pass_groups", "all_to_all"):
         e = m[name]
         for k in ("groups", "ranks_per_group", "stream_factor", "passes", "passes_per_gpu", "s_per_step", "particles_per_s",
@@ -75,6 +76,7 @@ def test_bench_keeps_its_line_when_the_second_split_is_killed():
     assert d["value"] > 1e7 and d["modes"]["default"] in ("pass_groups", "all_to_all")
     other = "all_to_all" if d["modes"]["default"] == "pass_groups" else "pass_groups"
     assert "signal %d" % int(signal.SIGTERM) in d["modes"][other]["error"]
+    assert d["aborted"] is True and r.returncode != 0  # the line is kept AND the launcher sees a failed run
     assert d["modes"][d["modes"]["default"]]["s_per_step"] > 0
 
 

@@ -30,7 +30,15 @@ EXPECTED = [
     ("2048 ZA", "launch_xfft_seq_t", "N = 2048, E = 16"),
     ("1024 ZA", "launch_yfft_f_t", "N = 1024, E = 16, W = 8,"),
     ("1024 ZA", "launch_xfft_seq_t", "N = 1024, E = 16"),
-    # PPD=2048 PLT+rescale (BASELINE C3): packed PLT3 arrays
+    # PPD=2048 PLT+rescale (BASELINE C3) and PPD=1024 PLT on one rank: the fused generator + z FFT (zd_kernels_fz.hip), the ky = 0 row
+    # through the general kernels, the x stage of the plane-interleaved rows
+    ("2048 PLT fused", "launch_genz_t", "L = 1024, R = 2, PLAW = false"),
+    ("1024 PLT fused", "launch_genz_t", "L = 1024, R = 1, PLAW = false"),
+    ("1024 PLT fused", "launch_genz_t", "L = 1024, R = 1, PLAW = true"),
+    ("2048 PLT fused", "launch_gen_z", "ZR = 16, NJ = 6, PLT = true, PLAW = false"),
+    ("2048 PLT fused", "launch_xfft_q2_plt_t", "N = 2048, E = 16"),
+    ("1024 PLT fused", "launch_xfft_q2_plt_t", "N = 1024, E = 16"),
+    # ... and the two-kernel stage on plain rows (ZD_StoreMode = packed, several ranks, options the fused kernel leaves alone)
     ("2048 PLT", "launch_genf_z", "ZR = 16, KIND = 4, PLAW = false"),
     ("2048 PLT", "launch_eig_lines", ""),
     ("2048 PLT", "launch_zfft_t", "L = 1024, E = 16, W = 8"),

@@ -79,7 +79,7 @@ EXPORTED_SYMBOLS = [
     "zd_plan_stream_factor", "zd_plan_passes", "zd_plan_plane_step", "zd_plan_record_size", "zd_plan_exchange_bytes", "zd_plan_local_planes",
     "zd_plan_plane_z", "zd_plan_stage_z", "zd_plan_stage_y", "zd_plan_stage_x", "zd_plan_stats", "zd_comm_unique_id", "zd_comm_create", "zd_comm_destroy", "zd_plan_ring_bytes", "zd_plan_run_pass",
     "zd_params_from_file", "zd_pk_create_from_file", "zd_pk_create_powerlaw", "zd_pk_power",
-    "zd_pk_sigmaR", "zd_pk_destroy", "zd_load_eigmodes", "zd_free", "zd_comm_abort", "zd_comm_traffic", "zd_choose_pass_groups", "zd_plan_run_passes",
+    "zd_pk_sigmaR", "zd_pk_destroy", "zd_load_eigmodes", "zd_free", "zd_comm_abort", "zd_comm_traffic", "zd_choose_pass_groups", "zd_plan_run_passes", "zd_comm_probe", "zd_choose_pass_groups_measured",
     "zd_dispatch_report",
 ]
 # test scaffolding: exists only in the -DZD_TESTING library (csrc/zd_testing.h, `make testing`), never in the product
@@ -155,6 +155,8 @@ def _load(path, testing):
     L.zd_comm_destroy.restype = None
     L.zd_comm_abort.argtypes = [vp]
     L.zd_comm_abort.restype = None
+    L.zd_comm_probe.argtypes = [vp, i64, i32, C.POINTER(C.c_double)]
+    L.zd_choose_pass_groups_measured.argtypes = [C.POINTER(ZdParams), C.c_int, i64, C.c_double, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_double)]
     L.zd_comm_traffic.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.c_int]
     L.zd_comm_traffic.restype = None
     L.zd_plan_ring_bytes.argtypes = [vp, C.POINTER(i32)]
@@ -470,6 +472,13 @@ class Comm:
         a, b = C.c_int64(), C.c_int64()
         self.L.zd_comm_traffic(self.h, C.byref(a), C.byref(b), int(reset))
         return a.value, b.value
+
+    def probe(self, bytes_per_peer=128 << 20, reps=3):
+        """GB/s one link of this rank carries per direction while every peer is sent to and received from at once (0.0 without peers)"""
+        r = C.c_double()
+        if self.L.zd_comm_probe(self.h, int(bytes_per_peer), int(reps), C.byref(r)):
+            raise RuntimeError("zd_comm_probe failed")
+        return r.value
 
     def abort(self):
         if self.h:

@@ -50,7 +50,7 @@ DispatchSite::DispatchSite(const char *f, int l) : func(f), line(l) {
 }  // namespace zd
 
 int64_t zd_dispatch_report(char *buf, int64_t cap) {
-    int64_t need = 0;
+    int64_t need = 0, w = 0;  // bytes the whole report takes / bytes written: whole lines only, nothing after the first that does not fit
     for (zd::DispatchSite *s = zd::g_dispatch_head.load(std::memory_order_acquire); s; s = s->next) {
         char line[1024];
         int n = snprintf(line, sizeof line, "%lld\t%d\t%s\n", s->count.load(std::memory_order_relaxed), s->line, s->func);
@@ -59,10 +59,13 @@ int64_t zd_dispatch_report(char *buf, int64_t cap) {
             n = (int) sizeof line - 1;
             line[n - 1] = '\n';
         }
-        if (buf && need + n < cap) memcpy(buf + need, line, (size_t) n);
+        if (buf && w == need && w + n < cap) {
+            memcpy(buf + w, line, (size_t) n);
+            w += n;
+        }
         need += n;
     }
-    if (buf && cap > 0) buf[need < cap ? need : cap - 1] = 0;
+    if (buf && cap > 0) buf[w] = 0;  // (w < cap: a C string of at most cap - 1 bytes, every byte of it written)
     return need + 1;
 }
 
@@ -296,8 +299,10 @@ extern "C" {
 // power-of-two grids keep the reference's arrays for ZD_qdensity (their kernels exist); ZD_qdensity = 2 (density only), PLT and
 // f_NL with a density stay on the convolution path for composite PPDs.
 static bool dens_fields(const zd_params *p) {
-    return p->qdensity == 1 && !p->qPLT && p->f_NL == 0. && p->qoneslab < 0 && !is_pow2(p->ppd) && zd::np2_supported_ppd((int) p->ppd)
-           && (p->store_mode == ZD_STORE_AUTO || p->store_mode == ZD_STORE_FIELDS);
+    // (PPD <= 8192: beyond it — 8640 = 64 * 135 — only the plain ZA field store has been run; the plan then refuses ZD_qdensity
+    // with the message of the PPD > 8192 gate instead of taking a six-field store nobody has tested at that size)
+    return p->qdensity == 1 && !p->qPLT && p->f_NL == 0. && p->qoneslab < 0 && !is_pow2(p->ppd) && p->ppd <= 8192
+           && zd::np2_supported_ppd((int) p->ppd) && (p->store_mode == ZD_STORE_AUTO || p->store_mode == ZD_STORE_FIELDS);
 }
 // Packed stores (zd_device.h PACK_*): without ZD_qdensity the density field is not transformed.
 static int pack_mode(const zd_params *p, int R) {
@@ -519,6 +524,49 @@ int zd_choose_pass_groups(const zd_params *p, int ngpu, int64_t budget_bytes, in
     }
     *groups        = g;
     *stream_factor = R;
+    return 0;
+}
+
+// The choice with a measured link rate (zd_comm_probe).  Where zd_choose_pass_groups takes one GPU per pass group — nothing
+// travels, every GPU generates all the modes once per pass of its own — the single group with the all-to-all is the alternative:
+// the ranks share the generations (rows ky = rank mod G), the block store is transposed between the z and the y / x passes
+// (src/block_array.cpp:387-414,466-504) in plane groups over every link of a GPU at once, passes pipelined over two send stores.
+// Both are priced from unit times of ONE MI355X per particle of the grid (measured, DESIGN.md 4 / 5 — PPD = 4096: ZA a full
+// generation 0.141 s, the z FFT beside it +0.185 s / 4 passes... per particle below; PLT from the PPD = 4096 PLT run; composite
+// grids: y + x at 1.85x) and the exchange's bytes per link at the measured rate:
+//   pass groups:  T = c_gen N^3 P / G + (c_zf + c_xy) N^3 / G                         P passes in all, P / G per GPU
+//   all-to-all:   T = t_z / P' + max(t_ex, t_xy + t_z (P' - 1) / P') + 0.05 t_xy      t_z = (c_gen P' + c_zf) N^3 / G, t_xy = c_xy N^3 / G,
+//                                                                                     t_ex = store bytes per rank and pass x P' / G / rate
+// (first Z stage exposed, the others and the XY stages beside the exchange, the last plane group's XY behind it; P' = 1: t_z + max).
+int zd_choose_pass_groups_measured(const zd_params *p, int ngpu, int64_t budget_bytes, double link_GBps, int32_t *groups,
+                                   int32_t *stream_factor, double *est_seconds) {
+    if (est_seconds) est_seconds[0] = est_seconds[1] = 0.0;
+    if (zd_choose_pass_groups(p, ngpu, budget_bytes, groups, stream_factor)) return 1;
+    if (!(link_GBps > 0.0) || ngpu < 2 || p->pass_groups != 0 || *groups != ngpu) return 0;  // nothing to decide
+    zd_params q   = *p;
+    q.pass_groups = 1;
+    int32_t g1 = 0, R1 = 0;
+    if (zd_choose_pass_groups(&q, ngpu, budget_bytes, &g1, &R1) || g1 != 1) return 0;  // no single group for this job: keep
+    const double n3 = (double) p->ppd * (double) p->ppd * (double) p->ppd;
+    const bool comp = !is_pow2(p->ppd);
+    // (ZD_k_cutoff = c keeps 1 / c^3 of the modes and 1 / c^2 of the (kx, ky) columns: generation and z FFT shrink with them,
+    // the y / x stages and the records do not)
+    const double kc = p->k_cutoff > 1.0 ? p->k_cutoff : 1.0;
+    const double c_gen = (p->qPLT ? 3.9e-12 : 2.05e-12) / (kc * kc * kc), c_zf = (p->qPLT ? 3.5e-12 : 2.7e-12) / (kc * kc);
+    const double c_xy  = (p->qPLT ? 3.7e-11 : 2.0e-11) * (comp ? 1.85 : 1.0);
+    const int P0 = *stream_factor / plan_plane_step(p, *stream_factor, 1), P1 = R1 / plan_plane_step(&q, R1, ngpu);
+    const double t_pg = c_gen * n3 * P0 / ngpu + (c_zf + c_xy) * n3 / ngpu;
+    const double t_z = (c_gen * P1 + c_zf) * n3 / ngpu, t_xy = c_xy * n3 / ngpu;
+    const double t_ex = (double) store_bytes(&q, R1, ngpu) * P1 / ngpu / (link_GBps * 1e9);
+    const double t_a2a = P1 >= 2 ? t_z / P1 + std::max(t_ex, t_xy + t_z * (P1 - 1) / P1) + 0.05 * t_xy : t_z + std::max(t_ex, t_xy) + 0.05 * t_xy;
+    if (est_seconds) {
+        est_seconds[0] = t_pg;
+        est_seconds[1] = t_a2a;
+    }
+    if (t_a2a < t_pg) {
+        *groups        = 1;
+        *stream_factor = R1;
+    }
     return 0;
 }
 
@@ -822,7 +870,7 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
             zdpcg::make_bit_table(b);
             return b;
         }();
-        if (zdk_upload_bit_table(&bt) != 0) {
+        if (zdk_upload_bit_table(&bt) != 0 || zdk_upload_bit_table_fz(&bt) != 0) {
             fprintf(stderr, "zeldovich_hip: uploading the RNG jump table failed\n");
             zd_plan_destroy(pl);
             return 1;
@@ -1013,10 +1061,20 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         S.one_block = (nranks == 1 && lBk == S.lHq + 1 && lBz == 0 && !S.rows_outer) ? 1 : 0;
         int row_pad = store_row_pad(pl->N);  // in complex elements
         if (const char *env = tune_env("ZD_PAD")) sscanf(env, "%d", &row_pad);
-        S.pitch      = pl->N + row_pad;
+        // Fused Z stage of the packed PLT store (zd_kernels_fz.hip: generator + z FFT in one kernel, the folded inputs stay on the
+        // CU): one rank, z lines of 1024 points (PPD = 1024, or 2048 = BASELINE C3 at R = 2), the table generator's arithmetic,
+        // version-2 streams, the whole field; and the kz = N/2 plane must be dead (the kernel never draws it: true unless
+        // CornerModes is set together with ZD_k_cutoff != 1).  ZD_StoreMode = packed keeps the two-kernel stage (A/B runs).
+        // Its store interleaves 4 planes along x (StoreLayout::lq = 2) so that a lane's 4 neighbours — 4 consecutive planes of
+        // ONE column — write a 64-byte run.
+        pl->fused_z = pl->pack == zd::PACK_PLT3 && p->store_mode == ZD_STORE_AUTO && S.one_block && zd::genz_plt_supported(pl->N, pl->L)
+                      && g.genf_tab && !v1 && !p->qonemode && p->qoneslab < 0 && phi_mode == 0 && phik == nullptr && p->k_cutoff >= 1.0
+                      && (g.kmax == pl->half || !p->corner_modes) && (S.prune & 7) == 7 && !tune_env("ZD_NO_FUSED_Z");
+        S.lq         = pl->fused_z ? 2 : 0;
+        S.pitch      = (pl->N + row_pad) << S.lq;
         S.a_rows     = (1 << lBk) << lBz;
         S.zb_rows    = S.a_rows * pl->narray;
-        S.kb_rows    = S.zb_rows * (pl->Zq >> lBz);
+        S.kb_rows    = S.zb_rows * ((pl->Zq >> S.lq) >> lBz);
         S.chunk_rows = S.kb_rows * ((2 * pl->Hq) >> lBk);
     }
 
@@ -1051,6 +1109,7 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         pl->ring_planes = field_ring_planes(pl->N, pl->Zq);
         zd::StoreLayout &Q = pl->SR;
         Q            = S;
+        Q.lq         = 0;
         Q.Hq         = pl->half;
         Q.lHq        = 0;
         while ((1 << Q.lHq) < pl->half) Q.lHq++;
@@ -1087,6 +1146,38 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         }
     }
     g.var_slots     = pl->d_red->sumsq;
+    if (pl->fused_z) {
+        // work items of k_genz_plt: for every half-space row ky >= 1 the live columns kx in (-w, w) (zero rule: column_is_zero), cut
+        // where the draw counter of a row jumps (x = N/2 | N/2 + 1) and into pieces of at most 128 columns (a piece costs its
+        // threads one jump from the row's stream head: ~14 steps of the 2^i table against 4 x 128 draws); longest first
+        std::vector<zd::FzItem> items;
+        const int SEG = 128;
+        for (int kyl = (rank == 0 ? 1 : 0); kyl < pl->Hq; kyl++) {
+            const int ky = rank + nranks * kyl;
+            auto add_range = [&](int xa, int xb) {  // [xa, xb): maximal runs of live columns, in pieces
+                int x = xa;
+                while (x < xb) {
+                    while (x < xb && zd::column_is_zero(S, x > pl->half ? x - pl->N : x, ky)) x++;
+                    int e = x;
+                    while (e < xb && !zd::column_is_zero(S, e > pl->half ? e - pl->N : e, ky)) e++;
+                    for (int q = x; q < e; q += SEG) items.push_back(zd::FzItem{kyl, q, std::min(SEG, e - q), 0});
+                    x = e;
+                }
+            };
+            add_range(0, pl->half + 1);
+            add_range(pl->half + 1, pl->N);
+        }
+        std::stable_sort(items.begin(), items.end(), [](const zd::FzItem &a, const zd::FzItem &b) { return a.n > b.n; });
+        pl->n_fzitems = (unsigned) items.size();
+        if (!items.empty()) {
+            PLCHECK(hipMalloc((void **) &pl->d_fzitems, sizeof(zd::FzItem) * items.size()));
+            PLCHECK(hipMemcpy(pl->d_fzitems, items.data(), sizeof(zd::FzItem) * items.size(), hipMemcpyHostToDevice));
+        }
+        int dev = 0;
+        hipGetDevice(&dev);
+        hipDeviceGetAttribute(&pl->ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (pl->ncu < 1) pl->ncu = 256;
+    }
 
     // ---- folded-input slabs (two, for the gen||zfft overlap): enough rows per launch to fill the chip ----
     {
@@ -1194,6 +1285,7 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
 void zd_plan_destroy(zd_plan *pl) {
     if (!pl) return;
     collect_events(pl);
+    hipFree(pl->d_fzitems);
     hipFree(pl->d_pk);
     hipFree(pl->d_lut);
     hipFree(pl->d_pktab);
@@ -1285,6 +1377,26 @@ static int any_stage_z(zd_plan *pl, int residue, void *d_send, hipStream_t st) {
 
 static int stage_z_impl(zd_plan *pl, int residue, void *d_send, hipStream_t st, bool detached, hipEvent_t wait_ev, hipEvent_t done_ev);
 
+// Z stage of a plan with the fused generator + z FFT (zd_kernels_fz.hip; one rank): the ky = 0 row — conjugate "loser" modes,
+// zeldovich.cpp:485-503 — through the general generator and k_zfft (one row), every other row through k_genz_plt; one stream
+static int fused_stage_z(zd_plan *pl, int residue, void *d_send, hipStream_t st, bool detached, hipEvent_t wait_ev, hipEvent_t done_ev) {
+    if (detached && wait_ev) HIPCHECK(hipStreamWaitEvent(st, wait_ev, 0));
+    pl->g.accum_var = pl->var_pending ? 1 : 0;  // once per run: every pass sees every mode
+    pl->var_pending = false;
+    const int zspan = span_begin(pl, ZD_K_ZSTAGE, st);
+    HIPCHECK(hipMemsetAsync(pl->d_tilectr, 0, sizeof(unsigned), st));
+    tick(pl, ZD_K_GEN, st, true);
+    if (zd::launch_gen(pl->g, pl->J, pl->jobs, pl->S, 0, 1, pl->L, residue, residue, pl->d_twN, pl->d_Y[0], nullptr, pl->gen_max_wgs, st)) return 1;
+    if (zd::launch_zfft(pl->L, pl->jobs, pl->S, 0, 0, 1, pl->Zq, pl->d_Y[0], pl->d_twL, d_send, st)) return 1;
+    if (zd::launch_genz_plt(pl->g, pl->S, 0, pl->L, residue, pl->n_fzitems, pl->d_fzitems, pl->d_twN, pl->d_twL, d_send, pl->d_tilectr,
+                            pl->ncu, st))
+        return 1;
+    tick(pl, ZD_K_GEN, st, false);
+    span_end(pl, zspan, st);
+    if (detached && done_ev) HIPCHECK(hipEventRecord(done_ev, st));
+    return 0;
+}
+
 int zd_plan_stage_z(zd_plan *pl, int residue, void *d_send, void *hip_stream) {
     return stage_z_impl(pl, residue, d_send, (hipStream_t) hip_stream, false, nullptr, nullptr);
 }
@@ -1306,6 +1418,7 @@ static int stage_z_impl(zd_plan *pl, int residue, void *d_send, hipStream_t st, 
         return 0;
     }
     if (pl->any) return any_stage_z(pl, residue, d_send, st);
+    if (pl->fused_z) return fused_stage_z(pl, residue, d_send, st, detached, wait_ev, done_ev);
     const int residue2 = pl->pstep == 2 ? residue + pl->R / 2 : residue;
     pl->g.accum_var = (pl->pack != zd::PACK_NONE && pl->var_pending) ? 1 : 0;  // once per run: every pass sees every mode
     pl->var_pending = false;
@@ -1986,6 +2099,7 @@ int zd_test_yfft_variant(int32_t n, int32_t variant, int32_t narray, int32_t npl
         lBk = (lt + 1) / 2; lBz = lt - lBk;
         while ((1 << lBz) > nplanes) lBz--;
     }
+    S.lq = 0;
     S.lBk = lBk; S.lBz = lBz; S.rows_outer = 0; S.one_block = 0; S.pitch = n; S.prune = 0; S.nt = 0; S.kmax = 0; S.fund2 = 0; S.k2_cutoff = 0;
     S.a_rows = (1 << lBk) << lBz;
     S.zb_rows = S.a_rows * narray;

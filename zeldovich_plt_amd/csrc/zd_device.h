@@ -127,6 +127,13 @@ struct StoreLayout {
     int prune, kmax;  // bits: 1 generator, 2 z FFT, 4 y FFT (per element), PRUNE_YTILE; bits 3..12 are tuning ablations
     double fund2, k2_cutoff;
     int nt;  // tuning (ZD_NT): non-temporal accesses, bit 0 y loads, 1 y stores, 2 x loads, 3 z stores, 4 z loads, 5 ring stores / 6 first-potential loads of k_yfft_f, 7 record stores
+    // Plane-interleaved rows (round 5; the fused generator + z FFT of the packed PLT store, zd_kernels_fz.hip): 2^lq consecutive
+    // planes share a row image, element (plane zl, column x) of a row sits at (x << lq) + (zl & (2^lq - 1)) of the row of plane
+    // group zl >> lq; `pitch` is then the pitch of that interleaved row ((N + pad) << lq) and the strides count plane GROUPS.
+    // A fused z workgroup holds ONE column's z lines (all planes, lanes along the planes): with lq = 2 its store instruction writes
+    // 64-byte runs (4 planes x 16 B) instead of 16-byte pieces, the y stage's 8-line tile is 2 columns x 4 planes = one 128-byte
+    // line, the x stage transforms the lines of a plane pair side by side.  0 everywhere else.
+    int lq;
 };
 
 // StoreLayout::prune bit: the y stage skips whole column tiles without a live row.  Set only together with
@@ -168,11 +175,21 @@ ZD_HD int store_row(const StoreLayout &L, int chunk, int zl, int a, int slot) {
 ZD_HD long long store_offset(const StoreLayout &L, int chunk, int zl, int a, int slot) {
     return (long long) store_row(L, chunk, zl, a, slot) * L.pitch;
 }
+// element offset of (chunk, local plane zl, array a, row slot, column x), plane-interleaved rows included (StoreLayout::lq)
+ZD_HD long long store_elem(const StoreLayout &L, int chunk, int zl, int a, int slot, int x) {
+    return (long long) store_row(L, chunk, zl >> L.lq, a, slot) * L.pitch + (((long long) x) << L.lq) + (zl & ((1 << L.lq) - 1));
+}
 ZD_HD long long row_offset(const StoreLayout &L, int zl, int a, int ky) {
     int c, s;
     row_slot(L, ky, c, s);
     return store_offset(L, c, zl, a, s);
 }
+
+// work item of the fused generator + z FFT (zd_kernels_fz.hip): `n` consecutive columns x0 .. x0 + n - 1 (not across x = N/2 | N/2 + 1,
+// where the draw counter of a row jumps) of the half-space row with local index kyl
+struct FzItem {
+    int kyl, x0, n, pad;
+};
 
 // Jobs of the z stage: which real-linear combination of the mode's fields is transformed and where
 // the result goes (see DESIGN.md "Hermitian pairing as FFT jobs").

@@ -19,10 +19,12 @@
 #include "zd_device.h"
 #include "zd_epi.h"
 #include "zd_launch.h"
+#include "zd_genmath.h"
 
 using namespace zd;
 using zdfft::cplx;
 using zdpcg::u128;
+using namespace zdgen;
 
 __constant__ zdpcg::BitTable c_bits;
 
@@ -79,9 +81,6 @@ extern "C" int zdk_upload_bit_table(const zdpcg::BitTable *host) {
 
 // ------------------------------------------------------------------------------------------------
 // device math for one mode
-
-// i mod N for 0 <= i < 2^31 (N a power of two on the production path; PPD = 2^a 3^b takes the division)
-__device__ __forceinline__ int modn(int N, int i) { return (N & (N - 1)) == 0 ? (i & (N - 1)) : (int) ((unsigned) i % (unsigned) N); }
 
 __device__ __forceinline__ u128 advance_bits(u128 s, uint64_t delta) {
     for (int i = 0; i < zdpcg::NBITS; i++) {
@@ -173,37 +172,6 @@ __device__ __forceinline__ void gauss_mode(const GenConst &g, double k2, uint64_
     gauss_from_pk(g, ZD_TUNE(g.ablate & 1) ? 1e-9 * k2 : pk_power<PLAW>(g, k2), r1, r2, dr, di);
 }
 
-// interp_eigmode + get_eigenmode (src/zeldovich.cpp:154-276); out = e_x,e_y,e_z (weighted), lambda.
-// The per-axis part of the lookup (table index or lower/upper corner + fraction, incl. the "never
-// interpolate across the +-Nyquist seam" rule :176-183 and the wrap :194-198) depends on one wavenumber
-// only, so the generator hoists x (fixed per thread) and y (fixed per row) out of its mode loop.
-struct EigAxis {
-    int l, h;   // exact stride: l = table index, h unused; interpolation: lower / upper corner
-    double f;   // fraction towards h
-};
-__device__ __forceinline__ EigAxis eig_axis(const GenConst &g, int ik) {  // ik = table-space index 0..N-1
-    EigAxis a;
-    const int N = g.N, ep = (int) g.eig_ppd;
-    if (ep % N == 0) {
-        a.l = ik * (ep / N);
-        a.h = a.l;
-        a.f = 0.0;
-        return a;
-    }
-    const int halfppd = ep / 2 + 1, ppdhalf = ep / 2;
-    double f = ((double) ep) / N * ik;
-    if (f > ppdhalf && f < halfppd) f = floor(f + 1);
-    a.l = (int) f;
-    a.h = a.l + 1;
-    if (a.h == ep) a.h = 0;
-    a.f = f - a.l;
-    return a;
-}
-__device__ __forceinline__ int eig_index_x(const GenConst &g, int kx) { return kx < 0 ? g.N + kx : kx; }
-__device__ __forceinline__ int eig_index_z(const GenConst &g, int kz) {
-    const int i = kz < 0 ? g.N + kz : kz;
-    return i > g.N / 2 ? g.N - i : i;  // +k half-space of the rfft layout
-}
 __device__ __forceinline__ void get_eigenmode_dev(const GenConst &g, int kx, int ky, int kz, const EigAxis &ax,
                                                   const EigAxis &ay, const EigAxis &az, double (&out)[4]) {
     const int ep = (int) g.eig_ppd, halfppd = ep / 2 + 1;
@@ -512,170 +480,6 @@ __global__ __launch_bounds__(GEN_BX) void k_gen(GenConst g, GenJumps J, JobList 
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_genf arithmetic.  The generator is VALU-bound (2 x 128-bit LCG steps + Box-Muller + P(k) per mode,
-// redone for every z-residue pass), and a wave's 64 modes have 64 unrelated |k|^2: gathering {P, 1/k^2}
-// from the by-|k|^2 table costs 64 cache-line fills per wave-instruction and was measured to take as
-// long as all the arithmetic together.  So k_genf evaluates everything from small LDS tables
-// (GenfTab, ~22 KB, built on the host in long double):
-//   * one_rand<2> (power_spectrum.cpp:284-308) is kept as the exact integer m = r + 1 (m = 0 <=> r = 2^64-1,
-//     i.e. the value 1.0) and its correctly rounded double; the 2^-64 scale is folded into the callers;
-//   * ln x: x = 2^e f, f in [sqrt(1/2), sqrt(2)), bin j of width 1/256 with c_j ~ 1/centre, ln f = -ln c_j +
-//     log1p(f c_j - 1) (7 terms; the two bins around f = 1 have c = 1 so that ln stays relatively exact near 1);
-//   * e^x = 2^k 2^(j/64) e^r, |r| <= ln2/128 (6 terms);
-//   * cos/sin(2 pi theta): nearest of 512 tabulated directions + a 3-term rotation;
-//   * P(k): SplineFunction::val with per-segment records {x_lo, 1/h, y_lo, y_hi, y2_lo h^2/6, y2_hi h^2/6}.
-// Each is within 4e-16 (relative) of the correctly rounded result; cgauss<2> itself evaluates
-// cos/sin(fl(2*M_PI*theta)), 4e-16 away from the exact angle.
-struct GenfTab {  // offsets in doubles inside the LDS image (zd_capi.cpp: build_genf_table)
-    static constexpr int SC = 0, LG = 1024, EX = 1392, SEG = 1456, GLUT = 1024;
-    static constexpr int lut(int nseg) { return SEG + 6 * nseg; }
-    static constexpr int size(int nseg) { return SEG + 6 * nseg + GLUT / 4; }
-};
-
-// a*b + c as the three-address VOP3 form.  Left to itself the compiler picks the two-address v_fmac_f64 for the
-// Horner steps below and then copies every coefficient into the destination first (a quarter of the loop's vector
-// instructions were such v_mov_b64; the asm form makes the generator ~7 % faster).
-// HAZARD: the compiler's hazard recognizer does not look at the operands of asm statements.  gfx950 needs a wait
-// state between a transcendental VALU op (v_rcp_f64, v_rsq_f64, ...) and the first read of its result; with an asm
-// v_fma_f64 as that first reader the wait state was missing whenever the scheduler happened to put the two back to
-// back (round 1: 1/k^2 wrong -> PLT displacements 15 % off, NaN in the packed ZA kernel; the parity tests caught both).
-// Two guards, neither by convention:
-//   * every transcendental builtin used next to asm FMAs goes through trans_rcp / trans_rsq below, which carry their
-//     own wait state (an `s_nop 0` tied to the result register: one issue cycle per reciprocal, ~3 per mode);
-//   * build() runs check_trans_hazard.py on the gfx950 ISA of this file: no instruction may read a TRANS result in
-//     the next issue slot.
-// -DZD_NO_FMA_ASM builds the plain-fma() version of everything (A/B parity runs).
-__device__ __forceinline__ double trans_rcp(double d) {
-    double r = __builtin_amdgcn_rcp(d);
-    asm volatile("s_nop 0" : "+v"(r));
-    return r;
-}
-__device__ __forceinline__ double trans_rsq(double d) {
-    double r = __builtin_amdgcn_rsq(d);
-    asm volatile("s_nop 0" : "+v"(r));
-    return r;
-}
-__device__ __forceinline__ double fma3(double a, double b, double c) {
-#ifdef ZD_NO_FMA_ASM
-    return fma(a, b, c);
-#endif
-    double d;
-    asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-
-__device__ __forceinline__ double fnma3(double a, double b, double c) {  // -a*b + c
-#ifdef ZD_NO_FMA_ASM
-    return fma(-a, b, c);
-#endif
-    double d;
-    asm volatile("v_fma_f64 %0, -%1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-__device__ __forceinline__ double fmas3(double a, double b, double c) {  // a*b - c
-#ifdef ZD_NO_FMA_ASM
-    return fma(a, b, -c);
-#endif
-    double d;
-    asm volatile("v_fma_f64 %0, %1, %2, -%3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-
-__device__ __forceinline__ double u64_to_double(uint64_t m) {  // round-to-nearest: both halves are exact, one rounding in the fma
-    return fma((double) (uint32_t) (m >> 32), 4294967296.0, (double) (uint32_t) m);
-}
-
-// ln(x * 2^-ebias) for a normal x > 0
-__device__ __forceinline__ double flog(double x, int ebias, const double *T) {
-    double f = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
-    int e    = __builtin_amdgcn_frexp_exp(x);
-    const bool lo = f < 0.70710678118654752440;
-    f = lo ? f + f : f;  // [sqrt(1/2), sqrt(2))
-    e = lo ? e - 1 : e;
-    const int j     = (int) (f * 256.0) - 181;
-    const double2 t = reinterpret_cast<const double2 *>(T + GenfTab::LG)[j];  // {c_j, -ln c_j}
-    const double r  = fma(f, t.x, -1.0);
-    double p = fma3(r, 1.0 / 7.0, -1.0 / 6.0);
-    p = fma3(r, p, 0.2);
-    p = fma3(r, p, -0.25);
-    p = fma3(r, p, 1.0 / 3.0);
-    p = fma3(r, p, -0.5);
-    p = fma3(r, p, 1.0);
-    const double de = (double) (e - ebias);
-    return fma3(de, 0.69314716756343842, fma3(de, 1.2996506893901347e-08, fma3(r, p, t.y)));
-}
-
-__device__ __forceinline__ double fexp(double x, const double *T) {
-    x = fmin(fmax(x, -745.0), 709.0);
-    const double n = __builtin_rint(x * 92.332482616893656877);  // 64 / ln 2
-    double r = fma3(n, -0.010830424493178725, x);
-    r = fma3(n, -2.0307042021720854e-10, r);
-    const int ni = (int) n;
-    double p = fma3(r, 1.0 / 720, 1.0 / 120);
-    p = fma3(r, p, 1.0 / 24);
-    p = fma3(r, p, 1.0 / 6);
-    p = fma3(r, p, 0.5);
-    p = fma3(r, p, 1.0);
-    p = fma3(r, p, 1.0);
-    return ldexp(T[GenfTab::EX + (ni & 63)] * p, ni >> 6);
-}
-
-__device__ __forceinline__ double frcp(double d) {
-    double r = trans_rcp(d);
-    const double e = fma(-d, r, 1.0);
-    r = fma3(e, r, r);
-    return fma3(fnma3(d, r, 1.0), r, r);
-}
-
-// sqrt(v) for v >= 0 (v = 0 -> 0); v is far from the subnormal range (P(k) |ln R| of a mode that carries power)
-__device__ __forceinline__ double sqrt_pos(double v) {
-    const double r = trans_rsq(v);
-    double g = v * r, h = 0.5 * r;
-    const double e = fnma3(h, g, 0.5);
-    g = fma3(g, e, g);
-    h = fma3(h, e, h);
-    g = fma3(fnma3(g, g, v), h, g);
-    g = fma3(fnma3(g, g, v), h, g);
-    return v > 0.0 ? g : 0.0;
-}
-
-// cos/sin(2 pi m 2^-64) from sc[j] = {cos, sin}(2 pi j / 512)
-__device__ __forceinline__ void sincos_u01(double md, const double *T, double &sn, double &cs) {
-    const double t = md * 2.77555756156289135e-17;  // m * 2^-55 = theta * 512, exact
-    const double j = __builtin_rint(t);
-    const double b = (t - j) * 1.22718463030851298e-02;  // 2 pi / 512 * (theta*512 - j), |b| <= pi/512
-    const double2 a = reinterpret_cast<const double2 *>(T + GenfTab::SC)[((int) j) & 511];
-    const double b2 = b * b;
-    const double sb = fma3(b * b2, fma3(b2, 8.33333333333333322e-03, -1.66666666666666657e-01), b);          // sin b
-    const double cm = b2 * fma3(b2, fma3(b2, -1.38888888888888894e-03, 4.16666666666666644e-02), -0.5);     // cos b - 1
-    cs = a.x + fmas3(a.x, cm, a.y * sb);
-    sn = a.y + fma3(a.y, cm, a.x * sb);
-}
-
-// PowerSpectrum::power (src/power_spectrum.cpp:225-261) for k2 = |k|^2 > 0, from the LDS image
-template <bool PLAW>
-__device__ __forceinline__ double genf_power(const GenConst &g, const double *T, double k2) {
-    const double v = 0.5 * flog(k2, 0, T);  // ln k
-    double val;
-    if constexpr (PLAW) {
-        val = g.powerlaw_index * v;
-    } else {
-        const int nseg = g.genf_nseg;
-        const unsigned short *lut = reinterpret_cast<const unsigned short *>(T + GenfTab::lut(nseg));
-        int c = (int) ((v - g.glut_x0) * g.glut_inv_dx);
-        c     = c < 0 ? 0 : (c >= GenfTab::GLUT ? GenfTab::GLUT - 1 : c);
-        int klo = lut[c];
-        const double *seg = T + GenfTab::SEG;
-        while (klo < nseg - 1 && seg[6 * (klo + 1)] <= v) klo++;  // largest klo with x[klo] <= v (spline_function.h:146-152)
-        const double2 *rec = reinterpret_cast<const double2 *>(seg + 6 * klo);
-        const double2 q0 = rec[0], q1 = rec[1], q2 = rec[2];  // {x_lo, 1/h}, {y_lo, y_hi}, {c_lo, c_hi}
-        const double b = (v - q0.x) * q0.y, a = 1.0 - b;
-        val = fma3(a, q1.x, b * q1.y) + fma3(fmas3(a * a, a, a), q2.x, fmas3(b * b, b, b) * q2.y);
-    }
-    return fexp(fma(-k2, g.pk_smooth2, val), T) * g.pk_norm;
-}
-
-// ------------------------------------------------------------------------------------------------
 // k_genf: the production generator for the half-space rows ky >= 1 (k_gen above stays the general
 // kernel: the ky = 0 plane with its conjugate "loser" modes, the f_NL passes, the one-mode filter, the
 // direct P(k) evaluation and the tuning ablations).  Same mapping, same RNG walk and same output as
@@ -694,11 +498,6 @@ enum { GENF_DENS = 0, GENF_ZA = 1, GENF_PLT = 2, GENF_ZAP = 3 /* PACK_ZAPAIR */,
        GENF_ZAF = 5 /* PACK_ZAFIELD: the sums of GENF_ZAP written out as they are (E, Z of both residues) */,
        GENF_PLTF = 6 /* PACK_PLTFIELD: the sums of GENF_PLTN written out as they are */,
        GENF_ZAFD = 7 /* PACK_ZAFIELD + ZD_qdensity = 1: the four potentials and the density sum D of both residues (six fields) */ };
-
-__device__ __forceinline__ void cmac(double &ar, double &ai, double c, double dr, double di) {
-    ar = fma(c, dr, ar);
-    ai = fma(c, di, ai);
-}
 
 // get_eigenmode for k_genf: the (x, y) part of the lookup — table offsets of the 4 corner columns and the products
 // w_x w_y — depends on the thread's kx and the row's ky only and is prepared once per tile; per mode remain the two
@@ -1688,13 +1487,17 @@ __global__ __launch_bounds__(W *L / E) void k_zfft(JobList jobs, StoreLayout S, 
     const int xt   = (N - x) & (N - 1);
     int t2 = t;
     asm volatile("" : "+v"(t2));  // keep the store-address arithmetic after the FFT (register pressure)
+    // (plane-interleaved rows, StoreLayout::lq — the fused PLT Z stage's store, whose ky = 0 row comes through here: planes of a
+    // group share a row, column x of plane zl sits at (x << lq) + zl % 2^lq; lq = 0 everywhere else)
+    const int lq = S.lq, qm = (1 << lq) - 1;
 #pragma unroll
     for (int e = 0; e < E; e++) {
         const int z2  = t2 + T * e;
         const int dst = z2 >> lZq, zl = z2 & (Zq - 1);  // Zq = 2^lZq
-        const int row = store_row(S, dst, zl, arr, loc_self);
-        if (st_self) st_stream(out + ((long long) row * S.pitch + x), cplx{re[e], im[e]}, ZD_TUNE(S.nt & 8));
-        if (st_twin) st_stream(out + ((long long) (row + drow) * S.pitch + xt), cplx{sgr * re[e], sgi * im[e]}, ZD_TUNE(S.nt & 8));
+        const int row = store_row(S, dst, zl >> lq, arr, loc_self);
+        if (st_self) st_stream(out + ((long long) row * S.pitch + ((long long) x << lq) + (zl & qm)), cplx{re[e], im[e]}, ZD_TUNE(S.nt & 8));
+        if (st_twin)
+            st_stream(out + ((long long) (row + drow) * S.pitch + ((long long) xt << lq) + (zl & qm)), cplx{sgr * re[e], sgi * im[e]}, ZD_TUNE(S.nt & 8));
     }
 }
 
@@ -1713,7 +1516,9 @@ __global__ __launch_bounds__(W *N / E, MINW) void k_yfft(StoreLayout S, const cp
     constexpr int G = W >= 8 ? 1 : 8 / W;
     int tile = blockIdx.x;
     if constexpr (G > 1 && (N / W) % (8 * G) == 0) tile = ((tile / (8 * G)) * 8 + (tile % 8)) * G + ((tile / 8) % G);
-    const int x = tile * W + w;
+    // plane-interleaved rows (StoreLayout::lq, single-rank stores only): the tile's W lines are W / 2^lq columns x 2^lq planes of the
+    // plane group blockIdx.z — the same contiguous W x 16 bytes of every row; xq = position inside the interleaved row
+    const int xq = tile * W + w, x = xq >> S.lq;
     const int zl = blockIdx.z, a = blockIdx.y;
     const int kxs = x > N / 2 ? x - N : x;
     // a tile none of whose columns has a live row: the z stage wrote nothing there and the x stage takes zeros for those
@@ -1726,7 +1531,7 @@ __global__ __launch_bounds__(W *N / E, MINW) void k_yfft(StoreLayout S, const cp
         // single rank, all 2*Hq row slots of a (plane, array) contiguous: one 64-bit scalar base per
         // workgroup and 32-bit byte offsets per element (half the address registers, no spills)
         char *base = reinterpret_cast<char *>(data + (long long) store_row(S, 0, zl, a, 0) * S.pitch);
-        const unsigned xb = (unsigned) x * 16u, pb = (unsigned) S.pitch * 16u;
+        const unsigned xb = (unsigned) xq * 16u, pb = (unsigned) S.pitch * 16u;
 #pragma unroll
         for (int e = 0; e < E; e++) {
             const int ky = t + T * e;
@@ -2415,6 +2220,93 @@ __global__ __launch_bounds__(N / E, 2) void k_xfft_seq_plt(StoreLayout S, EpiCon
     xfft_reduce<NT, 3>(lds, red, 0.0, mx);
 }
 
+// k_xfft_q2_plt: k_xfft_seq_plt for a store with plane-interleaved rows (StoreLayout::lq = 2, the fused PLT Z stage): a row of
+// the store holds 4 planes side by side (64 bytes per column), a workgroup transforms the lines of TWO of them (w = thread % 2:
+// lanes 2i, 2i + 1 read 32 contiguous bytes, the other half of every 64 belongs to the workgroup of the neighbouring pair, which
+// runs next to it on the same XCD), ColsInner<N, 2> exchanges, records from the registers as there.  256 threads at N = 2048, two
+// workgroups per CU.  Planes outside [plane0, plane0 + nplanes) of a pair are transformed but deliver nothing.
+// The two workgroups of a plane group (h = 0, 1: planes 4q + 2h, 4q + 2h + 1) read the same 128-byte lines: they are made
+// neighbours in the dispatch stream of ONE XCD (workgroups go to the XCDs round-robin by their linear index: row y = xcd mod 8,
+// positions alternate h = 0, 1), so that the second one finds the lines in that XCD's L2 (as two distant workgroups every line was
+// fetched from HBM twice: x stage of PPD=2048 PLT 201 ms against 134 on the plain rows).
+//   grid: (2 N, plane groups touched)   block: 2 N/E
+template <int N, int E>
+__global__ __launch_bounds__(2 * N / E, 2) void k_xfft_q2_plt(StoreLayout S, EpiConst ec, const cplx *__restrict__ tw,
+                                                            const cplx *__restrict__ data, int plane0, int nplanes, int z_first,
+                                                            int z_step, char *__restrict__ records, Reduce *__restrict__ red) {
+    using PL  = zdfft::Plan<N, E>;
+    using LDS = zdfft::ColsInner<N, 2>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int T = PL::T, NT = 2 * T;
+    const int w = threadIdx.x & 1, t = threadIdx.x >> 1;
+    static_assert(N % 8 == 0, "rows are dealt to the 8 XCDs");
+    const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3, h = pos & 1;
+    const int y = ((pos >> 1) << 3) + xcd;
+    const int pl = 4 * ((plane0 >> 2) + (int) blockIdx.y) + 2 * h + w;  // this thread's plane of the store
+    if (pl - w + 1 < plane0 || pl - w >= plane0 + nplanes) return;      // (uniform) neither plane of the pair is asked for
+    const bool active = pl >= plane0 && pl < plane0 + nplanes;
+    const int pi = pl - plane0;                                      // its position among the delivered planes
+    double *c2i = lds + LDS::SIZE;                                   // [x][w] = vz; a thread reads back only what it wrote itself
+    double c0r[E], c0i[E], c2r[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) c0r[e] = c0i[e] = c2r[e] = 0.0;
+    const int z = z_first + z_step * pi;
+    MaxAbs mx;
+    const long long plane_rec0 = (long long) pi * N * N;
+    const int sub = pl & 3;
+#pragma unroll 1
+    for (int it = 0; it < 3; it++) {
+        const int a = it == 0 ? 0 : (it == 1 ? 2 : 1);
+        const cplx *src = data + row_offset(S, pl >> 2, a, y) + sub;
+        double re[E], im[E];
+        int ta = t;
+        asm volatile("" : "+v"(ta));
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const cplx v = src[(x_is_dead(ec, ta + T * e) ? 0 : ta + T * e) << 2];  // (see k_xfft)
+            re[e] = v.x;
+            im[e] = v.y;
+        }
+        int t3 = t;
+        asm volatile("" : "+v"(t3));
+#pragma unroll
+        for (int e = 0; e < E; e++)
+            if (x_is_dead(ec, t3 + T * e)) re[e] = im[e] = 0.0;
+        __syncthreads();  // the previous transform's last LDS reads are done
+        zdfft::fft_line<PL, LDS>(re, im, t, w, lds, tw);
+        int t2 = t;
+        asm volatile("" : "+v"(t2));
+        if (it == 0) {
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                c0r[e] = re[e];
+                c0i[e] = im[e];
+            }
+            continue;
+        }
+        if (it == 1) {
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                c2r[e] = re[e];
+                c2i[2 * (t2 + T * e) + w] = im[e];
+            }
+            continue;
+        }
+        if (active) {
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const int xx = t2 + T * e;
+                const double pos[3] = {c0r[e], re[e], im[e]};
+                const double vel[3] = {c0i[e] * ec.vnorm, c2r[e] * ec.vnorm, c2i[2 * xx + w] * ec.vnorm};
+                max_track(mx, pos, ((unsigned long long) z * N + (unsigned long long) y) * N + (unsigned long long) xx);
+                if (records) emit_record(records, plane_rec0 + (long long) y * N + xx, ec, z, y, xx, pos, vel);
+            }
+        }
+    }
+    __syncthreads();
+    xfft_reduce<NT, 3>(lds, red, 0.0, mx);
+}
+
 // k_xfft_two: the same x pass as two launches of one line per workgroup (PPD = 16384: a line alone takes the 1024 threads
 // of a workgroup at 128 VGPRs, and holding a second line's results beside the transform spilled; PPD = 8192 with PLT: a
 // record needs all three arrays).  Launch 0 transforms the arrays the records only READ, each over its own ring row;
@@ -2985,7 +2877,11 @@ static int launch_yfft_t(const StoreLayout &S, int nplanes, const void *tw, void
     const size_t shmem = sizeof(double) * zdfft::ColsInner<N, W>::SIZE;
     set_dyn_lds<k_yfft<N, E, W, 1, false>>(shmem);
     set_dyn_lds<k_yfft<N, E, W, 1, true>>(shmem);
-    dim3 grid(N / W, S.narray, nplanes), block(threads);
+    if (S.lq && (!S.one_block || (N << S.lq) % W || nplanes % (1 << S.lq) || (unsigned long long) S.pitch * N * 16ull >= (1ull << 32))) {
+        fprintf(stderr, "zeldovich_hip: plane-interleaved rows need the single-rank store and whole plane groups\n");
+        return 2;
+    }
+    dim3 grid((N << S.lq) / W, S.narray, nplanes >> S.lq), block(threads);
     if (S.one_block) {
         hipLaunchKernelGGL((k_yfft<N, E, W, 1, true>), grid, block, shmem, st, S, (const cplx *) tw, (cplx *) data);
         ZD_LAUNCH_CHECK();
@@ -3175,6 +3071,18 @@ static int launch_xfft_seq_plt_t(const StoreLayout &S, const EpiConst &ec, const
     return 0;
 }
 
+template <int N, int E>
+static int launch_xfft_q2_plt_t(const StoreLayout &S, const EpiConst &ec, const void *tw, const void *data, int plane0, int nplanes,
+                                int z_first, int z_step, void *records, Reduce *red, hipStream_t st) {
+    const size_t shmem = sizeof(double) * (zdfft::ColsInner<N, 2>::SIZE + 2 * N);  // + vz of array 2, both lines
+    set_dyn_lds<k_xfft_q2_plt<N, E>>(shmem);
+    const int quads = ((plane0 + nplanes - 1) >> 2) - (plane0 >> 2) + 1;
+    dim3 grid(2 * N, quads), block(2 * N / E);
+    hipLaunchKernelGGL((k_xfft_q2_plt<N, E>), grid, block, shmem, st, S, ec, (const cplx *) tw, (const cplx *) data, plane0, nplanes,
+                       z_first, z_step, (char *) records, red);
+    ZD_LAUNCH_CHECK();
+    return 0;
+}
 template <int N, int E, bool PLT>
 static int launch_xfft_two_t(const StoreLayout &S, const EpiConst &ec, const void *tw, const void *data, int plane0,
                              int nplanes, int z_first, int z_step, void *records, Reduce *red, hipStream_t st) {
@@ -3191,6 +3099,14 @@ static int launch_xfft_two_t(const StoreLayout &S, const EpiConst &ec, const voi
 
 int launch_xfft(const StoreLayout &S, const EpiConst &ec, const void *tw, const void *data, int plane0, int nplanes,
                 int z_first, int z_step, void *records, float *density, Reduce *red, hipStream_t st) {
+    if (S.lq) {  // plane-interleaved rows: the store of the fused PLT Z stage (zd_kernels_fz.hip)
+        if (S.lq == 2 && S.one_block && S.narray == 3 && ec.pack == PACK_PLT3 && !density) {
+            if (S.N == 2048) return launch_xfft_q2_plt_t<2048, 16>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, red, st);
+            if (S.N == 1024) return launch_xfft_q2_plt_t<1024, 16>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, red, st);
+        }
+        fprintf(stderr, "zeldovich_hip: no x pass for plane-interleaved rows at PPD %d\n", S.N);
+        return 2;
+    }
     // PPD = 8192 with the field store's ring: three lines of a row are 1536 threads / 209 KB of LDS -> one row per
     // workgroup, its arrays in sequence
     if (S.N == 8192 && S.narray == 3 && ec.pack == PACK_ZAFIELD)

@@ -663,6 +663,7 @@ int launch_xdens_np2(int N, const void *tw, const void *dring, int ring_pitch, i
     if (N == (p) * (q)) return launch_xdens_q_t<p, 16, q>((const cplx *) tw, dring, ring_pitch, nplanes, density, st);
     NP2_SIZES(DC)
 #undef DC
+    fprintf(stderr, "zeldovich_hip: no density x pass for PPD = %d on the composite kernels (unsupported size, or its line does not fit the LDS)\n", N);
     return 2;
 }
 bool np2_supported_ppd(int N) {

@@ -81,6 +81,10 @@ int launch_fnl_stage(int which, const StoreLayout &S, double f_NL, const void *t
                      hipStream_t st);
 int launch_test_fft(int n, int kind, const void *tw, const void *in, void *out, long long lines, hipStream_t st);
 int test_fft_tile_width(int n);
+// ---- fused generator + z FFT of the packed PLT store (zd_kernels_fz.hip) ----
+bool genz_plt_supported(int N, int L);
+int launch_genz_plt(const GenConst &g, const StoreLayout &S, int ky0, int L, int residue, unsigned nitems, const FzItem *items,
+                    const void *twN, const void *twL, void *out, unsigned *ctr, int ncu, hipStream_t st);
 // ---- PPD = 2^a 3^b (zd_kernels_np2.hip) ----
 bool np2_split(int n, int *P, int *Q);
 int test_fftq_tile_width(int n);
@@ -115,3 +119,4 @@ int launch_copy16(const void *in, void *out, long long n16, hipStream_t st);
 }  // namespace zd
 
 extern "C" int zdk_upload_bit_table(const zdpcg::BitTable *host);
+extern "C" int zdk_upload_bit_table_fz(const zdpcg::BitTable *host);

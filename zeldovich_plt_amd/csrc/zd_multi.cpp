@@ -235,10 +235,15 @@ struct zd_comm {
     int rank = 0, nranks = 1;
     int kind = 0;  // 0 RCCL, 1 local
     ncclComm_t nccl = nullptr;
-    // Guards `nccl` against an abort from another thread (thread-per-GPU driver: whichever rank thread fails aborts EVERY
-    // communicator of the process): held by a rank around each group of RCCL host calls, and by the aborting thread while it
-    // aborts (= frees) this communicator and clears the pointer.  A rank therefore never enters RCCL with a freed handle.
+    // `nccl` against an abort from another thread (thread-per-GPU driver: whichever rank thread fails aborts EVERY communicator of
+    // the process).  The mutex is held only to publish / fetch / clear the handle and to count the rank into a block of RCCL host
+    // calls (`in_rccl`) — NEVER across the calls themselves: ncclGroupEnd may block (lazy p2p connection set-up waits for the
+    // peer), and CommAbort exists to unblock exactly such a call when the peer has failed (round 4 held the mutex across the
+    // block: a rank stuck in its first GroupEnd kept the aborter waiting for the lock).  The aborter takes the handle
+    // away under the lock (no NEW block starts), gives a rank that is inside a block a moment to come out (the common case: the
+    // calls only enqueue), and aborts — which frees the communicator — whether or not it did (comm_abort_handle).
     std::mutex nccl_mu;
+    std::atomic<int> in_rccl{0};
     bool owns_nccl = false;  // zd_comm_create: this object aborts / destroys the communicator; thread-per-GPU driver: the driver does
     LocalGroup *grp = nullptr;
     hipStream_t s_comm = nullptr;
@@ -380,15 +385,114 @@ int zd_comm_create(int rank, int nranks, const void *id128, zd_comm **out) {
     return 0;
 }
 
+namespace {
+bool comm_failed(const zd_comm *c);
+// A block of RCCL host calls of the rank that owns `c`: the handle is fetched and the rank counted in under the lock, the calls
+// run WITHOUT it (zd_comm::nccl_mu); h == nullptr: a peer failed (and may have taken the communicator away)
+struct RcclBlock {
+    zd_comm *c;
+    ncclComm_t h = nullptr;
+    explicit RcclBlock(zd_comm *c_) : c(c_) {
+        std::lock_guard<std::mutex> lk(c->nccl_mu);
+        if (!comm_failed(c) && c->nccl) {
+            h = c->nccl;
+            c->in_rccl.fetch_add(1, std::memory_order_acq_rel);
+        }
+    }
+    ~RcclBlock() {
+        if (h) c->in_rccl.fetch_sub(1, std::memory_order_acq_rel);
+    }
+    RcclBlock(const RcclBlock &) = delete;
+    RcclBlock &operator=(const RcclBlock &) = delete;
+};
+// take the communicator away from its rank and abort it (= free it: never destroyed again).  Not under the lock: a rank blocked
+// inside RCCL is what the abort is for.  A rank that is merely between two enqueueing calls gets up to `grace_ms` to leave its block
+// first.  Returns the handle it aborted (nullptr: there was none)
+ncclComm_t comm_abort_handle(zd_comm *c, int grace_ms = 500) {
+    ncclComm_t h = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(c->nccl_mu);
+        h       = c->nccl;
+        c->nccl = nullptr;
+    }
+    if (!h) return nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (c->in_rccl.load(std::memory_order_acquire) > 0
+           && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(grace_ms))
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    if (rccl() && rccl()->CommAbort) rccl()->CommAbort(h);
+    return h;
+}
+}  // namespace
+
 void zd_comm_abort(zd_comm *c) {
     if (!c) return;
     c->own_failed.store(1);
     if (c->failed) c->failed->store(1, std::memory_order_release);
-    std::lock_guard<std::mutex> lk(c->nccl_mu);
-    if (c->kind == 0 && c->owns_nccl && c->nccl && rccl() && rccl()->CommAbort) {
-        rccl()->CommAbort(c->nccl);  // frees the communicator: not destroyed again
-        c->nccl = nullptr;
-    }
+    if (c->kind == 0 && c->owns_nccl) comm_abort_handle(c);
+}
+
+// Timed probe of the links (VERDICT r4 #3b): `bytes_per_peer` to and from EVERY peer at once — the pattern of the exchange, every
+// link of the rank busy — as grouped send / receive calls on the communication stream, one warm-up and `reps` timed repetitions
+// between two hipEvents.  *GBps_per_peer = bytes_per_peer * reps / time: what ONE link of this rank carries per direction while
+// all of them work (the figure zd_choose_pass_groups_measured prices the all-to-all with).  0 for a communicator without peers or
+// with the local transport.  Every rank of the communicator must call it.
+int zd_comm_probe(zd_comm *c, int64_t bytes_per_peer, int32_t reps, double *GBps_per_peer) {
+    if (GBps_per_peer) *GBps_per_peer = 0.0;
+    if (!c || !GBps_per_peer || bytes_per_peer < 1 || reps < 1) return 1;
+    if (c->nranks < 2 || c->kind != 0) return 0;
+    RcclApi *R = rccl();
+    if (!R) return 1;
+    const int G = c->nranks, me = c->rank;
+    const size_t nb = (size_t) bytes_per_peer;
+    char *sbuf = nullptr, *rbuf = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = 1;
+    do {
+        if (hipMalloc((void **) &sbuf, nb * (size_t) (G - 1)) != hipSuccess || hipMalloc((void **) &rbuf, nb * (size_t) (G - 1)) != hipSuccess) break;
+        if (hipMemsetAsync(sbuf, 0x3c, nb * (size_t) (G - 1), c->s_comm) != hipSuccess) break;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) break;
+        bool ok = true;
+        for (int it = 0; it <= reps && ok; it++) {
+            if (it == 1) ok = hipEventRecord(e0, c->s_comm) == hipSuccess;  // (repetition 0 = warm-up: connection set-up)
+            RcclBlock blk(c);
+            if (!blk.h) {
+                ok = false;
+                break;
+            }
+            ok = ok && R->GroupStart() == ncclSuccess;
+            int slot = 0;
+            for (int p = 0; p < G && ok; p++) {
+                if (p == me) continue;
+                ok = R->Send(sbuf + nb * (size_t) slot, nb, ncclChar, p, blk.h, c->s_comm) == ncclSuccess
+                     && R->Recv(rbuf + nb * (size_t) slot, nb, ncclChar, p, blk.h, c->s_comm) == ncclSuccess;
+                slot++;
+            }
+            ok = (R->GroupEnd() == ncclSuccess) && ok;
+        }
+        ok = ok && hipEventRecord(e1, c->s_comm) == hipSuccess;
+        const auto t0 = std::chrono::steady_clock::now();
+        while (ok) {  // (bounded like the handshake: a link that does not come up must not hang the job)
+            const hipError_t q = hipStreamQuery(c->s_comm);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady || comm_failed(c) || std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) ok = false;
+            else std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        }
+        if (!ok) {
+            fprintf(stderr, "zeldovich_hip: rank %d of %d: the link probe (%lld bytes to every peer) failed or timed out\n", me, G, (long long) bytes_per_peer);
+            zd_comm_abort(c);
+            break;
+        }
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess || ms <= 0.f) break;
+        *GBps_per_peer = (double) nb * reps / (ms * 1e-3) / 1e9;
+        rc = 0;
+    } while (0);
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    hipFree(sbuf);
+    hipFree(rbuf);
+    return rc;
 }
 
 void zd_comm_traffic(zd_comm *c, int64_t *bytes_sent, int64_t *bytes_received, int reset) {
@@ -525,15 +629,15 @@ static int run_pass_body(zd_plan *pl, zd_comm *c, int pass, void *d_store, void 
                                     hipMemcpyDeviceToDevice, c->s_comm));
         } else {
             RcclApi *R = rccl();
-            std::lock_guard<std::mutex> lk(c->nccl_mu);
-            if (comm_failed(c) || !c->nccl) return 1;  // a peer failed (and may have aborted this communicator)
+            RcclBlock blk(c);
+            if (!blk.h) return 1;  // a peer failed (and may have aborted this communicator)
             MNCCL(R->GroupStart());
             for (int p = 0; p < G; p++) {
                 const char *sb = (const char *) d_store + (size_t) p * chunk_b + (size_t) p0 * cpb;
                 char *rb       = dst + (size_t) p * cpb * gp;
                 if (p == me) continue;
-                MNCCL(R->Send(sb, nb, ncclChar, p, c->nccl, c->s_comm));
-                MNCCL(R->Recv(rb, nb, ncclChar, p, c->nccl, c->s_comm));
+                MNCCL(R->Send(sb, nb, ncclChar, p, blk.h, c->s_comm));
+                MNCCL(R->Recv(rb, nb, ncclChar, p, blk.h, c->s_comm));
             }
             MNCCL(R->GroupEnd());
             MHIP(hipMemcpyAsync(dst + (size_t) me * cpb * gp, (const char *) d_store + (size_t) me * chunk_b + (size_t) p0 * cpb, nb,
@@ -607,6 +711,12 @@ static int run_passes_impl(zd_plan *pl, zd_comm *c, int first, int step, void *d
                            int64_t rec_planes, zd_pass_cb cb, void *user, void *hip_stream) {
     hipStream_t st = (hipStream_t) hip_stream;
     if (first < 0 || step < 1) return 1;
+    // the generator's run-ahead (stage_z_impl) needs this rank's NEXT pass while these passes run — and only then: left on the plan,
+    // a later zd_plan_stage_z / zd_plan_run_pass of consecutive residues would generate ahead into residue + step and throw it away
+    struct StepScope {
+        zd_plan *pl;
+        ~StepScope() { pl->pass_step = 1; }
+    } step_scope{pl};
     pl->pass_step = step;
     PassCb pc{cb, user, 0};
     const bool pipelined = c && pl->nranks > 1 && c->kind == 0 && d_store2 != nullptr && first + step < pl->npass;
@@ -703,15 +813,15 @@ static int phi_round(zd_plan *ph, zd_comm *c, void *d_store, void *d_phik, doubl
             }
         } else {
             RcclApi *R = rccl();
-            std::lock_guard<std::mutex> lk(c->nccl_mu);
-            if (comm_failed(c) || !c->nccl) return 1;  // (see run_pass_body)
+            RcclBlock blk(c);
+            if (!blk.h) return 1;  // (see run_pass_body)
             MNCCL(R->GroupStart());
             for (int p = 0; p < G; p++) {
                 char *sb = (char *) d_store + (size_t) p * chunk_b + (size_t) p0 * cpb;  // my rows, planes of rank p
                 char *rb = ring + (size_t) p * cpb * gp;                                 // rank p's rows, my planes
                 if (p == me) continue;
-                MNCCL(R->Send(reverse ? rb : sb, nb, ncclChar, p, c->nccl, c->s_comm));
-                MNCCL(R->Recv(reverse ? sb : rb, nb, ncclChar, p, c->nccl, c->s_comm));
+                MNCCL(R->Send(reverse ? rb : sb, nb, ncclChar, p, blk.h, c->s_comm));
+                MNCCL(R->Recv(reverse ? sb : rb, nb, ncclChar, p, blk.h, c->s_comm));
             }
             MNCCL(R->GroupEnd());
             char *own_s = (char *) d_store + (size_t) me * chunk_b + (size_t) p0 * cpb, *own_r = ring + (size_t) me * cpb * gp;
@@ -927,13 +1037,22 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
         if (aborted || transport != 0) return;
         aborted = true;
         RcclApi *R = rccl();
+        (void) R;
+        // first every handle is taken away (no rank starts a new block of RCCL calls), then the communicators are aborted — none
+        // of it under a rank's lock: a rank may sit in a blocking RCCL call that only the abort ends
         for (int g = 0; g < G; g++) {
-            std::lock_guard<std::mutex> lc(comms[g]->nccl_mu);
-            if (nccls[g] && R && R->CommAbort) {
-                R->CommAbort(nccls[g]);
-                nccls[g] = nullptr;
+            {
+                // a communicator its rank thread has not taken yet (the thread publishes nccls[g] into its zd_comm under this
+                // lock): nobody can be inside RCCL with it — aborted here, and the thread will find nullptr
+                std::lock_guard<std::mutex> lc(comms[g]->nccl_mu);
+                if (!comms[g]->nccl) {
+                    if (nccls[g] && rccl() && rccl()->CommAbort) rccl()->CommAbort(nccls[g]);
+                    nccls[g] = nullptr;
+                    continue;
+                }
             }
-            comms[g]->nccl = nullptr;
+            comm_abort_handle(comms[g]);
+            nccls[g] = nullptr;
         }
     };
     const auto t0 = std::chrono::steady_clock::now();

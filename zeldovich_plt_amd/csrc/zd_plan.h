@@ -65,6 +65,11 @@ struct zd_plan {
     hipEvent_t ev_fork = nullptr;
     hipEvent_t ev_pipe[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // one rank, two stores (zd_plan_run_passes): start, Z done x2, XY done x2
     bool overlap = true;
+    // fused Z stage of the packed PLT store (zd_kernels_fz.hip): work items (row, first column, columns), longest first
+    bool fused_z = false;
+    zd::FzItem *d_fzitems = nullptr;
+    unsigned n_fzitems = 0;
+    int ncu = 256;
     // ZD_Version = 1 (zd_kernels_v1.hip): mt19937 streams, one per yres; accepted pairs of the slab being generated
     int v1_block = 0;               // PPD / NumBlock streams (0: version 2)
     zd::V1Stream *d_v1streams = nullptr;
