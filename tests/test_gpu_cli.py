@@ -127,3 +127,45 @@ def test_cli_plt_on_a_composite_grid(tmp_path, oracle):
         assert np.array_equal(got["ijk"], want["ijk"])
         assert np.abs(got["d"] - want["d"]).max() <= 1e-6 * np.abs(want["d"]).max()
         assert np.abs(got["v"] - want["v"]).max() <= 1e-6 * np.abs(want["v"]).max()
+
+
+# BASELINE config 1 literally: the keys and values of the reference's example.par (CPD 375, NP = 128^3, ZD_NumBlock 4, RVZel,
+# relative file names resolved in the working directory), with ZD_qPLT = 0 — the CPU-runnable case of BASELINE.json — and as
+# shipped, ZD_qPLT = 1 with ./eigmodes128 (absent from the reference mount: a synthetic table in its layout, 128^3 cells = the
+# exact lookup of src/zeldovich.cpp:161-170)
+EXAMPLE_PAR = [("BoxSize", "720"), ("CPD", "375"), ("ICFormat", '"RVZel"'), ("InitialConditionsDirectory", '"./ic_out"'),
+               ("InitialRedshift", "49"), ("NP", "2097152"), ("ZD_NumBlock", "4"), ("ZD_PLT_filename", '"./eigmodes128"'),
+               ("ZD_PLT_target_z", "5"), ("ZD_Pk_filename", '"wmap1new.pow"'), ("ZD_Pk_norm", "8.0"), ("ZD_Pk_scale", "1.0"),
+               ("ZD_Pk_sigma", "0.0210839935761"), ("ZD_Pk_smooth", "0.0"), ("ZD_Seed", "12346"), ("ZD_k_cutoff", "1.0"),
+               ("ZD_qPLT", "1"), ("ZD_qPLT_rescale", "0"), ("ZD_qPk_fix_to_mean", "0"), ("ZD_Version", "2"), ("ZD_f_NL", "0")]
+
+
+@pytest.mark.parametrize("qplt", [0, 1])
+def test_cli_example_par_literally(tmp_path, oracle, qplt):
+    import shutil
+    n, cpd = 128, 375
+    shutil.copy(WMAP, tmp_path / "wmap1new.pow")
+    eig = oracle.synthetic_eigenmodes(128)
+    with open(tmp_path / "eigmodes128", "wb") as f:
+        f.write(np.int32(128).tobytes())
+        f.write(np.ascontiguousarray(eig, dtype=np.float64).tobytes())
+    (tmp_path / "example.par").write_text("# An example zeldovich parameter file.\n\n" + "".join(
+        "%s = %s\n" % (k, str(qplt) if k == "ZD_qPLT" else v) for k, v in EXAMPLE_PAR))
+    r = subprocess.run([EXE, "example.par"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr
+    pk = oracle.pk_from_file(WMAP, 720.0)
+    kw = dict(qPLT=1, qPLTrescale=0, PLT_target_z=5.0) if qplt else {}
+    ref = oracle.run(oracle.make_params(n, numblock=4, icformat="RVZel", cpd=cpd, **kw), pk, eig=eig if qplt else None,
+                     eig_ppd=128 if qplt else 0)
+    dt = oracle.RECORD_DTYPES["RVZel"]
+    out = tmp_path / "ic_out"
+    files = sorted(int(f.name[3:]) for f in out.iterdir() if f.name.startswith("ic_"))
+    assert files == sorted(set(z * cpd // n for z in range(n))) and len(files) == 128  # CPD > PPD: one plane per file
+    scale_d, scale_v = np.abs(ref["records"]["d"]).max(), np.abs(ref["records"]["v"]).max()
+    for f in files:
+        zs = [z for z in range(n) if z * cpd // n == f]
+        got = np.fromfile(out / ("ic_%d" % f), dtype=dt).reshape(len(zs), n, n)
+        want = ref["records"][zs]
+        assert np.array_equal(got["ijk"], want["ijk"])
+        assert np.abs(got["d"] - want["d"]).max() <= 1e-6 * scale_d and np.abs(got["v"] - want["v"]).max() <= 1e-6 * scale_v
+    assert "maximum component-wise displacements" in r.stderr

@@ -29,6 +29,11 @@ def _planes(zd, ps, eig, n, zs, **kw):
     import torch
     dt = zd.RECORD_DTYPES[FMT]
     p = zd.make_params(n, icformat=FMT, qPLT=1, **kw)
+    if p.stream_factor <= 0:
+        free_b, _ = torch.cuda.mem_get_info()
+        held = 0 if _STORE["t"] is None else _STORE["t"].numel()
+        p.stream_factor = zd.load_library().zd_choose_stream_factor(C.byref(p), 1, int(free_b) + held - (24 << 30))
+        assert p.stream_factor > 0
     plan = zd.Plan(p, ps, eig=eig)
     if _STORE["t"] is None or _STORE["t"].numel() < plan.exchange_bytes:
         _STORE["t"] = None

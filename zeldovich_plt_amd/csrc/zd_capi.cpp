@@ -1071,6 +1071,9 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
                       && g.genf_tab && !v1 && !p->qonemode && p->qoneslab < 0 && phi_mode == 0 && phik == nullptr && p->k_cutoff >= 1.0
                       && (g.kmax == pl->half || !p->corner_modes) && (S.prune & 7) == 7 && !tune_env("ZD_NO_FUSED_Z");
         S.lq         = pl->fused_z ? 2 : 0;
+        // (the pad that spreads the y stage's strided rows over the HBM channels: 24 elements per plain row; per plane row of an
+        // interleaved row 12 measured best — y stage of PPD=2048 PLT 144.5 ms at 24, 143.2 at 6, 139.7 at 12, 156.7 at 48)
+        if (S.lq && !tune_env("ZD_PAD")) row_pad = store_row_pad(pl->N) / 2;
         S.pitch      = (pl->N + row_pad) << S.lq;
         S.a_rows     = (1 << lBk) << lBz;
         S.zb_rows    = S.a_rows * pl->narray;

@@ -1548,11 +1548,16 @@ __global__ __launch_bounds__(W *N / E, MINW) void k_yfft(StoreLayout S, const cp
         // compiler does not keep 16 offset registers alive (and spill them) across the whole FFT
         int t2 = t;
         asm volatile("" : "+v"(t2));
+        // plane-interleaved rows (lq = 2, W = 8: the tile is one 128-byte line per row, 2 columns x 4 planes): the line goes back
+        // with the two columns of a plane side by side — [plane][column] instead of [column][plane] — so that the x stage, which
+        // transforms the lines of a plane PAIR, reads 64 contiguous bytes per column pair (whole sectors) instead of 32 of every 64
+        unsigned xs = xb;
+        if (S.lq == 2 && W == 8) xs = (unsigned) ((xq & ~7) + ((w & 3) << 1) + (w >> 2)) * 16u;
 #pragma unroll
         for (int e = 0; e < E; e++) {
             const int y = t2 + T * e;
             const unsigned slot = y < N / 2 ? y : (y == N / 2 ? N / 2 : N / 2 + (N - y));
-            st_stream(reinterpret_cast<cplx *>(base + (slot * pb + xb)), cplx{re[e], im[e]}, ZD_TUNE(S.nt & 2));
+            st_stream(reinterpret_cast<cplx *>(base + (slot * pb + xs)), cplx{re[e], im[e]}, ZD_TUNE(S.nt & 2));
         }
     } else {
         cplx *base = data + x;
@@ -2233,15 +2238,16 @@ __global__ __launch_bounds__(N / E, 2) void k_xfft_seq_plt(StoreLayout S, EpiCon
 template <int N, int E>
 __global__ __launch_bounds__(2 * N / E, 2) void k_xfft_q2_plt(StoreLayout S, EpiConst ec, const cplx *__restrict__ tw,
                                                             const cplx *__restrict__ data, int plane0, int nplanes, int z_first,
-                                                            int z_step, char *__restrict__ records, Reduce *__restrict__ red) {
+                                                            int z_step, char *__restrict__ records, Reduce *__restrict__ red, int hdist) {
     using PL  = zdfft::Plan<N, E>;
     using LDS = zdfft::ColsInner<N, 2>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int T = PL::T, NT = 2 * T;
     const int w = threadIdx.x & 1, t = threadIdx.x >> 1;
     static_assert(N % 8 == 0, "rows are dealt to the 8 XCDs");
-    const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3, h = pos & 1;
-    const int y = ((pos >> 1) << 3) + xcd;
+    const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
+    const int grp = pos / (2 * hdist), m = pos % (2 * hdist), h = m / hdist;  // hdist rows with h = 0, then the same rows with h = 1
+    const int y = ((grp * hdist + m % hdist) << 3) + xcd;
     const int pl = 4 * ((plane0 >> 2) + (int) blockIdx.y) + 2 * h + w;  // this thread's plane of the store
     if (pl - w + 1 < plane0 || pl - w >= plane0 + nplanes) return;      // (uniform) neither plane of the pair is asked for
     const bool active = pl >= plane0 && pl < plane0 + nplanes;
@@ -2257,13 +2263,16 @@ __global__ __launch_bounds__(2 * N / E, 2) void k_xfft_q2_plt(StoreLayout S, Epi
 #pragma unroll 1
     for (int it = 0; it < 3; it++) {
         const int a = it == 0 ? 0 : (it == 1 ? 2 : 1);
-        const cplx *src = data + row_offset(S, pl >> 2, a, y) + sub;
+        // after the y stage a row holds, per pair of columns, [plane 0..3][column 0..1] (k_yfft): element (x, plane) at
+        // 8 (x / 2) + 2 (plane % 4) + x % 2
+        const cplx *src = data + row_offset(S, pl >> 2, a, y) + 2 * sub;
         double re[E], im[E];
         int ta = t;
         asm volatile("" : "+v"(ta));
 #pragma unroll
         for (int e = 0; e < E; e++) {
-            const cplx v = src[(x_is_dead(ec, ta + T * e) ? 0 : ta + T * e) << 2];  // (see k_xfft)
+            const int xl = x_is_dead(ec, ta + T * e) ? 0 : ta + T * e;  // (see k_xfft)
+            const cplx v = src[((xl >> 1) << 3) + (xl & 1)];
             re[e] = v.x;
             im[e] = v.y;
         }
@@ -3078,8 +3087,13 @@ static int launch_xfft_q2_plt_t(const StoreLayout &S, const EpiConst &ec, const 
     set_dyn_lds<k_xfft_q2_plt<N, E>>(shmem);
     const int quads = ((plane0 + nplanes - 1) >> 2) - (plane0 >> 2) + 1;
     dim3 grid(2 * N, quads), block(2 * N / E);
+    // distance, in positions of an XCD's dispatch stream, between the two workgroups that read the same lines (see the kernel)
+    int hdist = 1;
+#ifdef ZD_TUNING
+    if (const char *env = getenv("ZD_XQ_DIST")) hdist = std::max(1, std::min(N / 8, atoi(env)));
+#endif
     hipLaunchKernelGGL((k_xfft_q2_plt<N, E>), grid, block, shmem, st, S, ec, (const cplx *) tw, (const cplx *) data, plane0, nplanes,
-                       z_first, z_step, (char *) records, red);
+                       z_first, z_step, (char *) records, red, hdist);
     ZD_LAUNCH_CHECK();
     return 0;
 }

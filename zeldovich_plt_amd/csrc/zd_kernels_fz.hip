@@ -119,6 +119,14 @@ __global__ __launch_bounds__(L / 2) void k_genz_plt(GenConst g, StoreLayout S, i
     for (int i = threadIdx.x; i < g.genf_n / 2; i += NT) reinterpret_cast<double2 *>(T)[i] = reinterpret_cast<const double2 *>(g.genf_tab)[i];
     unsigned *slot = reinterpret_cast<unsigned *>(T + g.genf_n);
     cplx *stage    = reinterpret_cast<cplx *>(T + ((g.genf_n + 3) & ~1));
+    // twiddles in LDS: the steady-state loop then has NO vector-memory loads — on gfx9 loads and stores share one in-order counter
+    // (vmcnt), so a load issued behind the column's 16 line stores waits for every one of them, and the stores, which should
+    // drain behind the next column's arithmetic, were 48 of the stage's 162 ms (profiles/r05_tuning_notes.md).
+    //   twl[m] = exp(2 pi i m / L), m < L/4: all the inter-pass twiddles a 16 x 16 x 4 transform of L = 1024 points asks for
+    //   twn[t] = exp(2 pi i t / N), t < L/2: the final factor W_N^{k2 residue} of line element k2 = t (element L - t: -conj)
+    cplx *twl = stage + NJOB * L, *twn = twl + L / 4;
+    for (int i = threadIdx.x; i < L / 4; i += NT) twl[i] = twL[i];
+    for (int i = threadIdx.x; i < L / 2; i += NT) twn[i] = twN[i];
     const int N = g.N, half = g.half;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
 
@@ -129,18 +137,10 @@ __global__ __launch_bounds__(L / 2) void k_genz_plt(GenConst g, StoreLayout S, i
     a[0] = t;
     if constexpr (R == 2) a[1] = t == 0 ? L / 2 : L - t;
     const int kA = t, kB = t == 0 ? L / 2 : L - t;
-    EigAxis az[R];
-#pragma unroll
-    for (int p = 0; p < R; p++) az[p] = eig_axis(g, a[p]);  // the table's +kz half space
     // final factor W_N^{k2 residue} of the two line elements; fold factor W_R^{(R-1) residue} of the "-" modes
-    double wAr = 1.0, wAi = 0.0, wBr = 1.0, wBi = 0.0;
-    if (R > 1) {
-        const cplx wa = twN[(kA * residue) & (N - 1)], wb = twN[(kB * residue) & (N - 1)];
-        wAr = wa.x, wAi = wa.y, wBr = wb.x, wBi = wb.y;
-    }
+    static_assert(R == 1 || R == 2, "the line twiddles below: residue 0 -> 1; residue 1 at N = 2 L -> twn[t], -conj twn[t]");
     const double fold_m = (R == 2 && (residue & 1)) ? -1.0 : 1.0;
     // thread 0: pair 0 is the single mode kz = 0; at R = 2 its pair 1 (kz = +-L/2) puts BOTH modes on element kB
-    const double to_a = t != 0 ? 1.0 : 0.0, to_b = 1.0 - to_a;
     const bool has_m0 = t != 0;
 
     double vsum = 0.0;
@@ -176,29 +176,43 @@ __global__ __launch_bounds__(L / 2) void k_genz_plt(GenConst g, StoreLayout S, i
 #pragma unroll
                 for (int p = 0; p < R; p++) {
                     // (both x corners whatever this column's fraction is: the next columns of the cell need the upper one)
-                    eig_yz_blend(g, ax.l, ay, az[p], Cl[p]);
-                    eig_yz_blend(g, ax.h, ay, az[p], Ch[p]);
+                    const EigAxis az = eig_axis(g, a[p]);  // the table's +kz half space
+                    eig_yz_blend(g, ax.l, ay, az, Cl[p]);
+                    eig_yz_blend(g, ax.h, ay, az, Ch[p]);
                 }
             }
             const int kxy2 = kx * kx + ky * ky;
             const bool dead_xy = dead_y || (kx < 0 ? -kx : kx) == g.kmax;  // zeldovich.cpp:350
-            // sums X, Y, Z, fX, fY, fZ of the two line elements
-            double Ar[NJOB], Ai[NJOB], Br[NJOB], Bi[NJOB];
-#pragma unroll
-            for (int j = 0; j < NJOB; j++) Ar[j] = Ai[j] = Br[j] = Bi[j] = 0.0;
+            // W_N^{k2 residue} of the two line elements: twn[t] for kA = t; kB = L - t: exp(2 pi i (L - t) / N) = -conj twn[t] (N = 2 L);
+            // thread 0: kB = L/2 -> i.  residue 0 (and R = 1): 1
+            double wAr = 1.0, wAi = 0.0, wBr = 1.0, wBi = 0.0;
+            if (R == 2 && (residue & 1)) {
+                int tl = t;
+                asm volatile("" : "+v"(tl));  // (address formed here: see kzl below)
+                const cplx wa = twn[tl];
+                wAr = wa.x, wAi = wa.y;
+                wBr = t == 0 ? 0.0 : -wa.x, wBi = t == 0 ? 1.0 : wa.y;
+            }
+            // The six job inputs of ONE mode (zd_kernels.hip genf_tile, GENF_PLTN: i X - fX, i X + fX, -Z + i Y, Z + i Y, -fZ + i fY,
+            // fZ + i fY with X = s_x D ...) times the line twiddle w: linear in the mode, so every mode goes straight into its line
+            // element in LDS — pair 0 writes the thread's two elements, pair 1 adds to them — and no sums are held in registers
+            // beside the Box-Muller chains (24 doubles: with them the kernel spilled, and spilled values come back through
+            // scratch LOADS, which wait behind the line stores in the vmcnt queue)
+            auto mode_jobs = [&](double dr, double di, double wr, double wi, double sx_, double sy_, double sz_, double f_,
+                                 double (&vr)[NJOB], double (&vi)[NJOB]) {
+                const double er = dr * wr - di * wi, ei = dr * wi + di * wr;
+                const double p1 = sx_ * er, p2 = sx_ * ei, q1 = f_ * p1, q2 = f_ * p2;
+                vr[0] = -q1 - p2, vi[0] = p1 - q2;  // JOB_XV_SELF (i - f) s_x D
+                vr[1] = q1 - p2, vi[1] = p1 + q2;   // JOB_XV_TWIN (i + f) s_x D
+                const double r1 = sz_ * er, r2 = sz_ * ei, t1 = sy_ * er, t2 = sy_ * ei;
+                vr[2] = -r1 - t2, vi[2] = t1 - r2;  // JOB_B_SELF  (-s_z + i s_y) D
+                vr[3] = r1 - t2, vi[3] = t1 + r2;   // JOB_B_TWIN  ( s_z + i s_y) D
+                const double u1 = f_ * r1, u2 = f_ * r2, v1 = f_ * t1, v2 = f_ * t2;
+                vr[4] = -u1 - v2, vi[4] = v1 - u2;  // JOB_D_SELF  f (-s_z + i s_y) D
+                vr[5] = u1 - v2, vi[5] = v1 + u2;   // JOB_D_TWIN  f ( s_z + i s_y) D
+            };
 #pragma unroll
             for (int p = 0; p < R; p++) {
-                if (p == 1) {
-                    // the sums of pair 0 wait in the thread's own two elements of the staged lines while pair 1 is worked on (24 doubles
-                    // less to hold beside two Box-Muller chains: without this the kernel spilled 54 registers at 256)
-                    __syncthreads();  // the previous column's line waves are done with their exchange areas
-#pragma unroll
-                    for (int j = 0; j < NJOB; j++) {
-                        stage[j * L + kA] = cplx{Ar[j], Ai[j]};
-                        stage[j * L + kB] = cplx{Br[j], Bi[j]};
-                        Ar[j] = Ai[j] = Br[j] = Bi[j] = 0.0;
-                    }
-                }
                 const int kz = a[p], k2i = kxy2 + kz * kz;
                 const bool live = !dead_xy && kz != g.kmax && (g.corner_modes || k2i < g.k2i_cut);
                 // the four draws; the generators move on to the next column
@@ -210,129 +224,91 @@ __global__ __launch_bounds__(L / 2) void k_genz_plt(GenConst g, StoreLayout S, i
                 s2 = zdpcg::step(sm[p]);
                 const uint64_t m2 = zdpcg::output(s2);
                 sm[p] = zdpcg::step(s2);
-                if (!__any(live) || ZD_TUNE(S.prune & 8)) continue;  // all 64 pairs of the wave zeroed (bit 3: tuning ablation — draws only)
-                // ---- shared by the pair: P(k), 1/k^2, eigenmode, f, rescale ----
-                const double k2v = (double) k2i * g.fundamental2;
-                const double P   = genf_power<PLAW>(g, T, k2v);
-                const double ik2 = frcp(k2v);
-                double eh[4];
-                {
-                    const double wl = 1 - ax.f, wh = ax.f;
+                double vPr[NJOB], vPi[NJOB], vMr[NJOB], vMi[NJOB];
+                const bool any = __any(live) && !ZD_TUNE(S.prune & 8);  // all 64 pairs of the wave zeroed? (bit 3: tuning ablation — draws only)
+                if (any) {
+                    // ---- shared by the pair: P(k), eigenmode, f, rescale ----
+                    const double k2v = (double) k2i * g.fundamental2;
+                    const double P   = genf_power<PLAW>(g, T, k2v);
+                    double eh[4];
+                    {
+                        const double wl = 1 - ax.f, wh = ax.f;
 #pragma unroll
-                    for (int q = 0; q < 4; q++) eh[q] = wl * Cl[p][q];
-                    if (wh != 0) {
+                        for (int q = 0; q < 4; q++) eh[q] = wl * Cl[p][q];
+                        if (wh != 0) {
 #pragma unroll
-                        for (int q = 0; q < 4; q++) eh[q] = fma(wh, Ch[p][q], eh[q]);
+                            for (int q = 0; q < 4; q++) eh[q] = fma(wh, Ch[p][q], eh[q]);
+                        }
+                    }
+                    // get_eigenmode (zeldovich.cpp:229-276) for kz = +a; the mode -a has e_z negated, everything else the same.  The
+                    // reference normalises e, forms e k^2 / (k.e) and the generator multiplies by fundamental / k^2: the coefficient
+                    // s_j = e_j / ((k.e) fundamental) does not depend on |e| or on k^2, so neither is computed (one reciprocal instead of
+                    // an inverse square root with two Newton steps and two reciprocals); k.e = 0 or not finite -> 0 as there (:262-263)
+                    int kzl = kz;
+                    asm volatile("" : "+v"(kzl));  // (double) kz is converted here, per column: hoisted out of the loop it was spilled,
+                                                   // and its reload is a vector-memory load in the hot loop (see twl above)
+                    const double dot = kx * eh[0] + ky * eh[1] + kzl * eh[2];
+                    double inv = frcp(dot * g.fundamental);
+                    if (!isfinite(inv)) inv = 0.0;
+                    const double f = (sqrt_pos(1. + 24 * eh[3] * g.f_cluster) - 1) * .25;
+                    if (g.qPLTrescale) inv *= fexp(g.ln_growth_ratio * (g.target_f - f), T);
+                    const double sx = inv * eh[0], sy = inv * eh[1], sz = inv * eh[2];
+                    // ---- cgauss<2> of the two modes (power_spectrum.cpp:338-359); zeroed lanes ride along with amplitude 0 ----
+                    double dpr, dpi, dmr, dmi;
+                    {
+                        const uint64_t u = p1 + 1ULL;  // one_rand<2>: (r + 1) 2^-64, and 1.0 for r = 2^64 - 1 (u = 0)
+                        double v = P;
+                        if (!g.fixed_power) v = -P * flog(u64_to_double(u), 64, T);
+                        v = (u == 0 && !g.fixed_power) || !live ? 0.0 : v;
+                        const double amp = sqrt_pos(v);
+                        double sn, cs;
+                        sincos_u01(u64_to_double(p2 + 1ULL), T, sn, cs);
+                        dpr = amp * cs, dpi = amp * sn;
+                    }
+                    {
+                        const uint64_t u = m1 + 1ULL;
+                        double v = P;
+                        if (!g.fixed_power) v = -P * flog(u64_to_double(u), 64, T);
+                        v = (u == 0 && !g.fixed_power) || !live || (p == 0 && !has_m0) ? 0.0 : v;
+                        const double amp = sqrt_pos(v);
+                        double sn, cs;
+                        sincos_u01(u64_to_double(m2 + 1ULL), T, sn, cs);
+                        dmr = amp * cs, dmi = amp * sn;
+                    }
+                    vsum = fma(dpr, dpr, fma(dpi, dpi, vsum));
+                    vsum = fma(dmr, dmr, fma(dmi, dmi, vsum));
+                    dmr *= fold_m;
+                    dmi *= fold_m;
+                    // pair 0: "+" -> element kA, "-" -> kB.   pair 1 (R = 2): "+" -> kB, "-" -> kA (thread 0: kB as well)
+                    const bool m_to_a = p == 1 && has_m0;
+                    mode_jobs(dpr, dpi, p == 0 ? wAr : wBr, p == 0 ? wAi : wBi, sx, sy, sz, f, vPr, vPi);
+                    mode_jobs(dmr, dmi, m_to_a ? wAr : wBr, m_to_a ? wAi : wBi, sx, sy, -sz, f, vMr, vMi);
+                } else if (p == 0) {
+#pragma unroll
+                    for (int j = 0; j < NJOB; j++) vPr[j] = vPi[j] = vMr[j] = vMi[j] = 0.0;
+                }
+                if (p == 0) {
+                    __syncthreads();  // the previous column's line waves are done with their exchange areas
+#pragma unroll
+                    for (int j = 0; j < NJOB; j++) {
+                        stage[j * L + kA] = cplx{vPr[j], vPi[j]};
+                        stage[j * L + kB] = cplx{vMr[j], vMi[j]};
+                    }
+                } else if (any) {
+                    const int km = has_m0 ? kA : kB;
+#pragma unroll
+                    for (int j = 0; j < NJOB; j++) {
+                        cplx q = stage[j * L + kB];
+                        q.x += vPr[j], q.y += vPi[j];
+                        stage[j * L + kB] = q;
+                    }
+#pragma unroll
+                    for (int j = 0; j < NJOB; j++) {  // (behind the loop above: thread 0 adds both modes to the same element)
+                        cplx q = stage[j * L + km];
+                        q.x += vMr[j], q.y += vMi[j];
+                        stage[j * L + km] = q;
                     }
                 }
-                // get_eigenmode (zeldovich.cpp:229-276) for kz = +a; the mode -a has e_z negated, everything else the same
-                const double n2 = eh[0] * eh[0] + eh[1] * eh[1] + eh[2] * eh[2];
-                double rr = trans_rsq(n2);
-                rr = rr * fma(-0.5 * n2, rr * rr, 1.5);
-                rr = rr * fma(-0.5 * n2, rr * rr, 1.5);
-                eh[0] *= rr;
-                eh[1] *= rr;
-                eh[2] *= rr;
-                const double dot = kx * eh[0] + ky * eh[1] + kz * eh[2];
-                double norm = (double) k2i * frcp(dot);
-                if (!isfinite(norm)) norm = 0.0;
-                const double f = (sqrt_pos(1. + 24 * eh[3] * g.f_cluster) - 1) * .25;
-                double rescale = 1.0;
-                if (g.qPLTrescale) rescale = fexp(g.ln_growth_ratio * (g.target_f - f), T);
-                const double sx = rescale * (norm * eh[0]) * g.fundamental * ik2;
-                const double sy = rescale * (norm * eh[1]) * g.fundamental * ik2;
-                const double sz = rescale * (norm * eh[2]) * g.fundamental * ik2;
-                // ---- cgauss<2> of the two modes (power_spectrum.cpp:338-359); zeroed lanes ride along with amplitude 0 ----
-                double dpr, dpi, dmr, dmi;
-                {
-                    const uint64_t u = p1 + 1ULL;  // one_rand<2>: (r + 1) 2^-64, and 1.0 for r = 2^64 - 1 (u = 0)
-                    double v = P;
-                    if (!g.fixed_power) v = -P * flog(u64_to_double(u), 64, T);
-                    v = (u == 0 && !g.fixed_power) || !live ? 0.0 : v;
-                    const double amp = sqrt_pos(v);
-                    double sn, cs;
-                    sincos_u01(u64_to_double(p2 + 1ULL), T, sn, cs);
-                    dpr = amp * cs, dpi = amp * sn;
-                }
-                {
-                    const uint64_t u = m1 + 1ULL;
-                    double v = P;
-                    if (!g.fixed_power) v = -P * flog(u64_to_double(u), 64, T);
-                    v = (u == 0 && !g.fixed_power) || !live || (p == 0 && !has_m0) ? 0.0 : v;
-                    const double amp = sqrt_pos(v);
-                    double sn, cs;
-                    sincos_u01(u64_to_double(m2 + 1ULL), T, sn, cs);
-                    dmr = amp * cs, dmi = amp * sn;
-                }
-                vsum = fma(dpr, dpr, fma(dpi, dpi, vsum));
-                vsum = fma(dmr, dmr, fma(dmi, dmi, vsum));
-                dmr *= fold_m;
-                dmi *= fold_m;
-                const double fx = f * sx, fy = f * sy, fz = f * sz;
-                if (p == 0) {  // "+" -> element kA, "-" -> element kB
-                    cmac(Ar[0], Ai[0], sx, dpr, dpi);
-                    cmac(Ar[1], Ai[1], sy, dpr, dpi);
-                    cmac(Ar[2], Ai[2], sz, dpr, dpi);
-                    cmac(Ar[3], Ai[3], fx, dpr, dpi);
-                    cmac(Ar[4], Ai[4], fy, dpr, dpi);
-                    cmac(Ar[5], Ai[5], fz, dpr, dpi);
-                    cmac(Br[0], Bi[0], sx, dmr, dmi);
-                    cmac(Br[1], Bi[1], sy, dmr, dmi);
-                    cmac(Br[2], Bi[2], -sz, dmr, dmi);
-                    cmac(Br[3], Bi[3], fx, dmr, dmi);
-                    cmac(Br[4], Bi[4], fy, dmr, dmi);
-                    cmac(Br[5], Bi[5], -fz, dmr, dmi);
-                } else {  // pair 1 (R = 2): "+" -> kB; "-" -> kA (thread 0: kB as well)
-                    cmac(Br[0], Bi[0], sx, dpr, dpi);
-                    cmac(Br[1], Bi[1], sy, dpr, dpi);
-                    cmac(Br[2], Bi[2], sz, dpr, dpi);
-                    cmac(Br[3], Bi[3], fx, dpr, dpi);
-                    cmac(Br[4], Bi[4], fy, dpr, dpi);
-                    cmac(Br[5], Bi[5], fz, dpr, dpi);
-                    const double ar = dmr * to_a, ai = dmi * to_a, br = dmr * to_b, bi = dmi * to_b;
-                    cmac(Ar[0], Ai[0], sx, ar, ai);
-                    cmac(Ar[1], Ai[1], sy, ar, ai);
-                    cmac(Ar[2], Ai[2], -sz, ar, ai);
-                    cmac(Ar[3], Ai[3], fx, ar, ai);
-                    cmac(Ar[4], Ai[4], fy, ar, ai);
-                    cmac(Ar[5], Ai[5], -fz, ar, ai);
-                    cmac(Br[0], Bi[0], sx, br, bi);
-                    cmac(Br[1], Bi[1], sy, br, bi);
-                    cmac(Br[2], Bi[2], -sz, br, bi);
-                    cmac(Br[3], Bi[3], fx, br, bi);
-                    cmac(Br[4], Bi[4], fy, br, bi);
-                    cmac(Br[5], Bi[5], -fz, br, bi);
-                }
-            }
-            // ---- job inputs (zd_kernels.hip genf_tile, GENF_PLTN) times W_N^{k2 residue} -> staged lines ----
-            if constexpr (R == 2) {
-#pragma unroll
-                for (int j = 0; j < NJOB; j++) {
-                    const cplx pa = stage[j * L + kA], pb = stage[j * L + kB];
-                    Ar[j] += pa.x;
-                    Ai[j] += pa.y;
-                    Br[j] += pb.x;
-                    Bi[j] += pb.y;
-                }
-            } else {
-                __syncthreads();  // the previous column's line waves are done with their exchange areas
-            }
-            {
-                auto put = [&](int j, int k2, double vr, double vi, double wr, double wi) {
-                    stage[j * L + k2] = cplx{vr * wr - vi * wi, vr * wi + vi * wr};
-                };
-                put(0, kA, -Ai[0] - Ar[3], Ar[0] - Ai[3], wAr, wAi);   // JOB_XV_SELF (i - f) s_x D = i X - fX
-                put(1, kA, -Ai[0] + Ar[3], Ar[0] + Ai[3], wAr, wAi);   // JOB_XV_TWIN (i + f) s_x D = i X + fX
-                put(2, kA, -Ar[2] - Ai[1], -Ai[2] + Ar[1], wAr, wAi);  // JOB_B_SELF  -Z + i Y
-                put(3, kA, Ar[2] - Ai[1], Ai[2] + Ar[1], wAr, wAi);    // JOB_B_TWIN   Z + i Y
-                put(4, kA, -Ar[5] - Ai[4], -Ai[5] + Ar[4], wAr, wAi);  // JOB_D_SELF  -fZ + i fY
-                put(5, kA, Ar[5] - Ai[4], Ai[5] + Ar[4], wAr, wAi);    // JOB_D_TWIN   fZ + i fY
-                put(0, kB, -Bi[0] - Br[3], Br[0] - Bi[3], wBr, wBi);
-                put(1, kB, -Bi[0] + Br[3], Br[0] + Bi[3], wBr, wBi);
-                put(2, kB, -Br[2] - Bi[1], -Bi[2] + Br[1], wBr, wBi);
-                put(3, kB, Br[2] - Bi[1], Bi[2] + Br[1], wBr, wBi);
-                put(4, kB, -Br[5] - Bi[4], -Bi[5] + Br[4], wBr, wBi);
-                put(5, kB, Br[5] - Bi[4], Bi[5] + Br[4], wBr, wBi);
             }
             __syncthreads();
             // ---- waves 0..5: one job line each — transform, Hermitian store ----
@@ -346,7 +322,9 @@ __global__ __launch_bounds__(L / 2) void k_genz_plt(GenConst g, StoreLayout S, i
                     im[e] = v.y;
                 }
                 wave_lds_sync();  // the line is in registers: its area now serves this wave's exchanges
-                if (!ZD_TUNE(S.prune & 128)) fft_line_wave<PL, XL>(re, im, lane, reinterpret_cast<double *>(stage + wave * L), twL);  // bit 7: ablation
+                int l3 = lane;
+                asm volatile("" : "+v"(l3));  // (the transform's LDS addresses are formed per column, not carried — and spilled — across the loop)
+                if (!ZD_TUNE(S.prune & 128)) fft_line_wave<PL, XL>(re, im, l3, reinterpret_cast<double *>(stage + wave * L), twl);  // bit 7: ablation
                 if (ZD_TUNE(S.prune & 16) && re[0] != 123.456) continue;  // bit 4: tuning ablation (no stores)
                 const int arr = wave >> 1, twin = wave & 1;
                 const int sl = twin ? S.Hq + kyl : kyl;
@@ -373,7 +351,9 @@ namespace zd {
 
 bool genz_plt_supported(int N, int L) { return L == 1024 && (N == L || N == 2 * L); }
 
-size_t genz_plt_lds_bytes(const GenConst &g, int L) { return sizeof(double) * (size_t) ((g.genf_n + 3) & ~1) + sizeof(cplx) * 6 * (size_t) L; }
+size_t genz_plt_lds_bytes(const GenConst &g, int L) {  // table image + slot | 6 staged lines | twl[L/4] | twn[L/2]
+    return sizeof(double) * (size_t) ((g.genf_n + 3) & ~1) + sizeof(cplx) * (6 * (size_t) L + L / 4 + L / 2);
+}
 
 template <int L, int R, bool PLAW>
 static int launch_genz_t(const GenConst &g, const StoreLayout &S, int ky0, int residue, unsigned nitems, const FzItem *items,
