@@ -423,7 +423,8 @@ def main():
         store_b = float(plan.exchange_bytes) * plan.passes
         fields = plan.store_mode == "fields"
         inter_b = 1.5 * particles * 16 if fields else store_b
-        design = {"z_stage": 3.0 * store_b,                       # folded inputs written + read, store written
+        fused_z = kl["k_zfft"] == 0 and kl["k_gen"] > 0  # PLT on one rank at z lines of 1024: generator + z FFT are one kernel
+        design = {"z_stage": (1.0 if fused_z else 3.0) * store_b,  # (folded inputs written + read,) store written
                   "k_yfft": (store_b + inter_b) if fields else 2.0 * store_b,
                   "k_xfft": inter_b + recsize * particles}
         # PMC bytes per launch come from a rocprofv3 --pmc run of THIS command (scripts/gpu_profile.sh), committed as
@@ -463,6 +464,9 @@ def main():
                              "note": "overlapped span inside z_stage"}
         per_kernel["k_gen"]["bound"] = ("fp64/int VALU: 2 pcg64 steps + Box-Muller + P(k) per mode, regenerated for each "
                                         "of the %d passes" % plan.passes)
+        if fused_z:
+            per_kernel["k_gen"]["note"] = ("k_genz_plt: generator + z FFT + Hermitian stores in one kernel (the folded inputs stay on the "
+                                           "CU); = the whole z_stage")
         dom = max(alg, key=lambda k: kms[k])
         du = per_kernel[dom]
         dom_kernel, dom_launches = dom, kl[dom]

@@ -14,6 +14,10 @@ cut -c1-300 $R/gpurun_out/${TAG}_bench_under_rocprof.json
 for c in FETCH_SIZE WRITE_SIZE; do
 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${TAG}_$c -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-isolated $ARGS > $R/gpurun_out/pmc_${TAG}_$c.log 2>&1 || { tail -5 $R/gpurun_out/pmc_${TAG}_$c.log; exit 1; }
 done
+# 2b. one more pass with the SQ issue counters (where the waves' cycles go: bench.py reports them as roofline.valu_issue when the
+#     dominant unit is the vector-bound Z stage)
+SQ="SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU"
+rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${TAG}_SQ -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-isolated $ARGS > $R/gpurun_out/pmc_${TAG}_SQ.log 2>&1 || { tail -5 $R/gpurun_out/pmc_${TAG}_SQ.log; exit 1; }
 cd $R
 python3 - <<PY
 import csv, glob, collections, os, json
@@ -38,12 +42,22 @@ out={"workload": "PPD=%s plt=%d" % (wl.split()[0].split("=")[1], 1 if "qPLT=1" i
      "store_arrays": 3 if ("fields" in line["config"]["store"] or line["config"]["store"].startswith("3")) else int(line["config"]["store"].split()[0]),
      "passes": line["config"]["passes"], "bytes_per_launch": {}, "bytes_per_step": {},
      "note": "(2*FETCH_SIZE + WRITE_SIZE)*1024/launches: gfx950 FETCH_SIZE counts half of wide coalesced reads (MI355X_MICROARCH.md, HBM)"}
+NAMES={"k_genf":"k_gen","k_genz_plt":"k_gen","k_zfft_f":"k_zfft","k_yfft_f":"k_yfft","k_xfft_seq":"k_xfft","k_xfft_seq_plt":"k_xfft","k_xfft_q2_plt":"k_xfft"}
+# SQ counters per kernel: fractions of the waves' cycles (summed over waves) spent issuing / issuing VALU / waiting to issue
+sqf=glob.glob(f"{R}/gpurun_out/pmc_{TAG}_SQ/**/*counter_collection.csv", recursive=True)
+if sqf:
+    sq=collections.defaultdict(lambda: collections.defaultdict(float))
+    for row in csv.DictReader(open(sqf[0])):
+        k=row["Kernel_Name"].split("<")[0].split("(")[0].replace("void ","").strip()
+        sq[NAMES.get(k,k)][row["Counter_Name"]]+=float(row["Counter_Value"])
+    out["sq"]={k:{"valu_issue_per_wave_cycle": v["SQ_ACTIVE_INST_VALU"]/v["SQ_WAVE_CYCLES"], "any_issue_per_wave_cycle": v["SQ_ACTIVE_INST_ANY"]/v["SQ_WAVE_CYCLES"],
+                  "wait_to_issue_per_wave_cycle": v["SQ_WAIT_INST_ANY"]/v["SQ_WAVE_CYCLES"]} for k,v in sq.items() if k.startswith("k_") and v["SQ_WAVE_CYCLES"]>0}
 for k,v in res.items():
     if not k.startswith("k_") or "FETCH_SIZE" not in v or "WRITE_SIZE" not in v: continue
     n=v["FETCH_SIZE"]["launches"]
     fetch=2*v["FETCH_SIZE"]["total_KB"]*1024; write=v["WRITE_SIZE"]["total_KB"]*1024
     k=k.split("(")[0]
-    name={"k_genf":"k_gen","k_zfft_f":"k_zfft","k_yfft_f":"k_yfft","k_xfft_seq":"k_xfft","k_xfft_seq_plt":"k_xfft"}.get(k,k)
+    name=NAMES.get(k,k)
     out["bytes_per_launch"][name]=out["bytes_per_launch"].get(name,0)+(fetch+write)/n
     out["bytes_per_step"][name]=out["bytes_per_step"].get(name,0)+(fetch+write)
     print(k,"launches",n,"fetch GB (x2)",round(fetch/1e9,1),"write GB",round(write/1e9,1),"per launch MB",round((fetch+write)/n/1e6,1))

@@ -221,7 +221,13 @@ def _planes(zd, ps, n, zs, stride=1, eig=None, fmt="Zeldovich", want_density=Fal
     return res, info
 
 
-@pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096, 3456, 1000, 2000, 2500])
+# (slow: 3456 <-> 6912 — the composite kernels at those sizes run in the direct-sum fixtures ppd3456_za / ppd6912_plt_rescale and the
+# one-mode tests; 1000 / 2500: the convolution family keeps its link 2000 <-> 4000c)
+_SLOW = pytest.mark.slow
+
+
+@pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096, pytest.param(3456, marks=_SLOW), pytest.param(1000, marks=_SLOW), 2000,
+                               pytest.param(2500, marks=_SLOW)])
 def test_oversampled_planes_exact_at_full_size(zd, n):
     """PPD = 2n, ZD_k_cutoff = 2 at even lattice sites == PPD = n, ZD_k_cutoff = 1 (8192 <-> 4096: BASELINE C5 / C4,
     4096 <-> 2048: C3 size; 6912 <-> 3456: the production Abacus size 6912 = 2^8 3^3 on the composite-transform kernels;
@@ -250,7 +256,12 @@ def test_oversampled_planes_exact_at_full_size(zd, n):
         assert err < (1e-13 if n in (2048, 4096) else 1e-12)  # composite transforms: 27-term outer sums; 1000 / 2000: convolutions
 
 
-@pytest.mark.parametrize("n", [224, 448, 896, 1792, 3584, 336, 672, 1344, 2688, 560, 1120, 2240, 784, 1568, 3136, 2160, 4320])
+# (one link per family and chain end every time — 224 (oracle-anchored start), the top links 3584, 2688, 2240, 3136, 4320; the links in
+# between are `slow`: their sizes still run the one-mode PLT / density tests below and the dispatch-coverage check)
+@pytest.mark.parametrize("n", [224, pytest.param(448, marks=_SLOW), pytest.param(896, marks=_SLOW), pytest.param(1792, marks=_SLOW), 3584,
+                               336, pytest.param(672, marks=_SLOW), pytest.param(1344, marks=_SLOW), 2688, 560,
+                               pytest.param(1120, marks=_SLOW), 2240, 784, pytest.param(1568, marks=_SLOW), 3136,
+                               pytest.param(2160, marks=_SLOW), 4320])
 def test_radix7_oversampled_planes(zd, n):
     """Every composite grid with a radix-7 outer transform (round 4: Q = 7, 21, 35, 49 and Q = 135; csrc/zd_kernels_np2.hip NP2_SIZES)
     runs at its own size: PPD = 2n with ZD_k_cutoff = 2 at even sites == PPD = n.  The chains start from a run checked elsewhere:
@@ -276,7 +287,11 @@ def test_radix7_oversampled_planes(zd, n):
         assert err < 1e-12
 
 
-@pytest.mark.parametrize("n", [192, 384, 768, 1536, 1152, 2304, 320, 1280, 2560, 960, 1920, 3840, 1600, 3200, 720, 1440, 2880, 1200, 2400, 4000])
+# (per family Q = 3, 9, 5, 15, 25, 45, 75, 125: the first link and the top link every time, the ones in between `slow` —
+# except 1920: the only run with z lines of 1920 = 128 * 15, which the dispatch-coverage check wants)
+@pytest.mark.parametrize("n", [192, pytest.param(384, marks=_SLOW), pytest.param(768, marks=_SLOW), 1536, 1152, 2304, 320,
+                               pytest.param(1280, marks=_SLOW), 2560, 960, 1920, 3840, 1600, 3200, 720,
+                               pytest.param(1440, marks=_SLOW), 2880, 1200, 2400, 4000])
 def test_smooth_sizes_oversampled_planes(zd, n):
     """The 3- and 5-smooth composite grids of rounds 2 and 3 that had no run AT their size in the suite (found with zd_dispatch_report:
     384, 640, 768, 1440, 1536, 1920, 2304, 2400, 2560, 2880, 3072, 3200, 3840, 4608, 4800, 5120, 5760, 6400, 7680, 8000 — their
@@ -449,7 +464,7 @@ def test_density_planes_of_the_reference_arrays_at_4096(zd, n, kc):
     assert np.abs(da).max() > 0 and np.abs(da - db).max() <= 2e-7 * np.abs(da).max()
 
 
-@pytest.mark.parametrize("n", [512, 1024, 2048])
+@pytest.mark.parametrize("n", [512, pytest.param(1024, marks=_SLOW), pytest.param(2048, marks=_SLOW)])
 def test_density_only_runs_at_large_sizes(zd, n):
     """ZD_qdensity = 2 (one array, no records: launch_xfft_t<N, 16, 1, .>) at the large powers of two: the variance of the density
     planes it writes must equal the generator's sum of |D|^2 of the default ZA run (Parseval; src/output.cpp:225-228 sums the planes)"""
@@ -460,7 +475,7 @@ def test_density_only_runs_at_large_sizes(zd, n):
     assert abs(a["density_variance"] - b["density_variance"]) <= 2e-6 * a["density_variance"]  # float32 planes summed in double
 
 
-@pytest.mark.parametrize("n,R", [(256, 2), (1024, 4), (2048, 8)])
+@pytest.mark.parametrize("n,R", [(256, 2), (1024, 4), pytest.param(2048, 8, marks=_SLOW)])
 def test_fnl_round_trip_identity_at_large_sizes(zd, n, R):
     """The phi round of ZD_f_NL (inverse z / y / x transforms of phi = D / M, phi + f_NL phi^2, forward x / y / z transforms, D = phi M:
     k_xphi / k_yfwd / k_zfwd, launch_fnl_t<N>) at sizes the oracle cannot run: with f_NL = 1e-300 the nonlinear term vanishes and
@@ -626,6 +641,8 @@ def test_ppd6912_on_one_gpu_plane_waves(zd, oracle, n, R, modes):
             assert np.abs(rec["v"][..., 2 - j] - vnorm * want).max() <= 1e-12 * vnorm * scale, (mode, j)
 
 
+@pytest.mark.slow  # (15 s of 208 GB allocations; C3 is anchored by its direct-sum fixture and by tests/test_gpu_fused_z.py, the reference's
+                   # four arrays at 2048 by the random-plane comparison above)
 def test_ppd2048_plt_store_and_stream_invariance(zd, oracle):
     """C3 (PPD = 2048, PLT + rescale): the packed store and the reference's four arrays give the same reductions over all 8.6e9
     particles (size-independent property; the oracle cannot run that many)"""

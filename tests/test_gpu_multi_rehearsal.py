@@ -212,3 +212,24 @@ def test_one_rank_two_stores_equal_one_store(zd, oracle, kw):
     ref = zd.generate(p, ps, eig=eig)
     for z in range(n):
         assert ref["records"][z].reshape(n, n).tobytes() == b[z].tobytes(), z
+
+
+def test_a_rank_that_fails_before_its_first_pass_does_not_strand_its_peers(zd):
+    """a rank fails BEFORE pass 0 (store allocation, plan error) while its peers already sit inside their first
+    grouped send / receive — a blocking call that only the abort of the communicator ends.  Round 4 held the communicator's mutex
+    across that call, so the aborting thread waited for a lock its victim could not release.  On the in-process emulation of the
+    RCCL calls (whose GroupEnd blocks on the peer for up to 30 s and returns at once when the communicator is aborted): the job must
+    come back with an error well before that."""
+    L = zd.load_testing_library()
+    ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
+    for ngpu in (2, 4):
+        L.zd_test_fail_rank(1)
+        t0 = time.time()
+        try:
+            with pytest.raises(RuntimeError):
+                zd.generate(zd.make_params(128, icformat="RVZel", stream_factor=4, ngpu=ngpu, exchange_planes=3, pass_groups=1), ps, loopback=True)
+        finally:
+            L.zd_test_fail_rank(-1)
+        assert time.time() - t0 < 15, time.time() - t0
+    out = zd.generate(zd.make_params(64, icformat="RVZel", stream_factor=2, ngpu=2, pass_groups=1), ps, loopback=True)  # usable afterwards
+    assert sorted(out["planes_seen"]) == list(range(64))

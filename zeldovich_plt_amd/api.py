@@ -83,7 +83,7 @@ EXPORTED_SYMBOLS = [
     "zd_dispatch_report",
 ]
 # test scaffolding: exists only in the -DZD_TESTING library (csrc/zd_testing.h, `make testing`), never in the product
-TESTING_SYMBOLS = ["zd_test_draws", "zd_test_modes", "zd_test_modes_table", "zd_test_v1_words", "zd_test_generate_loopback",
+TESTING_SYMBOLS = ["zd_test_draws", "zd_test_modes", "zd_test_modes_table", "zd_test_v1_words", "zd_test_generate_loopback", "zd_test_fail_rank",
                    "zd_test_fft", "zd_test_poison"]
 STORE_MODES = {"auto": 0, "reference": 1, "packed": 2, "fields": 3}  # zd_params.store_mode (ZD_STORE_*)
 

@@ -299,10 +299,10 @@ extern "C" {
 // power-of-two grids keep the reference's arrays for ZD_qdensity (their kernels exist); ZD_qdensity = 2 (density only), PLT and
 // f_NL with a density stay on the convolution path for composite PPDs.
 static bool dens_fields(const zd_params *p) {
-    // (PPD <= 8192: beyond it — 8640 = 64 * 135 — only the plain ZA field store has been run; the plan then refuses ZD_qdensity
-    // with the message of the PPD > 8192 gate instead of taking a six-field store nobody has tested at that size)
-    return p->qdensity == 1 && !p->qPLT && p->f_NL == 0. && p->qoneslab < 0 && !is_pow2(p->ppd) && p->ppd <= 8192
-           && zd::np2_supported_ppd((int) p->ppd) && (p->store_mode == ZD_STORE_AUTO || p->store_mode == ZD_STORE_FIELDS);
+    // (8640 = 64 * 135 included: the six-field store runs there too — tests/test_gpu_baseline_regime.py,
+    // test_density_one_mode_at_every_composite_size[8640]; the PPD > 8192 gate's message says so)
+    return p->qdensity == 1 && !p->qPLT && p->f_NL == 0. && p->qoneslab < 0 && !is_pow2(p->ppd) && zd::np2_supported_ppd((int) p->ppd)
+           && (p->store_mode == ZD_STORE_AUTO || p->store_mode == ZD_STORE_FIELDS);
 }
 // Packed stores (zd_device.h PACK_*): without ZD_qdensity the density field is not transformed.
 static int pack_mode(const zd_params *p, int R) {
@@ -747,7 +747,8 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
     if (zd::pack_is_fields(pl->pack) && ((pl->half / nranks) % zd::FIELD_RB || N / R > 2048))  // row blocks of 8, z FFT <= 2048
         pl->pack = N > 4096 ? zd::PACK_NONE : (pl->pack == zd::PACK_PLTFIELD ? zd::PACK_PLT3 : zd::PACK_ZAPAIR);
     if (N > 8192 && pl->pack != zd::PACK_ZAFIELD) {  // a 16384-point line fills a workgroup: only the field store's kernels exist (also 8640 = 64 * 135: ZA)
-        fprintf(stderr, "zeldovich_hip: PPD = %lld runs on the ZA field store only (ZD_StreamFactor >= 16, no ZD_qdensity / ZD_qPLT / ZD_f_NL)\n",
+        fprintf(stderr, "zeldovich_hip: PPD = %lld runs on the ZA field store only (ZD_StreamFactor >= 16; no ZD_qPLT / ZD_f_NL / ZD_qdensity = 2; "
+                        "ZD_qdensity = 1 on the composite grid 8640 only)\n",
                 (long long) N);
         delete pl;
         return 1;
@@ -1259,8 +1260,21 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         pl->d_Y.assign(K, nullptr);
         for (int i = 0; i < K; i++) PLCHECK(hipMalloc((void **) &pl->d_Y[i], (size_t) row_b * rows));
         if (pl->overlap) {
-            PLCHECK(hipStreamCreateWithFlags(&pl->s_gen, hipStreamNonBlocking));
-            PLCHECK(hipStreamCreateWithFlags(&pl->s_fft, hipStreamNonBlocking));
+#ifdef ZD_TUNING
+            // A/B (VERDICT r4 #5 i): ZD_CU_SPLIT = n gives the z FFT's stream n CUs of every XCD's 32 and the generator's stream
+            // the other 32 - n (hipExtStreamCreateWithCUMask; CU c of the mask = XCD c % 8, CU c / 8 of it on this part)
+            if (const char *env = tune_env("ZD_CU_SPLIT")) {
+                const int nf = std::max(1, std::min(31, atoi(env)));
+                uint32_t mg[8] = {0}, mf[8] = {0};
+                for (int c = 0; c < 256; c++) ((c / 8) < nf ? mf : mg)[c / 32] |= 1u << (c % 32);
+                PLCHECK(hipExtStreamCreateWithCUMask(&pl->s_gen, 8, mg));
+                PLCHECK(hipExtStreamCreateWithCUMask(&pl->s_fft, 8, mf));
+            } else
+#endif
+            {
+                PLCHECK(hipStreamCreateWithFlags(&pl->s_gen, hipStreamNonBlocking));
+                PLCHECK(hipStreamCreateWithFlags(&pl->s_fft, hipStreamNonBlocking));
+            }
             PLCHECK(hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming));
             pl->ev_gen.assign(K, nullptr);
             pl->ev_fft.assign(K, nullptr);

@@ -499,6 +499,22 @@ enum { GENF_DENS = 0, GENF_ZA = 1, GENF_PLT = 2, GENF_ZAP = 3 /* PACK_ZAPAIR */,
        GENF_PLTF = 6 /* PACK_PLTFIELD: the sums of GENF_PLTN written out as they are */,
        GENF_ZAFD = 7 /* PACK_ZAFIELD + ZD_qdensity = 1: the four potentials and the density sum D of both residues (six fields) */ };
 
+// Tail of the k_genf eigenmode lookups: from the blended (un-normalised) table entry eh = (e_x, e_y, e_z, lambda) of |kz| to the
+// coefficient of the displacement, out[j] = s_j = e_j k^2 / (k.e) x fundamental / k^2 = e_j / ((k.e) fundamental) (round 5: neither
+// |e| nor k^2 enters — the reference normalises e, src/zeldovich.cpp:255-262, forms e k^2 / (k.e) and LoadPlane multiplies by
+// fundamental / k^2, :428-434; one reciprocal instead of an inverse square root with two Newton steps and two reciprocals: 25 of a
+// PLT mode's ~350 instructions); k.e = 0 or not finite -> 0 as there (:262-263; k = 0 does not occur: ky >= 1); out[3] = lambda
+__device__ __forceinline__ void eig_coeff_tail(double fundamental, int kx, int ky, int kz, double (&eh)[4], double (&out)[4]) {
+    eh[2] *= (kz < 0 ? -1.0 : 1.0);
+    const double dot = kx * eh[0] + ky * eh[1] + kz * eh[2];
+    double inv = frcp(dot * fundamental);
+    if (!isfinite(inv)) inv = 0.0;
+    out[0] = inv * eh[0];
+    out[1] = inv * eh[1];
+    out[2] = inv * eh[2];
+    out[3] = eh[3];
+}
+
 // get_eigenmode for k_genf: the (x, y) part of the lookup — table offsets of the 4 corner columns and the products
 // w_x w_y — depends on the thread's kx and the row's ky only and is prepared once per tile; per mode remain the two
 // z corners, 1/|e| by rsq + Newton and k^2/(k.e) by reciprocal (get_eigenmode_dev: sqrt + two divisions).
@@ -520,6 +536,7 @@ __device__ __forceinline__ EigXY eig_xy(const GenConst &g, const EigAxis &ax, co
 }
 __device__ __forceinline__ void eigenmode_fast(const GenConst &g, int kx, int ky, int kz, const EigXY &q, const EigAxis &az,
                                                double (&out)[4]) {
+    const double fundamental = g.fundamental;
     const double2 *E = reinterpret_cast<const double2 *>(g.eig);
     double eh[4];
     if ((int) g.eig_ppd % g.N == 0) {
@@ -544,22 +561,7 @@ __device__ __forceinline__ void eigenmode_fast(const GenConst &g, int kx, int ky
             }
         }
     }
-    eh[2] *= (kz < 0 ? -1.0 : 1.0);
-    const double n2 = eh[0] * eh[0] + eh[1] * eh[1] + eh[2] * eh[2];
-    double r = trans_rsq(n2);
-    r = r * fma(-0.5 * n2, r * r, 1.5);
-    r = r * fma(-0.5 * n2, r * r, 1.5);
-    eh[0] *= r;
-    eh[1] *= r;
-    eh[2] *= r;
-    const double k2  = (double) (kx * kx + ky * ky + kz * kz);
-    const double dot = kx * eh[0] + ky * eh[1] + kz * eh[2];
-    double norm = k2 * frcp(dot);
-    if (k2 == 0.0 || !isfinite(norm)) norm = 0.0;
-    out[0] = norm * eh[0];
-    out[1] = norm * eh[1];
-    out[2] = norm * eh[2];
-    out[3] = eh[3];
+    eig_coeff_tail(fundamental, kx, ky, kz, eh, out);
 }
 
 // The (x, y) part of the trilinear lookup does not depend on kz: k_eig_lines does it once per column of a slab and pass — for
@@ -619,7 +621,7 @@ __device__ __forceinline__ EigRaw eig_lines_load(const GenConst &g, int kz, int 
     return r;
 }
 // eigenmode_lines from loaded entries (same arithmetic, same order)
-__device__ __forceinline__ void eig_lines_finish(int kx, int ky, int kz, const EigRaw &r, double (&out)[4]) {
+__device__ __forceinline__ void eig_lines_finish(double fundamental, int kx, int ky, int kz, const EigRaw &r, double (&out)[4]) {
     double eh[4] = {0.0, 0.0, 0.0, 0.0};
     if (r.wl != 0) {
         eh[0] = r.wl * r.a0.x;
@@ -633,26 +635,12 @@ __device__ __forceinline__ void eig_lines_finish(int kx, int ky, int kz, const E
         eh[2] += r.wh * r.b1.x;
         eh[3] += r.wh * r.b1.y;
     }
-    eh[2] *= (kz < 0 ? -1.0 : 1.0);
-    const double n2 = eh[0] * eh[0] + eh[1] * eh[1] + eh[2] * eh[2];
-    double rr = trans_rsq(n2);
-    rr = rr * fma(-0.5 * n2, rr * rr, 1.5);
-    rr = rr * fma(-0.5 * n2, rr * rr, 1.5);
-    eh[0] *= rr;
-    eh[1] *= rr;
-    eh[2] *= rr;
-    const double k2  = (double) (kx * kx + ky * ky + kz * kz);
-    const double dot = kx * eh[0] + ky * eh[1] + kz * eh[2];
-    double norm = k2 * frcp(dot);
-    if (k2 == 0.0 || !isfinite(norm)) norm = 0.0;
-    out[0] = norm * eh[0];
-    out[1] = norm * eh[1];
-    out[2] = norm * eh[2];
-    out[3] = eh[3];
+    eig_coeff_tail(fundamental, kx, ky, kz, eh, out);
 }
 
 // eigenmode_fast from the slab's (x, y)-interpolated lines (k_eig_lines); `row` = row of the slab
 __device__ __forceinline__ void eigenmode_lines(const GenConst &g, int kx, int ky, int kz, int row, int x, const EigAxis &az, double (&out)[4]) {
+    const double fundamental = g.fundamental;
     const double2 *V = reinterpret_cast<const double2 *>(g.eig_lines);
     const size_t il = (((size_t) az.l * g.eig_rows + row) * g.N + x) * 2;
     const double wl = 1 - az.f, wh = az.f;
@@ -672,22 +660,7 @@ __device__ __forceinline__ void eigenmode_lines(const GenConst &g, int kx, int k
         eh[2] += wh * b1.x;
         eh[3] += wh * b1.y;
     }
-    eh[2] *= (kz < 0 ? -1.0 : 1.0);
-    const double n2 = eh[0] * eh[0] + eh[1] * eh[1] + eh[2] * eh[2];
-    double r = trans_rsq(n2);
-    r = r * fma(-0.5 * n2, r * r, 1.5);
-    r = r * fma(-0.5 * n2, r * r, 1.5);
-    eh[0] *= r;
-    eh[1] *= r;
-    eh[2] *= r;
-    const double k2  = (double) (kx * kx + ky * ky + kz * kz);
-    const double dot = kx * eh[0] + ky * eh[1] + kz * eh[2];
-    double norm = k2 * frcp(dot);
-    if (k2 == 0.0 || !isfinite(norm)) norm = 0.0;
-    out[0] = norm * eh[0];
-    out[1] = norm * eh[1];
-    out[2] = norm * eh[2];
-    out[3] = eh[3];
+    eig_coeff_tail(fundamental, kx, ky, kz, eh, out);
 }
 
 template <int ZR, int KIND, bool PLAW>
@@ -825,9 +798,7 @@ __device__ __forceinline__ double genf_tile(const GenConst &g, const GenJumps &J
                 const double f = (sqrt_pos(1. + 24 * e[3] * g.f_cluster) - 1) * .25;
                 double rescale = 1.0;
                 if (g.qPLTrescale) rescale = fexp(g.ln_growth_ratio * (g.target_f - f), T);
-                const double sx = rescale * e[0] * g.fundamental * ik2;
-                const double sy = rescale * e[1] * g.fundamental * ik2;
-                const double sz = rescale * e[2] * g.fundamental * ik2;
+                const double sx = rescale * e[0], sy = rescale * e[1], sz = rescale * e[2];  // e = the coefficients s_j (eig_coeff_tail)
                 cmac(accr[B + 0], acci[B + 0], sx, dr, di);
                 cmac(accr[B + 1], acci[B + 1], sy, dr, di);
                 cmac(accr[B + 2], acci[B + 2], sz, dr, di);
@@ -1020,15 +991,13 @@ __device__ __forceinline__ double genf_tile_kz(const GenConst &g, const GenJumps
             const double ik2 = frcp(k2v);
             double e[4];
             if (g.eig_lines)  // (uniform) the slab's (x, y)-interpolated lines, requested one fold term ahead
-                eig_lines_finish(kx, ky, kz, ecur, e);
+                eig_lines_finish(g.fundamental, kx, ky, kz, ecur, e);
             else
                 eigenmode_fast(g, kx, ky, kz, exy, eig_axis(g, eig_index_z(g, kz)), e);
             const double f = (sqrt_pos(1. + 24 * e[3] * g.f_cluster) - 1) * .25;
             double rescale = 1.0;
             if (g.qPLTrescale) rescale = fexp(g.ln_growth_ratio * (g.target_f - f), T);
-            const double sx = rescale * e[0] * g.fundamental * ik2;
-            const double sy = rescale * e[1] * g.fundamental * ik2;
-            const double sz = rescale * e[2] * g.fundamental * ik2;
+            const double sx = rescale * e[0], sy = rescale * e[1], sz = rescale * e[2];  // e = the coefficients s_j (eig_coeff_tail)
             auto one = [&](uint64_t r1, uint64_t r2, int kf, double szs, double (&ar)[6], double (&ai)[6]) {
                 // cgauss<2> (power_spectrum.cpp:338-359); zeroed lanes of a live wave ride along with amplitude 0
                 const uint64_t m1 = r1 + 1ULL;
@@ -2886,7 +2855,9 @@ static int launch_yfft_t(const StoreLayout &S, int nplanes, const void *tw, void
     const size_t shmem = sizeof(double) * zdfft::ColsInner<N, W>::SIZE;
     set_dyn_lds<k_yfft<N, E, W, 1, false>>(shmem);
     set_dyn_lds<k_yfft<N, E, W, 1, true>>(shmem);
-    if (S.lq && (!S.one_block || (N << S.lq) % W || nplanes % (1 << S.lq) || (unsigned long long) S.pitch * N * 16ull >= (1ull << 32))) {
+    // (lq = 2 with W = 8 only: the tile is then one 128-byte line per row, which the kernel writes back [plane][column] — the order
+    // k_xfft_q2_plt reads)
+    if (S.lq && (S.lq != 2 || W != 8 || !S.one_block || nplanes % (1 << S.lq) || (unsigned long long) S.pitch * N * 16ull >= (1ull << 32))) {
         fprintf(stderr, "zeldovich_hip: plane-interleaved rows need the single-rank store and whole plane groups\n");
         return 2;
     }
@@ -2927,6 +2898,11 @@ int launch_zfft_fields(int L, const FieldLayout &F, const StoreLayout &S, int ky
                        const void *twL, void *out, hipStream_t st) {
 #define ZCASE(l, e, nc) \
     case l: return launch_zfft_f_t<l, e, nc>(F, S, ky0, kyloc0, nky, Y, twL, out, st);
+#ifdef ZD_TUNING
+    // A/B (VERDICT r4 #5 ii): the 512-point z FFT of the default workload with 8 elements per thread — 512 threads of half the
+    // registers, two waves per SIMD beside the generator's three instead of one
+    if (L == 512 && getenv("ZD_ZFFT_E8")) return launch_zfft_f_t<512, 8, 1>(F, S, ky0, kyloc0, nky, Y, twL, out, st);
+#endif
     switch (L) {  // = zfft_fields_tile_columns
         ZCASE(32, 16, 4)
         ZCASE(64, 16, 4)

@@ -30,6 +30,9 @@
 
 #include "zd_launch.h"
 #include "zd_plan.h"
+#ifdef ZD_TESTING
+#include "zd_testing.h"  // (default visibility of the test hooks defined here)
+#endif
 
 using zdfft::cplx;
 
@@ -125,7 +128,9 @@ struct LoopState {
     std::vector<std::vector<LoopMsg>> box;  // box[src * n + dst]: messages in posting order
     std::vector<size_t> taken;              // next message the receiver takes
     int n = 0;
+    std::atomic<bool> aborted{false};       // the emulated ncclCommAbort: a rank blocked in loop_group_end comes out with an error
 } g_loop;
+std::atomic<int> g_test_fail_rank{-1};      // zd_test_fail_rank: this rank of the thread-per-GPU driver fails before its first pass
 struct LoopOp {
     bool send;
     void *ptr;
@@ -172,7 +177,8 @@ ncclResult_t loop_group_end() {
             std::unique_lock<std::mutex> lk(g_loop.mu);
             const size_t key = (size_t) op.peer * n + me;
             // (bounded: a rank that failed never posts, and a test must not hang the box)
-            if (!g_loop.cv.wait_for(lk, std::chrono::seconds(30), [&] { return g_loop.box[key].size() > g_loop.taken[key]; }))
+            if (!g_loop.cv.wait_for(lk, std::chrono::seconds(30), [&] { return g_loop.aborted.load() || g_loop.box[key].size() > g_loop.taken[key]; })
+                || g_loop.aborted.load())
                 return ncclInternalError;
             LoopMsg &m = g_loop.box[key][g_loop.taken[key]++];
             if (m.nb != op.nb) return ncclInvalidArgument;
@@ -188,10 +194,19 @@ ncclResult_t loop_group_end() {
     for (auto &pi : mine) {  // the send buffers may be reused only after the receivers have read them
         std::unique_lock<std::mutex> lk(g_loop.mu);
         const size_t key = (size_t) me * n + pi.first;
-        if (!g_loop.cv.wait_for(lk, std::chrono::seconds(30), [&] { return g_loop.box[key][pi.second].has_done; })) return ncclInternalError;
+        if (!g_loop.cv.wait_for(lk, std::chrono::seconds(30), [&] { return g_loop.aborted.load() || g_loop.box[key][pi.second].has_done; })
+            || g_loop.aborted.load())
+            return ncclInternalError;
         if (hipStreamWaitEvent(st, g_loop.box[key][pi.second].done, 0) != hipSuccess) return ncclInternalError;
     }
     t_loop_ops.clear();
+    return ncclSuccess;
+}
+// like ncclCommAbort for a blocking communicator: whoever is inside a blocking call of the job comes out with an error
+ncclResult_t loop_comm_abort(ncclComm_t) {
+    g_loop.aborted.store(true);
+    std::lock_guard<std::mutex> lk(g_loop.mu);
+    g_loop.cv.notify_all();
     return ncclSuccess;
 }
 const char *loop_error_string(ncclResult_t) { return "loopback transport"; }
@@ -424,6 +439,10 @@ ncclComm_t comm_abort_handle(zd_comm *c, int grace_ms = 500) {
     return h;
 }
 }  // namespace
+
+#ifdef ZD_TESTING
+void zd_test_fail_rank(int rank) { g_test_fail_rank.store(rank); }
+#endif
 
 void zd_comm_abort(zd_comm *c) {
     if (!c) return;
@@ -987,6 +1006,8 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
         g_loop_api.Send        = loop_send;
         g_loop_api.Recv        = loop_recv;
         g_loop_api.GetErrorString = loop_error_string;
+        g_loop_api.CommAbort   = loop_comm_abort;
+        g_loop.aborted.store(false);
         g_rccl_override        = &g_loop_api;
         for (int g = 0; g < G; g++) {
             loops[g].rank = g;
@@ -1034,7 +1055,7 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
         job_failed.store(1, std::memory_order_release);
         for (LocalGroup &grp : grps) grp.fail();
         std::lock_guard<std::mutex> lk(abort_mu);
-        if (aborted || transport != 0) return;
+        if (aborted || transport == 1) return;  // (RCCL, or its emulation in the testing library)
         aborted = true;
         RcclApi *R = rccl();
         (void) R;
@@ -1084,6 +1105,12 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
                 c->grp    = &grps[grp_id];
                 c->failed = &job_failed;
                 if (comm_prepare(c)) break;
+#ifdef ZD_TESTING
+                if (g_test_fail_rank.load() == g) {  // a rank that fails BEFORE its first exchange (store allocation, plan error):
+                    fprintf(stderr, "zeldovich_hip: (test) rank %d fails before pass 0\n", g);  // its peers sit in their first GroupEnd
+                    break;
+                }
+#endif
                 if (p.f_NL != 0.) {  // the phi round first (its own plan, store and ring), then the main plan reads PhiK
                     zd_plan *ph = nullptr;
                     void *d_phi = nullptr;

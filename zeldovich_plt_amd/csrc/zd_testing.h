@@ -29,6 +29,9 @@ int zd_test_v1_words(int64_t seed, int32_t nblocks, uint32_t *out);
 int zd_test_fft(int32_t n, int64_t lines, int32_t axis_kind, const double *in, double *out);
 /* on != 0: every store / exchange ring / phi field the library allocates from now on starts out as NaN bytes */
 void zd_test_poison(int on);
+/* rank >= 0: that rank of the thread-per-GPU driver (zd_generate with ngpu > 1, zd_test_generate_loopback) fails BEFORE its first
+ * pass — its peers are then blocked inside their first grouped send / receive, which only an abort ends; -1: nobody */
+void zd_test_fail_rank(int rank);
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }
