@@ -150,9 +150,15 @@ def _store_tensor(nbytes):
     return _STORE["t"]
 
 
+# tests of this module that allocate large buffers inside the library (the store must make room for them); the others — grids up to
+# 512 — run beside the cached store (round 5: every drop costs the next user ~8 s of hipMalloc)
+_MEMORY_HUNGRY = {"test_density_only_runs_at_large_sizes", "test_fnl_round_trip_identity_at_large_sizes",
+                  "test_ppd2048_plt_store_and_stream_invariance", "test_plain_fma_build_passes_the_parity_suite"}
+
+
 @pytest.fixture(autouse=True)
 def _store_cache_guard(request):
-    if request.node.originalname not in _STORE_USERS:
+    if request.node.originalname in _MEMORY_HUNGRY:
         _drop_store()
     yield
 
