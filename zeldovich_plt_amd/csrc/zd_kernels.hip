@@ -2204,21 +2204,27 @@ __global__ __launch_bounds__(N / E, 2) void k_xfft_seq_plt(StoreLayout S, EpiCon
 // positions alternate h = 0, 1), so that the second one finds the lines in that XCD's L2 (as two distant workgroups every line was
 // fetched from HBM twice: x stage of PPD=2048 PLT 201 ms against 134 on the plain rows).
 //   grid: (2 N, plane groups touched)   block: 2 N/E
-template <int N, int E>
-__global__ __launch_bounds__(2 * N / E, 2) void k_xfft_q2_plt(StoreLayout S, EpiConst ec, const cplx *__restrict__ tw,
+template <int N, int E, int NP = 2>
+__global__ __launch_bounds__(NP * N / E, NP == 2 ? 2 : 1) void k_xfft_q2_plt(StoreLayout S, EpiConst ec, const cplx *__restrict__ tw,
                                                             const cplx *__restrict__ data, int plane0, int nplanes, int z_first,
                                                             int z_step, char *__restrict__ records, Reduce *__restrict__ red, int hdist) {
     using PL  = zdfft::Plan<N, E>;
-    using LDS = zdfft::ColsInner<N, 2>;
+    using LDS = zdfft::ColsInner<N, NP>;  // NP = 2 planes of the group per workgroup (product) or all 4 (A/B: ZD_XQ_NP4)
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr int T = PL::T, NT = 2 * T;
-    const int w = threadIdx.x & 1, t = threadIdx.x >> 1;
+    constexpr int T = PL::T, NT = NP * T;
+    const int w = threadIdx.x % NP, t = threadIdx.x / NP;
     static_assert(N % 8 == 0, "rows are dealt to the 8 XCDs");
-    const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
-    const int grp = pos / (2 * hdist), m = pos % (2 * hdist), h = m / hdist;  // hdist rows with h = 0, then the same rows with h = 1
-    const int y = ((grp * hdist + m % hdist) << 3) + xcd;
+    int y, h = 0;
+    if constexpr (NP == 2) {
+        const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
+        const int grp = pos / (2 * hdist), m = pos % (2 * hdist);  // hdist rows with h = 0, then the same rows with h = 1
+        h = m / hdist;
+        y = ((grp * hdist + m % hdist) << 3) + xcd;
+    } else {
+        y = blockIdx.x;
+    }
     const int pl = 4 * ((plane0 >> 2) + (int) blockIdx.y) + 2 * h + w;  // this thread's plane of the store
-    if (pl - w + 1 < plane0 || pl - w >= plane0 + nplanes) return;      // (uniform) neither plane of the pair is asked for
+    if (pl - w + NP - 1 < plane0 || pl - w >= plane0 + nplanes) return;  // (uniform) none of the workgroup's planes is asked for
     const bool active = pl >= plane0 && pl < plane0 + nplanes;
     const int pi = pl - plane0;                                      // its position among the delivered planes
     double *c2i = lds + LDS::SIZE;                                   // [x][w] = vz; a thread reads back only what it wrote itself
@@ -2266,7 +2272,7 @@ __global__ __launch_bounds__(2 * N / E, 2) void k_xfft_q2_plt(StoreLayout S, Epi
 #pragma unroll
             for (int e = 0; e < E; e++) {
                 c2r[e] = re[e];
-                c2i[2 * (t2 + T * e) + w] = im[e];
+                c2i[NP * (t2 + T * e) + w] = im[e];
             }
             continue;
         }
@@ -2275,7 +2281,7 @@ __global__ __launch_bounds__(2 * N / E, 2) void k_xfft_q2_plt(StoreLayout S, Epi
             for (int e = 0; e < E; e++) {
                 const int xx = t2 + T * e;
                 const double pos[3] = {c0r[e], re[e], im[e]};
-                const double vel[3] = {c0i[e] * ec.vnorm, c2r[e] * ec.vnorm, c2i[2 * xx + w] * ec.vnorm};
+                const double vel[3] = {c0i[e] * ec.vnorm, c2r[e] * ec.vnorm, c2i[NP * xx + w] * ec.vnorm};
                 max_track(mx, pos, ((unsigned long long) z * N + (unsigned long long) y) * N + (unsigned long long) xx);
                 if (records) emit_record(records, plane_rec0 + (long long) y * N + xx, ec, z, y, xx, pos, vel);
             }
@@ -3059,6 +3065,17 @@ static int launch_xfft_seq_plt_t(const StoreLayout &S, const EpiConst &ec, const
 template <int N, int E>
 static int launch_xfft_q2_plt_t(const StoreLayout &S, const EpiConst &ec, const void *tw, const void *data, int plane0, int nplanes,
                                 int z_first, int z_step, void *records, Reduce *red, hipStream_t st) {
+#ifdef ZD_TUNING
+    if (getenv("ZD_XQ_NP4")) {  // A/B: one workgroup per plane group (all four planes: whole 64-byte pieces per column, one workgroup per CU)
+        const size_t sh4 = sizeof(double) * (zdfft::ColsInner<N, 4>::SIZE + 4 * N);
+        set_dyn_lds<k_xfft_q2_plt<N, E, 4>>(sh4);
+        const int q4 = ((plane0 + nplanes - 1) >> 2) - (plane0 >> 2) + 1;
+        hipLaunchKernelGGL((k_xfft_q2_plt<N, E, 4>), dim3(N, q4), dim3(4 * N / E), sh4, st, S, ec, (const cplx *) tw, (const cplx *) data, plane0,
+                           nplanes, z_first, z_step, (char *) records, red, 1);
+        ZD_LAUNCH_CHECK();
+        return 0;
+    }
+#endif
     const size_t shmem = sizeof(double) * (zdfft::ColsInner<N, 2>::SIZE + 2 * N);  // + vz of array 2, both lines
     set_dyn_lds<k_xfft_q2_plt<N, E>>(shmem);
     const int quads = ((plane0 + nplanes - 1) >> 2) - (plane0 >> 2) + 1;
