@@ -10,10 +10,12 @@ for spec in sys.argv[1:]:
     kw, eig = {}, None
     if len(f) > 2 and f[2] == "dens":
         kw = dict(qdensity=1)
+    if len(f) > 2 and f[2] == "dens2":
+        kw = dict(qdensity=2)
     if plt:
         import bench
         eig = bench.synthetic_eigenmodes(128)
         kw = dict(qPLT=1, qPLTrescale=1, PLT_target_z=5.0, z_initial=49.0)
     a = zd.generate(zd.make_params(n, icformat="RVZel", profile=1, k_cutoff=kc, **kw), ps, eig=eig, collect=False)
-    print(n, "PLT" if plt else ("ZA+density" if kw.get("qdensity") else "ZA"), "k_cutoff", kc, "R", a["stream_factor"], "sec", round(a["seconds_total"], 2),
+    print(n, "PLT" if plt else ("ZA+density" if kw.get("qdensity") == 1 else ("density only" if kw.get("qdensity") == 2 else "ZA")), "k_cutoff", kc, "R", a["stream_factor"], "sec", round(a["seconds_total"], 2),
           {k: round(v) for k, v in a["kernel_ms"].items()}, "var", repr(a["density_variance"]), flush=True)

@@ -854,6 +854,28 @@ def test_density_on_composite_grids_vs_oracle(zd, oracle, ps, opk, n, kw):
     assert sorted(got["planes_seen"]) == list(range(n))
 
 
+@pytest.mark.parametrize("n,kw", [
+    (96, dict(stream_factor=2)),                      # 32 * 3
+    (160, dict(stream_factor=2, k_cutoff=2.0)),       # 32 * 5, pruned columns
+    (224, dict(stream_factor=2)),                     # 32 * 7
+    (192, dict(stream_factor=2, ngpu=2)),             # two ranks that exchange the six fields
+])
+def test_density_only_on_composite_grids_vs_oracle(zd, oracle, ps, opk, n, kw):
+    """ZD_qdensity = 2 — density only: no displacements, no records (src/zeldovich.cpp:303,872-876, src/output.cpp:94,207-224) — on the
+    composite kernels (round 5; before: the ~6x slower convolution path): the six-field ZA store, of which only the
+    density array is built and transformed.  Density planes (float32) and density_variance against the oracle; no records, and
+    max_disp stays zero as in the reference (WriteParticlesSlab never touches it)."""
+    kw = dict(kw)
+    plan = zd.Plan(zd.make_params(n, qdensity=2, **{k: v for k, v in kw.items() if k != "ngpu"}), ps)
+    assert plan.store_mode == "fields"  # not the single reference array of the convolution path
+    plan.close()
+    got, ref = _compare(zd, oracle, ps, opk, n, qdensity=2, **kw)
+    assert got["records"] is None and ref["records"] is None
+    assert got["density"] is not None and np.abs(ref["density"]).max() > 0
+    assert np.abs(got["max_disp"]).max() == 0.0
+    assert sorted(got["planes_seen"]) == list(range(n))
+
+
 def test_density_on_composite_grid_short_z_lines_vs_convolution_path(zd, ps):
     """PPD = 480 = 32 * 15 with ZD_qdensity = 1 at R = 8: z lines of 60 = 4 * 15, i.e. the generator's short walk (four z rows per
     thread, `k_genf<4, GENF_ZAFD>`) and the 4-element z transform with six fields — beyond the oracle's O(N^4) plain DFT, so the

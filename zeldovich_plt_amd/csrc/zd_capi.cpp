@@ -301,7 +301,9 @@ extern "C" {
 static bool dens_fields(const zd_params *p) {
     // (8640 = 64 * 135 included: the six-field store runs there too — tests/test_gpu_baseline_regime.py,
     // test_density_one_mode_at_every_composite_size[8640]; the PPD > 8192 gate's message says so)
-    return p->qdensity == 1 && !p->qPLT && p->f_NL == 0. && p->qoneslab < 0 && !is_pow2(p->ppd) && zd::np2_supported_ppd((int) p->ppd)
+    // (ZD_qdensity = 2, density only — round 5: the same six-field store, the displacement arrays are simply not built and no records
+    // are written; the four potentials ride along unused, which still beats the convolution path by ~4x)
+    return (p->qdensity == 1 || p->qdensity == 2) && !p->qPLT && p->f_NL == 0. && p->qoneslab < 0 && !is_pow2(p->ppd) && zd::np2_supported_ppd((int) p->ppd)
            && (p->store_mode == ZD_STORE_AUTO || p->store_mode == ZD_STORE_FIELDS);
 }
 // Packed stores (zd_device.h PACK_*): without ZD_qdensity the density field is not transformed.
@@ -741,7 +743,8 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
     pl->nranks  = nranks;
     pl->N       = (int) N;
     pl->half    = (int) (N / 2);
-    pl->narray  = (phi_mode == 1 || p->qdensity == 2) ? 1 : (p->qPLT ? 4 : 2);  // zeldovich.cpp:871-876
+    // (density only: one array — zeldovich.cpp:871-876 — except on the composite kernels, where it rides on the six-field ZA store)
+    pl->narray  = (phi_mode == 1 || (p->qdensity == 2 && (any_path || !dens_fields(p)))) ? 1 : (p->qPLT ? 4 : 2);
     if (phi_mode == 0 && phik == nullptr && pl->narray >= 2 && !any_path) pl->pack = pack_mode(p, R);
     pl->any = any_path;
     if (zd::pack_is_fields(pl->pack) && ((pl->half / nranks) % zd::FIELD_RB || N / R > 2048))  // row blocks of 8, z FFT <= 2048
@@ -762,6 +765,7 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
     }
     if (pl->pack != zd::PACK_NONE) pl->narray = 3;
     pl->dens    = pl->pack == zd::PACK_ZAFIELD && dens_fields(p) && np2;
+    pl->dens_only = pl->dens && p->qdensity == 2;  // density planes only: no displacement arrays, no records (src/output.cpp:94,207)
     if (pl->pack == zd::PACK_ZAFIELD && dens_fields(p) && !np2) {  // (cannot happen: dens_fields is composite-only)
         delete pl;
         return 1;
@@ -1602,16 +1606,18 @@ int zd_plan_stage_x_group(zd_plan *pl, int residue, const void *d_recv, int chun
             char *rec_g = d_records ? (char *) d_records + (size_t) g0 * ps * pl->N * pl->N * pl->ec.recsize : nullptr;
             const int z_first = (int) zd_plan_plane_z(pl, residue, gplane0 + (int64_t) g0 * ps);
             tick(pl, ZD_K_YFFT, st, true);
-            if (pl->d_twq_n ? zd::launch_yfft_fields_np2(F, pl->S, pl->d_twq_n, d_recv, p0 + g0, ng, pl->SR.pitch, pl->d_ring, 0, st)
-                            : zd::launch_yfft_fields(F, pl->S, pl->d_twN, d_recv, p0 + g0, ng, pl->SR.pitch, pl->d_ring, st))
+            if (!pl->dens_only
+                && (pl->d_twq_n ? zd::launch_yfft_fields_np2(F, pl->S, pl->d_twq_n, d_recv, p0 + g0, ng, pl->SR.pitch, pl->d_ring, 0, st)
+                                : zd::launch_yfft_fields(F, pl->S, pl->d_twN, d_recv, p0 + g0, ng, pl->SR.pitch, pl->d_ring, st)))
                 return 1;
             if (pl->dens && d_density
                 && zd::launch_yfft_fields_np2(F, pl->S, pl->d_twq_n, d_recv, p0 + g0, ng, pl->SR.pitch, pl->d_ring_dens, 1, st))
                 return 1;
             tick(pl, ZD_K_YFFT, st, false);
             tick(pl, ZD_K_XFFT, st, true);
-            if (pl->d_twq_n ? zd::launch_xfft_np2(pl->N, pl->ec, pl->d_twq_n, pl->d_ring, pl->SR.pitch, ng, z_first, pl->R, rec_g, pl->d_red, st)
-                            : zd::launch_xfft(pl->SR, pl->ec, pl->d_twN, pl->d_ring, 0, ng, z_first, pl->R, rec_g, nullptr, pl->d_red, st))
+            if (!pl->dens_only
+                && (pl->d_twq_n ? zd::launch_xfft_np2(pl->N, pl->ec, pl->d_twq_n, pl->d_ring, pl->SR.pitch, ng, z_first, pl->R, rec_g, pl->d_red, st)
+                                : zd::launch_xfft(pl->SR, pl->ec, pl->d_twN, pl->d_ring, 0, ng, z_first, pl->R, rec_g, nullptr, pl->d_red, st)))
                 return 1;
             if (pl->dens && d_density
                 && zd::launch_xdens_np2(pl->N, pl->d_twq_n, pl->d_ring_dens, pl->SR.pitch, ng, d_density + (size_t) g0 * ps * pl->N * pl->N, st))
@@ -1731,7 +1737,7 @@ int zd_generate(const zd_params *p_in, const zd_pk *pk, const double *eig, int64
     }
     const int R = pl->R, recsize = pl->ec.recsize, npass = pl->npass, pstep = pl->pstep;
     const int64_t Pp = zd_plan_local_planes(pl);  // planes delivered per pass
-    const bool want_rec = pl->narray >= 2, want_dens = p.qdensity != 0;
+    const bool want_rec = pl->narray >= 2 && !pl->dens_only, want_dens = p.qdensity != 0;
 
     // Delivery (WriteParticlesSlab's role, src/output.cpp:207-224) is asynchronous: NB = 2 record buffers on the device
     // and in pinned host memory; chunk i is produced into buffer i % 2 on the compute stream, copied D2H on a copy stream

@@ -1135,7 +1135,7 @@ int zd_generate_multi(const zd_params *p_in, const zd_pk *pk, const double *eig,
                     break;
                 }
                 const int ps = pl->pstep;
-                const bool want_rec = pl->narray >= 2, want_dens = p.qdensity != 0;  // ZD_qdensity = 2: density only
+                const bool want_rec = pl->narray >= 2 && !pl->dens_only, want_dens = p.qdensity != 0;  // ZD_qdensity = 2: density only
                 const size_t nn = (size_t) pl->N * pl->N;
                 const size_t plane_rec_b = want_rec ? nn * pl->ec.recsize : 0;
                 const int64_t ring_b = cb ? ((int64_t) 1 << 30) : ((int64_t) 4 << 30);

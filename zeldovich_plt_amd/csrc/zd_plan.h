@@ -31,6 +31,7 @@ struct zd_plan {
     zd::StoreLayout SR;             // the ring as a single-rank block store of 3 arrays
     zdfft::cplx *d_ring = nullptr;
     bool dens = false;              // ZD_qdensity = 1 on the six-field store (composite grids): fields 4, 5 = D of the two residues
+    bool dens_only = false;         // ZD_qdensity = 2 there: density planes only, no records
     zdfft::cplx *d_ring_dens = nullptr;  // ... and their array delta_r0 + i delta_r1 for the ring's planes
     int ring_planes = 0;
     int64_t store_bytes_ = 0;       // bytes of the send (= receive) buffer per pass
