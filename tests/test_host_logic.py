@@ -64,8 +64,9 @@ def test_stream_factor_for_any_even_ppd(zd):
     assert R(1001, 250 * GB) == -1         # odd PPD: the reference requires an even one too
     assert R(1000, 250 * GB, nranks=2) == -1
     assert R(1000, 250 * GB, qPLT=1) == 1 and R(1000, 250 * GB, qdensity=2) == 1
-    assert R(96, 250 * GB) == 2 and R(96, 250 * GB, qdensity=1) == 2 and R(96, 250 * GB, qdensity=2) == 1   # composite kernels (ZA, also
-    # with a density since round 4) / convolution kernels (density only)
+    assert R(96, 250 * GB) == 2 and R(96, 250 * GB, qdensity=1) == 2 and R(96, 250 * GB, qdensity=2) == 2   # composite kernels (ZA, also
+    # with a density since round 4, density only since round 5: the six-field store) ...
+    assert R(96, 250 * GB, qdensity=2, qPLT=1) == 1  # ... PLT with a density: convolution kernels (reference arrays)
     assert R(1000, 250 * GB, f_NL=1.0, n_s=0.96, Omega_M=0.3) == 1
     # radix-7 composite grids (round 4): 7168 = 1024 * 7 with z lines of 112 = 16 * 7; 3584 = 512 * 7, z lines of 448; 4320 = 32 * 135
     # has no z kernel of 16 * 135 (1080 threads): z lines of 432 = 16 * 27
@@ -198,9 +199,12 @@ def test_stream_factor_chooser(zd):
     pc, pcd = zd.make_params(3456), zd.make_params(3456, qdensity=1)
     assert L.zd_choose_stream_factor(C.byref(pc), 1, 256 * GB) == 4
     assert L.zd_choose_stream_factor(C.byref(pcd), 1, 256 * GB) == 6
-    # ZD_qdensity = 2 (density only) and PLT with a density stay on the convolution path: one array / four arrays, any divisor
+    # ZD_qdensity = 2 (density only): the same six-field store since round 5 (only its density array is built); PLT with a density stays
+    # on the convolution path (four reference arrays, any divisor)
     pc2 = zd.make_params(3456, qdensity=2)
-    assert L.zd_choose_stream_factor(C.byref(pc2), 1, 256 * GB) == 3
+    assert L.zd_choose_stream_factor(C.byref(pc2), 1, 256 * GB) == 6
+    pc3 = zd.make_params(3456, qdensity=1, qPLT=1)
+    assert L.zd_choose_stream_factor(C.byref(pc3), 1, 256 * GB) not in (-1, 4, 6)
 
 
 # ---- host emulation of the device FFT engine -------------------------------------------------------
