@@ -73,6 +73,10 @@ CASES = [
     (1024, dict(k_cutoff=2.0), [1, 766]),                       # pruned columns, kmax = 256: dead pairs inside live waves
     (1024, dict(corner_modes=1), [2, 1023]),                     # no sphere: every wave of every column live
     (2048, dict(qPLTrescale=1, PLT_target_z=5.0, z_initial=49.0), [0, 1, 1030, 2047]),
+    # z lines of 512 points (half a wave per line): PPD = 512 (BASELINE C2's size: also compared with the ORACLE record by record,
+    # tests/test_gpu_baseline_regime.py::test_ppd512_plt_vs_oracle) and PPD = 1024 at R = 2
+    (512, dict(qPLTrescale=1, PLT_target_z=5.0, z_initial=49.0), [0, 2, 255, 511]),
+    (1024, dict(stream_factor=2, qPLTrescale=1, PLT_target_z=5.0, z_initial=49.0), [1, 514, 1023]),
 ]
 
 

@@ -38,6 +38,9 @@ EXPECTED = [
     ("2048 PLT fused", "launch_gen_z", "ZR = 16, NJ = 6, PLT = true, PLAW = false"),
     ("2048 PLT fused", "launch_xfft_q2_plt_t", "N = 2048, E = 16"),
     ("1024 PLT fused", "launch_xfft_q2_plt_t", "N = 1024, E = 16"),
+    ("512 PLT fused (BASELINE C2)", "launch_genz_t", "L = 512, R = 1, PLAW = false"),
+    ("512 PLT fused (BASELINE C2)", "launch_xfft_q2_plt_t", "N = 512, E = 16"),
+    ("1024 PLT fused at R = 2", "launch_genz_t", "L = 512, R = 2, PLAW = false"),
     # ... and the two-kernel stage on plain rows (ZD_StoreMode = packed, several ranks, options the fused kernel leaves alone)
     ("2048 PLT", "launch_genf_z", "ZR = 16, KIND = 4, PLAW = false"),
     ("2048 PLT", "launch_eig_lines", ""),

@@ -1067,7 +1067,7 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         int row_pad = store_row_pad(pl->N);  // in complex elements
         if (const char *env = tune_env("ZD_PAD")) sscanf(env, "%d", &row_pad);
         // Fused Z stage of the packed PLT store (zd_kernels_fz.hip: generator + z FFT in one kernel, the folded inputs stay on the
-        // CU): one rank, z lines of 1024 points (PPD = 1024, or 2048 = BASELINE C3 at R = 2), the table generator's arithmetic,
+        // CU): one rank, z lines of 1024 or 512 points (PPD = 512 = BASELINE C2, 1024, or 2048 = BASELINE C3 at R = 2), the table generator's arithmetic,
         // version-2 streams, the whole field; and the kz = N/2 plane must be dead (the kernel never draws it: true unless
         // CornerModes is set together with ZD_k_cutoff != 1).  ZD_StoreMode = packed keeps the two-kernel stage (A/B runs).
         // Its store interleaves 4 planes along x (StoreLayout::lq = 2) so that a lane's 4 neighbours — 4 consecutive planes of

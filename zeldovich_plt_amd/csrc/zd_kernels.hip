@@ -1521,7 +1521,7 @@ __global__ __launch_bounds__(W *N / E, MINW) void k_yfft(StoreLayout S, const cp
         // with the two columns of a plane side by side — [plane][column] instead of [column][plane] — so that the x stage, which
         // transforms the lines of a plane PAIR, reads 64 contiguous bytes per column pair (whole sectors) instead of 32 of every 64
         unsigned xs = xb;
-        if (S.lq == 2 && W == 8) xs = (unsigned) ((xq & ~7) + ((w & 3) << 1) + (w >> 2)) * 16u;
+        if (S.lq == 2 && W % 8 == 0) xs = (unsigned) ((xq & ~7) + ((w & 3) << 1) + ((w >> 2) & 1)) * 16u;  // (W = 16: two such lines per row)
 #pragma unroll
         for (int e = 0; e < E; e++) {
             const int y = t2 + T * e;
@@ -2861,9 +2861,9 @@ static int launch_yfft_t(const StoreLayout &S, int nplanes, const void *tw, void
     const size_t shmem = sizeof(double) * zdfft::ColsInner<N, W>::SIZE;
     set_dyn_lds<k_yfft<N, E, W, 1, false>>(shmem);
     set_dyn_lds<k_yfft<N, E, W, 1, true>>(shmem);
-    // (lq = 2 with W = 8 only: the tile is then one 128-byte line per row, which the kernel writes back [plane][column] — the order
-    // k_xfft_q2_plt reads)
-    if (S.lq && (S.lq != 2 || W != 8 || !S.one_block || nplanes % (1 << S.lq) || (unsigned long long) S.pitch * N * 16ull >= (1ull << 32))) {
+    // (lq = 2 with W a multiple of 8 only: the tile is then whole 128-byte lines per row, which the kernel writes back
+    // [plane][column] — the order k_xfft_q2_plt reads)
+    if (S.lq && (S.lq != 2 || W % 8 != 0 || !S.one_block || nplanes % (1 << S.lq) || (unsigned long long) S.pitch * N * 16ull >= (1ull << 32))) {
         fprintf(stderr, "zeldovich_hip: plane-interleaved rows need the single-rank store and whole plane groups\n");
         return 2;
     }
@@ -3110,6 +3110,7 @@ int launch_xfft(const StoreLayout &S, const EpiConst &ec, const void *tw, const 
         if (S.lq == 2 && S.one_block && S.narray == 3 && ec.pack == PACK_PLT3 && !density) {
             if (S.N == 2048) return launch_xfft_q2_plt_t<2048, 16>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, red, st);
             if (S.N == 1024) return launch_xfft_q2_plt_t<1024, 16>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, red, st);
+            if (S.N == 512) return launch_xfft_q2_plt_t<512, 16>(S, ec, tw, data, plane0, nplanes, z_first, z_step, records, red, st);
         }
         fprintf(stderr, "zeldovich_hip: no x pass for plane-interleaved rows at PPD %d\n", S.N);
         return 2;

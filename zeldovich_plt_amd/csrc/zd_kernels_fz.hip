@@ -65,7 +65,8 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// zdfft::fft_line for a line owned by ONE wave (PL::T == 64): the same passes, the exchanges without workgroup barriers
+// zdfft::fft_line for a line owned by ONE wave (PL::T == 64) or by half a wave (PL::T == 32: the two halves run the same instructions on
+// their own lines and exchange areas): the same passes, the exchanges without workgroup barriers
 template <class PL, class XL, int P = 0>
 __device__ __forceinline__ void fft_line_wave(double (&re)[PL::E], double (&im)[PL::E], int t, double *lds, const cplx *__restrict__ tw) {
     zdfft::pass_compute<PL, P>(re, im, t, tw);
@@ -104,17 +105,19 @@ __device__ __forceinline__ void eig_yz_blend(const GenConst &g, int cx, const Ei
 
 }  // namespace
 
-// grid: persistent, one workgroup per CU (the staged lines + the generator's table image are 118 KB of LDS)   block: L / 2
+// grid: persistent, one workgroup per CU at L = 1024 (the staged lines + the generator's table image are 118 KB of LDS), two at
+// L = 512   block: L / 2
 template <int L, int R, bool PLAW>
 __global__ __launch_bounds__(L / 2) void k_genz_plt(GenConst g, StoreLayout S, int ky0, int residue, unsigned nitems,
                                                    const FzItem *__restrict__ items, const cplx *__restrict__ twN,
                                                    const cplx *__restrict__ twL, cplx *__restrict__ out,
                                                    unsigned *__restrict__ ctr) {
-    static_assert(L == 1024 && (R == 1 || R == 2), "one wave per 1024-point line; one or two fold terms");
+    static_assert((L == 1024 || L == 512) && (R == 1 || R == 2), "a wave per 1024-point line, half a wave per 512-point line; one or two fold terms");
     constexpr int NT = L / 2, E = 16, NJOB = 6;
     using PL = zdfft::Plan<L, E>;
     using XL = zdfft::LineInner<L, 1>;
-    static_assert(PL::T == 64, "a line is one wave");
+    constexpr int TL = PL::T, LPW = 64 / TL;  // threads per line, lines per wave
+    static_assert(TL == 64 || TL == 32, "a line is a wave or half a wave");
     extern __shared__ __attribute__((aligned(16))) double T[];  // GenfTab image | work-item slot | staged lines [job][k2]
     for (int i = threadIdx.x; i < g.genf_n / 2; i += NT) reinterpret_cast<double2 *>(T)[i] = reinterpret_cast<const double2 *>(g.genf_tab)[i];
     unsigned *slot = reinterpret_cast<unsigned *>(T + g.genf_n);
@@ -122,10 +125,11 @@ __global__ __launch_bounds__(L / 2) void k_genz_plt(GenConst g, StoreLayout S, i
     // twiddles in LDS: the steady-state loop then has NO vector-memory loads — on gfx9 loads and stores share one in-order counter
     // (vmcnt), so a load issued behind the column's 16 line stores waits for every one of them, and the stores, which should
     // drain behind the next column's arithmetic, were 48 of the stage's 162 ms (profiles/r05_tuning_notes.md).
-    //   twl[m] = exp(2 pi i m / L), m < L/4: all the inter-pass twiddles a 16 x 16 x 4 transform of L = 1024 points asks for
+    //   twl[m] = exp(2 pi i m / L), m < 256: all the inter-pass twiddles a 16 x 16 x 4 (L = 1024) or 16 x 16 x 2 (L = 512) transform asks for
     //   twn[t] = exp(2 pi i t / N), t < L/2: the final factor W_N^{k2 residue} of line element k2 = t (element L - t: -conj)
-    cplx *twl = stage + NJOB * L, *twn = twl + L / 4;
-    for (int i = threadIdx.x; i < L / 4; i += NT) twl[i] = twL[i];
+    constexpr int NTWL = 256;
+    cplx *twl = stage + NJOB * L, *twn = twl + NTWL;
+    for (int i = threadIdx.x; i < NTWL; i += NT) twl[i] = twL[i];
     for (int i = threadIdx.x; i < L / 2; i += NT) twn[i] = twN[i];
     const int N = g.N, half = g.half;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
@@ -311,30 +315,31 @@ __global__ __launch_bounds__(L / 2) void k_genz_plt(GenConst g, StoreLayout S, i
                 }
             }
             __syncthreads();
-            // ---- waves 0..5: one job line each — transform, Hermitian store ----
-            if (wave < NJOB) {
+            // ---- the first 6 / LPW waves: one job line per wave (L = 1024) or per half wave (L = 512) — transform, Hermitian store ----
+            if (wave < NJOB / LPW) {
                 double re[E], im[E];
-                const cplx *line = stage + wave * L;
+                const int jl = wave * LPW + lane / TL, tl = lane % TL;  // job line, thread of the line
+                const cplx *line = stage + jl * L;
 #pragma unroll
                 for (int e = 0; e < E; e++) {
-                    const cplx v = line[lane + 64 * e];
+                    const cplx v = line[tl + TL * e];
                     re[e] = v.x;
                     im[e] = v.y;
                 }
-                wave_lds_sync();  // the line is in registers: its area now serves this wave's exchanges
-                int l3 = lane;
+                wave_lds_sync();  // the line is in registers: its area now serves its threads' exchanges
+                int l3 = tl;
                 asm volatile("" : "+v"(l3));  // (the transform's LDS addresses are formed per column, not carried — and spilled — across the loop)
-                if (!ZD_TUNE(S.prune & 128)) fft_line_wave<PL, XL>(re, im, l3, reinterpret_cast<double *>(stage + wave * L), twl);  // bit 7: ablation
+                if (!ZD_TUNE(S.prune & 128)) fft_line_wave<PL, XL>(re, im, l3, reinterpret_cast<double *>(stage + jl * L), twl);  // bit 7: ablation
                 if (ZD_TUNE(S.prune & 16) && re[0] != 123.456) continue;  // bit 4: tuning ablation (no stores)
-                const int arr = wave >> 1, twin = wave & 1;
+                const int arr = jl >> 1, twin = jl & 1;
                 const int sl = twin ? S.Hq + kyl : kyl;
                 const int xs = twin ? ((N - x) & (N - 1)) : x;
                 const double sgi = twin ? -1.0 : 1.0;  // twin jobs are stored conjugated
-                int l2 = lane;
+                int l2 = tl;
                 asm volatile("" : "+v"(l2));  // keep the address arithmetic behind the transform (registers)
 #pragma unroll
                 for (int e = 0; e < E; e++) {
-                    const int z2 = l2 + 64 * e;
+                    const int z2 = l2 + TL * e;
                     out[store_elem(S, 0, z2, arr, sl, xs)] = cplx{re[e], sgi * im[e]};
                 }
             }
@@ -349,10 +354,10 @@ __global__ __launch_bounds__(L / 2) void k_genz_plt(GenConst g, StoreLayout S, i
 
 namespace zd {
 
-bool genz_plt_supported(int N, int L) { return L == 1024 && (N == L || N == 2 * L); }
+bool genz_plt_supported(int N, int L) { return (L == 1024 || L == 512) && (N == L || N == 2 * L); }
 
 size_t genz_plt_lds_bytes(const GenConst &g, int L) {  // table image + slot | 6 staged lines | twl[L/4] | twn[L/2]
-    return sizeof(double) * (size_t) ((g.genf_n + 3) & ~1) + sizeof(cplx) * (6 * (size_t) L + L / 4 + L / 2);
+    return sizeof(double) * (size_t) ((g.genf_n + 3) & ~1) + sizeof(cplx) * (6 * (size_t) L + 256 + L / 2);
 }
 
 template <int L, int R, bool PLAW>
@@ -360,7 +365,7 @@ static int launch_genz_t(const GenConst &g, const StoreLayout &S, int ky0, int r
                          const void *twN, const void *twL, void *out, unsigned *ctr, int ncu, hipStream_t st) {
     const size_t shmem = genz_plt_lds_bytes(g, L);
     set_dyn_lds<k_genz_plt<L, R, PLAW>>(shmem);
-    dim3 grid((unsigned) std::min<long long>(nitems, ncu)), block(L / 2);
+    dim3 grid((unsigned) std::min<long long>(nitems, (long long) ncu * (L == 512 ? 2 : 1))), block(L / 2);
     hipLaunchKernelGGL((k_genz_plt<L, R, PLAW>), grid, block, shmem, st, g, S, ky0, residue, nitems, items, (const cplx *) twN,
                        (const cplx *) twL, (cplx *) out, ctr);
     ZD_LAUNCH_CHECK();
@@ -379,6 +384,8 @@ int launch_genz_plt(const GenConst &g, const StoreLayout &S, int ky0, int L, int
                              : launch_genz_t<l, r, false>(g, S, ky0, residue, nitems, items, twN, twL, out, ctr, ncu, st);
     GZ(1024, 1)
     GZ(1024, 2)
+    GZ(512, 1)
+    GZ(512, 2)
 #undef GZ
     return 2;
 }
