@@ -112,8 +112,9 @@ def test_fused_z_stage_power_law_and_fixed_amplitudes(zd, oracle):
 
 
 def test_options_the_fused_kernel_does_not_take_keep_the_two_kernel_stage(zd, oracle):
-    """CornerModes with ZD_k_cutoff = 2 (the kz = N/2 plane is live: the fused kernel never draws it), the one-mode filter, several
-    ranks and ZD_StoreMode = packed run on plain rows as before — and give the records of the default run where both exist"""
+    """CornerModes with ZD_k_cutoff = 2 (the kz = N/2 plane is live: the fused kernel never draws it), several ranks and
+    ZD_StoreMode = packed run on plain rows as before.  (The one-mode filter IS taken by the fused kernel: the closed-form one-mode
+    runs at PPD = 2048 PLT + rescale, tests/test_gpu_baseline_regime.py::test_large_plt_plane_waves_and_stream_invariance, go through it.)"""
     ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
     eig = oracle.synthetic_eigenmodes(128)
     import zeldovich_plt_amd.api as api
@@ -128,3 +129,12 @@ def test_options_the_fused_kernel_does_not_take_keep_the_two_kernel_stage(zd, or
     plan = zd.Plan(p, ps, eig=eig, rank=0, nranks=2)  # two ranks: the exchange addresses plain rows
     plan.close()
     assert launches() == n0
+    # ... and the one-mode filter through the fused kernel against the two-kernel stage: one live mode per pair, with its mirror zeroed
+    for mode in ((3, 5, 7), (-9, 1, -2), (5, 2, 0), (17, 100, -400)):
+        kw = dict(qonemode=1, one_mode=mode, qPLTrescale=1, PLT_target_z=5.0, z_initial=49.0)
+        a, _ = _planes(zd, ps, eig, 1024, [4, 600], **kw)
+        b, _ = _planes(zd, ps, eig, 1024, [4, 600], store_mode="packed", **kw)
+        for z in (4, 600):
+            scale = np.abs(b[z]["d"]).max()
+            assert scale > 0 and np.abs(a[z]["d"] - b[z]["d"]).max() <= 1e-12 * scale and np.abs(a[z]["v"] - b[z]["v"]).max() <= 1e-12 * scale, mode
+    assert launches() > n0

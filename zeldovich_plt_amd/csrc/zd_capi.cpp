@@ -1073,7 +1073,7 @@ static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig
         // Its store interleaves 4 planes along x (StoreLayout::lq = 2) so that a lane's 4 neighbours — 4 consecutive planes of
         // ONE column — write a 64-byte run.
         pl->fused_z = pl->pack == zd::PACK_PLT3 && p->store_mode == ZD_STORE_AUTO && S.one_block && zd::genz_plt_supported(pl->N, pl->L)
-                      && g.genf_tab && !v1 && !p->qonemode && p->qoneslab < 0 && phi_mode == 0 && phik == nullptr && p->k_cutoff >= 1.0
+                      && g.genf_tab && !v1 && p->qoneslab < 0 && phi_mode == 0 && phik == nullptr && p->k_cutoff >= 1.0
                       && (g.kmax == pl->half || !p->corner_modes) && (S.prune & 7) == 7 && !tune_env("ZD_NO_FUSED_Z");
         S.lq         = pl->fused_z ? 2 : 0;
         // (the pad that spreads the y stage's strided rows over the HBM channels: 24 elements per plain row; per plane row of an

@@ -219,6 +219,10 @@ __global__ __launch_bounds__(L / 2) void k_genz_plt(GenConst g, StoreLayout S, i
             for (int p = 0; p < R; p++) {
                 const int kz = a[p], k2i = kxy2 + kz * kz;
                 const bool live = !dead_xy && kz != g.kmax && (g.corner_modes || k2i < g.k2i_cut);
+                // ZD_qonemode (zeldovich.cpp:354-356): only the mode one_mode survives — the two modes of a pair then differ
+                const bool om = g.qonemode != 0, omxy = kx == g.one_mode[0] && ky == g.one_mode[1];
+                const bool liveP = live && (!om || (omxy && kz == g.one_mode[2]));
+                const bool liveM = live && (!om || (omxy && -kz == g.one_mode[2]));
                 // the four draws; the generators move on to the next column
                 const uint64_t p1 = zdpcg::output(sp[p]);
                 u128 s2 = zdpcg::step(sp[p]);
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(L / 2) void k_genz_plt(GenConst g, StoreLayout S, i
                 const uint64_t m2 = zdpcg::output(s2);
                 sm[p] = zdpcg::step(s2);
                 double vPr[NJOB], vPi[NJOB], vMr[NJOB], vMi[NJOB];
-                const bool any = __any(live) && !ZD_TUNE(S.prune & 8);  // all 64 pairs of the wave zeroed? (bit 3: tuning ablation — draws only)
+                const bool any = __any(liveP || liveM) && !ZD_TUNE(S.prune & 8);  // all 64 pairs of the wave zeroed? (bit 3: tuning ablation — draws only)
                 if (any) {
                     // ---- shared by the pair: P(k), eigenmode, f, rescale ----
                     const double k2v = (double) k2i * g.fundamental2;
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(L / 2) void k_genz_plt(GenConst g, StoreLayout S, i
                         const uint64_t u = p1 + 1ULL;  // one_rand<2>: (r + 1) 2^-64, and 1.0 for r = 2^64 - 1 (u = 0)
                         double v = P;
                         if (!g.fixed_power) v = -P * flog(u64_to_double(u), 64, T);
-                        v = (u == 0 && !g.fixed_power) || !live ? 0.0 : v;
+                        v = (u == 0 && !g.fixed_power) || !liveP ? 0.0 : v;
                         const double amp = sqrt_pos(v);
                         double sn, cs;
                         sincos_u01(u64_to_double(p2 + 1ULL), T, sn, cs);
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(L / 2) void k_genz_plt(GenConst g, StoreLayout S, i
                         const uint64_t u = m1 + 1ULL;
                         double v = P;
                         if (!g.fixed_power) v = -P * flog(u64_to_double(u), 64, T);
-                        v = (u == 0 && !g.fixed_power) || !live || (p == 0 && !has_m0) ? 0.0 : v;
+                        v = (u == 0 && !g.fixed_power) || !liveM || (p == 0 && !has_m0) ? 0.0 : v;
                         const double amp = sqrt_pos(v);
                         double sn, cs;
                         sincos_u01(u64_to_double(m2 + 1ULL), T, sn, cs);
