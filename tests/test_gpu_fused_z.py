@@ -23,6 +23,14 @@ def zd():
 
 
 _STORE = {"t": None}
+_EIG = {}
+
+
+def _eig128(oracle):
+    """the synthetic 128^3 eigenmode table (0.8 s of numpy per call: made once per module)"""
+    if "t" not in _EIG:
+        _EIG["t"] = oracle.synthetic_eigenmodes(128)
+    return _EIG["t"]
 
 
 def _planes(zd, ps, eig, n, zs, **kw):
@@ -83,7 +91,7 @@ CASES = [
 @pytest.mark.parametrize("n,kw,zs", CASES)
 def test_fused_z_stage_equals_the_two_kernel_stage(zd, oracle, n, kw, zs):
     ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
-    eig = oracle.synthetic_eigenmodes(128)
+    eig = _eig128(oracle)
     a, ia = _planes(zd, ps, eig, n, zs, **kw)
     b, ib = _planes(zd, ps, eig, n, zs, store_mode="packed", **kw)
     import zeldovich_plt_amd.api as api
@@ -102,7 +110,7 @@ def test_fused_z_stage_equals_the_two_kernel_stage(zd, oracle, n, kw, zs):
 
 def test_fused_z_stage_power_law_and_fixed_amplitudes(zd, oracle):
     """the PLAW instantiation and ZD_qPk_fix_to_mean through the fused kernel"""
-    eig = oracle.synthetic_eigenmodes(128)
+    eig = _eig128(oracle)
     for ps in (zd.PowerSpectrum.from_powerlaw(-1.5, 720.0), zd.PowerSpectrum.from_file(WMAP, 720.0, fix_to_mean=1)):
         a, _ = _planes(zd, ps, eig, 1024, [5, 900])
         b, _ = _planes(zd, ps, eig, 1024, [5, 900], store_mode="packed")
@@ -116,7 +124,7 @@ def test_options_the_fused_kernel_does_not_take_keep_the_two_kernel_stage(zd, or
     ZD_StoreMode = packed run on plain rows as before.  (The one-mode filter IS taken by the fused kernel: the closed-form one-mode
     runs at PPD = 2048 PLT + rescale, tests/test_gpu_baseline_regime.py::test_large_plt_plane_waves_and_stream_invariance, go through it.)"""
     ps = zd.PowerSpectrum.from_file(WMAP, 720.0)
-    eig = oracle.synthetic_eigenmodes(128)
+    eig = _eig128(oracle)
     import zeldovich_plt_amd.api as api
 
     def launches():
