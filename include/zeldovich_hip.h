@@ -29,7 +29,7 @@ enum { ZD_FMT_ZEL = 0, ZD_FMT_RVZEL = 1, ZD_FMT_RVDOUBLEZEL = 2, ZD_FMT_ZELSIMPL
  * quantities of Parameters::setup (src/parameters.cpp:172-174) already filled in. */
 typedef struct zd_params {
     int64_t ppd;        /* cbrt(NP): a power of two in [32, 16384] (above 8192: ZA field store only; 8192 with PLT: its field store only, i.e. no ZD_qdensity / ZD_f_NL), or 2^a Q with a >= 5 and Q one of 3, 9, 27, 5, 15,
-                         * 25, 45, 75, 125, 135, 7, 21, 35, 49 (sizes: csrc/zd_kernels_np2.hip NP2_SIZES; the composite-transform kernels: ZA also with ZD_qdensity = 1 or 2, PLT without a density), or ANY other even number in [8, 8192]
+                         * 25, 45, 75, 125, 135, 7, 21, 35, 49 (sizes: csrc/zd_kernels_np2.hip NP2_SIZES; the composite-transform kernels: ZA and PLT, also with ZD_qdensity = 1 or 2 — PLT with a density on one rank per pass group), or ANY other even number in [8, 8192]
                          * (one rank: convolution transforms on the power-of-two engine, ~6x slower) */
     int32_t numblock;   /* ZD_NumBlock: v2 output does not depend on it; version 1: PPD / numblock random streams */
     int32_t cpd;        /* CPD: only used by the writer for ic_{z*cpd/ppd} */

@@ -876,6 +876,43 @@ def test_density_only_on_composite_grids_vs_oracle(zd, oracle, ps, opk, n, kw):
     assert sorted(got["planes_seen"]) == list(range(n))
 
 
+@pytest.mark.parametrize("n,kw", [
+    (96, dict(stream_factor=1)),                                   # 32 * 3: z lines of 96, the density half at 2 x 48
+    (160, dict(stream_factor=1, qPLTrescale=1)),                   # 32 * 5
+    (224, dict(stream_factor=1)),                                  # 32 * 7
+    (192, dict(stream_factor=2, qPLTrescale=1)),                   # two passes, each with its own density-only pass (R = 4) in front
+    (192, dict()),                                                 # stream factor left to the library
+    (192, dict(stream_factor=2, ngpu=2, pass_groups=2)),           # two GPUs, one pass each: every rank composes its own pass
+])
+def test_plt_with_density_on_composite_grids_vs_oracle(zd, oracle, ps, opk, n, kw):
+    """ZD_qPLT with ZD_qdensity = 1 on the composite kernels (round 5; before: the ~6x slower convolution path): the PLT
+    field store has no density field, so every pass is preceded by a density-only pass of the six-field ZA store at twice the
+    stream factor — the same planes — on the same store (`plan_create_ex`, `plt_dens_split`).  Records, density planes, density_variance and
+    max_disp against the oracle."""
+    eig = oracle.synthetic_eigenmodes(32)
+    kw = dict(kw)
+    if kw.get("qPLTrescale"):
+        kw.update(PLT_target_z=5.0, z_initial=49.0)
+    plan = zd.Plan(zd.make_params(n, qPLT=1, qdensity=1, **{k: v for k, v in kw.items() if k not in ("ngpu", "pass_groups")}), ps, eig=eig)
+    if kw.get("stream_factor"):
+        assert plan.store_mode == "fields"  # the composite PLT field store, not the convolution path's reference arrays
+    plan.close()
+    got, ref = _compare(zd, oracle, ps, opk, n, eig=eig, qPLT=1, qdensity=1, **kw)
+    assert got["records"] is not None and got["density"] is not None and np.abs(ref["density"]).max() > 0
+    assert sorted(got["planes_seen"]) == list(range(n))
+
+
+def test_density_only_ignores_plt_on_composite_grids(zd, oracle, ps, opk):
+    """ZD_qdensity = 2 with ZD_qPLT set: the displacement arrays are never built (src/zeldovich.cpp:303,440), so the run is the ZA
+    density-only run — on the composite kernels too (it used to fall to the convolution path because of the PLT flag)"""
+    eig = oracle.synthetic_eigenmodes(32)
+    plan = zd.Plan(zd.make_params(160, qPLT=1, qdensity=2, stream_factor=2), ps, eig=eig)
+    assert plan.store_mode == "fields"
+    plan.close()
+    got, ref = _compare(zd, oracle, ps, opk, 160, eig=eig, qPLT=1, qdensity=2, stream_factor=2)
+    assert got["records"] is None and got["density"] is not None
+
+
 def test_density_on_composite_grid_short_z_lines_vs_convolution_path(zd, ps):
     """PPD = 480 = 32 * 15 with ZD_qdensity = 1 at R = 8: z lines of 60 = 4 * 15, i.e. the generator's short walk (four z rows per
     thread, `k_genf<4, GENF_ZAFD>`) and the 4-element z transform with six fields — beyond the oracle's O(N^4) plain DFT, so the

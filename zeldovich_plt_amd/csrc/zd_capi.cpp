@@ -296,8 +296,8 @@ extern "C" {
 
 // ZD_qdensity = 1 on the composite grids (PPD = 2^a 3^b 5^c 7^d; round 4): the ZA field store carries two more half-space sums — the
 // density D of the two residues of a pass — and the y / x stages add one array, delta_r0 + i delta_r1 (zd_kernels_np2.hip).  The
-// power-of-two grids keep the reference's arrays for ZD_qdensity (their kernels exist); ZD_qdensity = 2 (density only), PLT and
-// f_NL with a density stay on the convolution path for composite PPDs.
+// power-of-two grids keep the reference's arrays for ZD_qdensity (their kernels exist).  PLT with ZD_qdensity = 1 on a composite grid
+// is composed of a PLT run and density-only passes of this store (plt_dens_split); f_NL stays on the convolution path there.
 static bool dens_fields(const zd_params *p) {
     // (8640 = 64 * 135 included: the six-field store runs there too — tests/test_gpu_baseline_regime.py,
     // test_density_one_mode_at_every_composite_size[8640]; the PPD > 8192 gate's message says so)
@@ -416,7 +416,59 @@ static bool np2_stream_factor_ok(int64_t N, int R) {
     return R >= 1 && (R == 1 || R % 2 == 0) && N % R == 0 && zd::np2_supported_zlen((int) (N / R));
 }
 
-int zd_choose_stream_factor(const zd_params *p, int nranks, int64_t budget_bytes) {
+// ZD_qdensity = 2 (density only): the displacement arrays are never built (src/zeldovich.cpp:303,440), so the eigenmodes of ZD_qPLT
+// never enter — the run IS the ZA density-only run, on every grid and path
+static zd_params canonical(const zd_params *p) {
+    zd_params c = *p;
+    if (c.qdensity == 2) c.qPLT = c.qPLTrescale = 0;
+    return c;
+}
+
+// PLT with ZD_qdensity = 1 on the composite grids, one rank (round 5): the PLT field store has no density field and its paired
+// generator no registers for a seventh pair of sums, so the density planes come from a second plan — density only, ZA six-field
+// store (dens_only) — at stream factor 2R: its pass j holds the residues j and j + R, i.e. exactly the planes z = j (mod R) of this
+// plan's pass j, in the same delivery order.  It runs at the head of the Z stage on the same store (which the PLT pass then
+// overwrites) and leaves N/R planes of float32 behind.  Before: the ~6x slower convolution path.
+static bool plt_dens_split(const zd_params *p, int nranks) {
+    return p->qPLT && p->qdensity == 1 && p->f_NL == 0. && p->qoneslab < 0 && nranks == 1 && !is_pow2(p->ppd)
+           && zd::np2_supported_ppd((int) p->ppd) && (p->store_mode == ZD_STORE_AUTO || p->store_mode == ZD_STORE_FIELDS)
+           && !tune_env("ZD_NO_DENS_SPLIT");
+}
+// (the two halves of such a run)
+static zd_params split_plt_half(const zd_params *p) {
+    zd_params a = *p;
+    a.qdensity  = 0;
+    return a;
+}
+static zd_params split_dens_half(const zd_params *p, int R) {
+    zd_params b     = *p;
+    b.qPLT          = 0;
+    b.qPLTrescale   = 0;
+    b.qdensity      = 2;
+    b.stream_factor = 2 * R;
+    return b;
+}
+
+static int choose_stream_factor_one(const zd_params *p, int nranks, int64_t budget_bytes);
+int zd_choose_stream_factor(const zd_params *p_in, int nranks, int64_t budget_bytes) {
+    const zd_params pc = canonical(p_in);
+    if (plt_dens_split(&pc, nranks)) {
+        // the PLT half's own choice, with room for what the density half adds: N/R planes of float32, its two rings (3 + 1 arrays of
+        // <= 6 GB / 3) and its tables; both R and 2R must have z lines the composite kernels transform
+        const zd_params pa = split_plt_half(&pc);
+        const int64_t N = pc.ppd;
+        for (int R = 1; N / R >= 24; R = R == 1 ? 2 : R + 2) {
+            if (!np2_stream_factor_ok(N, R) || !np2_stream_factor_ok(N, 2 * R) || N / R > 2048) continue;
+            if (!zd::pack_is_fields(pack_mode(&pa, R)) || (N / 2) % zd::FIELD_RB) break;
+            const int64_t ring = (int64_t) field_ring_planes(N, N / R) * N * (N + store_row_pad(N)) * 16;
+            const int64_t need = store_bytes(&pa, R, 1) + 3 * ring                                             // the PLT half
+                                 + (N / R) * N * N * 4 + 4 * ring + ((int64_t) 1 << 30);                       // + the density half
+            if (need <= budget_bytes) return R;
+        }
+    }
+    return choose_stream_factor_one(&pc, nranks, budget_bytes);
+}
+static int choose_stream_factor_one(const zd_params *p, int nranks, int64_t budget_bytes) {
     const int64_t N = p->ppd;
     // ZA without density: two residues share a pass, so R = 2 is preferred over R = 1 whenever the z FFT is long enough
     int R0 = 1;
@@ -464,7 +516,8 @@ static int plan_plane_step(const zd_params *p, int R, int nranks) {
     return (pm == zd::PACK_ZAPAIR || pm == zd::PACK_ZAFIELD) ? 2 : 1;
 }
 
-int zd_choose_pass_groups(const zd_params *p, int ngpu, int64_t budget_bytes, int32_t *groups, int32_t *stream_factor) {
+int zd_choose_pass_groups(const zd_params *p_in, int ngpu, int64_t budget_bytes, int32_t *groups, int32_t *stream_factor) {
+    const zd_params pc = canonical(p_in), *p = &pc;
     if (ngpu < 1) ngpu = 1;
     int g = p->pass_groups;
     if (g < 0 || (g > 0 && ngpu % g)) {
@@ -540,8 +593,9 @@ int zd_choose_pass_groups(const zd_params *p, int ngpu, int64_t budget_bytes, in
 //   all-to-all:   T = t_z / P' + max(t_ex, t_xy + t_z (P' - 1) / P') + 0.05 t_xy      t_z = (c_gen P' + c_zf) N^3 / G, t_xy = c_xy N^3 / G,
 //                                                                                     t_ex = store bytes per rank and pass x P' / G / rate
 // (first Z stage exposed, the others and the XY stages beside the exchange, the last plane group's XY behind it; P' = 1: t_z + max).
-int zd_choose_pass_groups_measured(const zd_params *p, int ngpu, int64_t budget_bytes, double link_GBps, int32_t *groups,
+int zd_choose_pass_groups_measured(const zd_params *p_in, int ngpu, int64_t budget_bytes, double link_GBps, int32_t *groups,
                                    int32_t *stream_factor, double *est_seconds) {
+    const zd_params pc = canonical(p_in), *p = &pc;
     if (est_seconds) est_seconds[0] = est_seconds[1] = 0.0;
     if (zd_choose_pass_groups(p, ngpu, budget_bytes, groups, stream_factor)) return 1;
     if (!(link_GBps > 0.0) || ngpu < 2 || p->pass_groups != 0 || *groups != ngpu) return 0;  // nothing to decide
@@ -676,8 +730,39 @@ int zd_plan_create(const zd_params *p, const zd_pk *pk, const double *eig, int64
     return 0;
 }
 
-static int plan_create_ex(const zd_params *p, const zd_pk *pk, const double *eig, int64_t eig_ppd, int rank, int nranks,
+static int plan_create_one(const zd_params *p, const zd_pk *pk, const double *eig, int64_t eig_ppd, int rank, int nranks, int phi_mode,
+                           const cplx *phik, zd_plan **out);
+
+static int plan_create_ex(const zd_params *p_in, const zd_pk *pk, const double *eig, int64_t eig_ppd, int rank, int nranks,
                           int phi_mode, const cplx *phik, zd_plan **out) {
+    const zd_params pc = canonical(p_in);
+    const bool split_R_ok = pc.stream_factor <= 0 || (np2_stream_factor_ok(pc.ppd, pc.stream_factor) && np2_stream_factor_ok(pc.ppd, 2 * pc.stream_factor));
+    if (phi_mode == 0 && phik == nullptr && plt_dens_split(&pc, nranks) && split_R_ok && eig != nullptr && eig_ppd > 0) {
+        const zd_params pa = split_plt_half(&pc);
+        zd_plan *A = nullptr, *B = nullptr;
+        bool ok = plan_create_one(&pa, pk, eig, eig_ppd, rank, nranks, 0, nullptr, &A) == 0;
+        ok = ok && A->pack == zd::PACK_PLTFIELD && !A->any && np2_stream_factor_ok(pc.ppd, 2 * A->R);
+        if (ok) {
+            const zd_params pb = split_dens_half(&pc, A->R);
+            ok = plan_create_one(&pb, pk, nullptr, 0, rank, nranks, 0, nullptr, &B) == 0;
+            ok = ok && B->dens_only && B->npass == A->npass && B->pstep == 2 && 2 * B->Zq == A->Zq;
+        }
+        if (ok) ok = zd_store_alloc((void **) &A->d_dens_pass, (size_t) A->Zq * pc.ppd * pc.ppd * sizeof(float)) == hipSuccess;
+        if (ok) {
+            A->dens_sub     = B;
+            A->p            = pc;  // (what the callers read back: ZD_qdensity = 1)
+            A->store_bytes_ = std::max(A->store_bytes_, B->store_bytes_);
+            *out            = A;
+            return 0;
+        }
+        zd_plan_destroy(B);
+        zd_plan_destroy(A);  // the run falls back to the reference arrays (convolution path)
+    }
+    return plan_create_one(&pc, pk, eig, eig_ppd, rank, nranks, phi_mode, phik, out);
+}
+
+static int plan_create_one(const zd_params *p, const zd_pk *pk, const double *eig, int64_t eig_ppd, int rank, int nranks,
+                           int phi_mode, const cplx *phik, zd_plan **out) {
     const int64_t N = p->ppd;
     // Three transform families: powers of two (zd_kernels.hip), 2^a 3^b on the field stores (zd_kernels_np2.hip), and ANY
     // other even PPD — or a 2^a 3^b one with options the composite kernels lack — as convolutions on the power-of-two engine
@@ -1324,6 +1409,8 @@ void zd_plan_destroy(zd_plan *pl) {
     hipFree(pl->d_fieldrows);
     hipFree(pl->d_ring);
     hipFree(pl->d_ring_dens);
+    hipFree(pl->d_dens_pass);
+    zd_plan_destroy(pl->dens_sub);
     hipFree(pl->d_v1streams);
     hipFree(pl->d_v1dev);
     hipFree(pl->d_v1err);
@@ -1432,6 +1519,23 @@ int zd_plan_stage_z_detached(zd_plan *pl, int residue, void *d_send, void *hip_s
 
 static int stage_z_impl(zd_plan *pl, int residue, void *d_send, hipStream_t st, bool detached, hipEvent_t wait_ev, hipEvent_t done_ev) {
     if (residue < 0 || residue >= pl->npass) return 1;
+    if (pl->dens_sub) {
+        // PLT + ZD_qdensity = 1 on a composite grid (plan_create_ex): first the whole density-only pass — Z stage into this store,
+        // y / x stages of its density array — whose planes are the planes of this pass; then the PLT pass proper over the same
+        // store.  All in stream order on st (a detached call included: the density planes are kept in ONE buffer).
+        zd_plan *B = pl->dens_sub;
+        if (detached && wait_ev) HIPCHECK(hipStreamWaitEvent(st, wait_ev, 0));
+        B->pass_step = pl->pass_step;
+        if (stage_z_impl(B, residue, d_send, st, false, nullptr, nullptr)) return 1;
+        if (zd_plan_stage_x_group(B, residue, d_send, B->Zq, 0, 0, (int64_t) B->Zq * 2, nullptr, pl->d_dens_pass, st)) return 1;
+        zd_plan *sub = pl->dens_sub;
+        pl->dens_sub = nullptr;  // (the PLT pass itself)
+        const int rc = stage_z_impl(pl, residue, d_send, st, false, nullptr, nullptr);
+        pl->dens_sub = sub;
+        if (rc) return rc;
+        if (detached && done_ev) HIPCHECK(hipEventRecord(done_ev, st));
+        return 0;
+    }
     if (detached && (pl->any || !pl->overlap)) {  // no worker streams: in stream order on st
         if (wait_ev) HIPCHECK(hipStreamWaitEvent(st, wait_ev, 0));
         if (stage_z_impl(pl, residue, d_send, st, false, nullptr, nullptr)) return 1;
@@ -1587,6 +1691,11 @@ int zd_plan_stage_x_group(zd_plan *pl, int residue, const void *d_recv, int chun
                 (long long) plane0, (long long) nplanes, ps, (long long) chunk_planes * ps);
         return 1;
     }
+    if (d_density && pl->dens_sub) {  // the planes the density-only half left behind at the head of this pass's Z stage
+        HIPCHECK(hipMemcpyAsync(d_density, pl->d_dens_pass + (size_t) gplane0 * pl->N * pl->N, (size_t) nplanes * pl->N * pl->N * sizeof(float),
+                                hipMemcpyDeviceToDevice, st));
+        d_density = nullptr;
+    }
     if (d_density && pl->pack != zd::PACK_NONE && !pl->dens) return 1;  // packed stores carry no density field (but the six-field store)
     if (pl->any) {  // x lines of the planes in place (each plane once), then the particle epilogue
         const int z_first = (int) zd_plan_plane_z(pl, residue, gplane0);
@@ -1672,6 +1781,14 @@ int zd_plan_stats(zd_plan *pl, zd_stats *out) {
         out->kernel_launches[k] = pl->launches[k];
         pl->kernel_ms[k]        = 0;
         pl->launches[k]         = 0;
+    }
+    if (pl->dens_sub) {  // the density-only half of a PLT + ZD_qdensity = 1 run: its kernels belong to this run's time
+        zd_stats sb;
+        if (zd_plan_stats(pl->dens_sub, &sb)) return 1;
+        for (int k = 0; k < ZD_K_COUNT; k++) {
+            out->kernel_ms[k] += sb.kernel_ms[k];
+            out->kernel_launches[k] += sb.kernel_launches[k];
+        }
     }
     out->bytes_intermediate = zd_plan_exchange_bytes(pl);
     out->bytes_sent         = pl->bytes_sent;

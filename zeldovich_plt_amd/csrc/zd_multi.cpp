@@ -743,7 +743,7 @@ static int run_passes_impl(zd_plan *pl, zd_comm *c, int first, int step, void *d
     // store while the y / x stages of pass p — HBM-bound — run on the caller's stream; its z FFT waits until the XY stages of pass
     // p - 1 have left that store.  Two stores of half the size mean twice the passes (twice the generations), so whether this
     // pays is a measurement: bench.py --two-stores (profiles/r04_tuning_notes.md).
-    if (!pipelined && pl->nranks == 1 && d_store2 != nullptr && first + step < pl->npass && pl->overlap && !pl->any) {
+    if (!pipelined && pl->nranks == 1 && d_store2 != nullptr && first + step < pl->npass && pl->overlap && !pl->any && !pl->dens_sub) {
         for (hipEvent_t &e : pl->ev_pipe)
             if (!e) MHIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         hipEvent_t ev_start = pl->ev_pipe[0], *ev_zd = pl->ev_pipe + 1, *ev_xy = pl->ev_pipe + 3;

@@ -33,6 +33,11 @@ struct zd_plan {
     bool dens = false;              // ZD_qdensity = 1 on the six-field store (composite grids): fields 4, 5 = D of the two residues
     bool dens_only = false;         // ZD_qdensity = 2 there: density planes only, no records
     zdfft::cplx *d_ring_dens = nullptr;  // ... and their array delta_r0 + i delta_r1 for the ring's planes
+    // PLT + ZD_qdensity = 1 on the composite grids (one rank): the density planes of a pass come from a second, density-only plan at
+    // stream factor 2R (its pass j = residues j, j + R = exactly the planes of this plan's pass j), run at the head of the Z stage on
+    // the same store; they wait here, in delivery order, for the x stage's calls
+    zd_plan *dens_sub = nullptr;
+    float *d_dens_pass = nullptr;
     int ring_planes = 0;
     int64_t store_bytes_ = 0;       // bytes of the send (= receive) buffer per pass
     // device tables
