@@ -878,8 +878,8 @@ def test_density_only_on_composite_grids_vs_oracle(zd, oracle, ps, opk, n, kw):
 
 @pytest.mark.parametrize("n,kw", [
     (96, dict(stream_factor=1)),                                   # 32 * 3: z lines of 96, the density half at 2 x 48
-    (160, dict(stream_factor=1, qPLTrescale=1)),                   # 32 * 5
-    (224, dict(stream_factor=1)),                                  # 32 * 7
+    pytest.param(160, dict(stream_factor=1, qPLTrescale=1), marks=pytest.mark.slow),  # 32 * 5
+    pytest.param(224, dict(stream_factor=1), marks=pytest.mark.slow),                 # 32 * 7
     (192, dict(stream_factor=2, qPLTrescale=1)),                   # two passes, each with its own density-only pass (R = 4) in front
     (192, dict()),                                                 # stream factor left to the library
     (192, dict(stream_factor=2, ngpu=2, pass_groups=2)),           # two GPUs, one pass each: every rank composes its own pass
