@@ -92,3 +92,64 @@ def test_soak_random_options_vs_oracle(zd, oracle, wmap_path):
             print("   FAILED:", repr(e)[:300], flush=True)
             failed.append((desc, repr(e)[:300]))
     assert not failed, failed
+
+
+def test_soak_store_modes_agree_at_mid_sizes(zd, oracle, wmap_path):
+    """Sizes the oracle does not reach in seconds (512 ... 1280, powers of two and composite): the same random options through the
+    library's different stores — `auto` (packed / field stores, the fused PLT Z stage at 512 and 1024, composite kernels) against
+    `reference` (the reference's arrays; composite grids: the convolution kernels) and, where it differs from `auto`, `packed` —
+    three sample planes record by record, density_variance, max_disp and its lattice site.  ZD_SOAK_SEED / ZD_SOAK_TRIALS2."""
+    seed = int(os.environ.get("ZD_SOAK_SEED", "1"))
+    trials = int(os.environ.get("ZD_SOAK_TRIALS2", "24"))
+    rng = np.random.default_rng(1000 + seed)
+    failed = []
+    for trial in range(trials):
+        n = int(rng.choice([512, 512, 1024, 1024, 768, 640, 896, 1280]))
+        comp = n & (n - 1) != 0
+        plt = bool(rng.integers(0, 2))
+        kw = dict(seed=int(rng.integers(1, 2 ** 31 - 1)), k_cutoff=float(rng.choice([1.0, 1.0, 1.0, 1.5, 2.0, 4.0])),
+                  corner_modes=int(rng.integers(0, 2)), f_cluster=float(rng.choice([1.0, 0.93])), boxsize=float(rng.choice([720.0, 90.0, 2000.0])))
+        eig = None
+        if plt:
+            eig = oracle.synthetic_eigenmodes(int(rng.choice([32, 48, 64, 128])), seed=int(rng.integers(0, 100)))
+            kw.update(qPLT=1, qPLTrescale=int(rng.integers(0, 2)), PLT_target_z=float(rng.choice([3.0, 9.0])))
+        if rng.integers(0, 6) == 0:
+            h = n // 2
+            kw.update(qonemode=1, one_mode=[int(rng.choice([-1, 1])) * int(rng.integers(1, h // 3)), int(rng.integers(1, h // 3)),
+                                            int(rng.choice([-1, 1])) * int(rng.integers(1, h // 3))])
+        pkw = dict(fix_to_mean=int(rng.integers(0, 2)), Pk_smooth=float(rng.choice([0.0, 0.0, 0.5])))
+        ps = zd.PowerSpectrum.from_file(wmap_path, kw["boxsize"], **pkw)
+        zs = sorted(int(z) for z in rng.choice(n, 3, replace=False))
+        modes = ["reference", "auto"] + (["packed"] if not comp and rng.integers(0, 2) else [])
+        desc = (trial, n, kw, pkw, None if eig is None else eig.shape[0], zs, modes)
+        print("trial", *desc, flush=True)
+        res = {}
+        try:
+            for m in modes:
+                planes = {}
+
+                def keep(z, rec):
+                    if z in zs:
+                        planes[z] = rec.copy()
+
+                out = zd.generate_planes(zd.make_params(n, icformat="RVdoubleZel", store_mode=m, **kw), ps, keep, eig=eig)
+                res[m] = (planes, out)
+            ref_planes, ref = res["reference"]
+            for m in modes[1:]:
+                planes, out = res[m]
+                assert out["planes"] == ref["planes"] == n
+                for z in zs:
+                    a, b = planes[z], ref_planes[z]
+                    assert np.array_equal(a["ijk"], b["ijk"])
+                    for f in ("d", "v"):
+                        scale = np.abs(b[f]).max()
+                        assert np.abs(a[f] - b[f]).max() <= 1e-10 * max(scale, 1e-300), (m, z, f, np.abs(a[f] - b[f]).max(), scale)
+                assert abs(out["density_variance"] - ref["density_variance"]) <= 1e-10 * ref["density_variance"], m
+                md, mr = np.asarray(out["max_disp"]), np.asarray(ref["max_disp"])
+                if kw.get("qonemode"):  # a plane wave: +max and -max tie to rounding, either may be the first (see _compare's tie_ok)
+                    md, mr = np.abs(md), np.abs(mr)
+                assert np.abs(md - mr).max() <= 1e-10 * np.abs(mr).max(), m
+        except Exception as e:
+            print("   FAILED:", repr(e)[:400], flush=True)
+            failed.append((desc, repr(e)[:400]))
+    assert not failed, failed
