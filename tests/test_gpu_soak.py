@@ -98,13 +98,14 @@ def test_soak_store_modes_agree_at_mid_sizes(zd, oracle, wmap_path):
     """Sizes the oracle does not reach in seconds (512 ... 1280, powers of two and composite): the same random options through the
     library's different stores — `auto` (packed / field stores, the fused PLT Z stage at 512 and 1024, composite kernels) against
     `reference` (the reference's arrays; composite grids: the convolution kernels) and, where it differs from `auto`, `packed` —
-    three sample planes record by record, density_variance, max_disp and its lattice site.  ZD_SOAK_SEED / ZD_SOAK_TRIALS2."""
+    three sample planes record by record, density_variance, max_disp and its lattice site.  ZD_SOAK_SEED / ZD_SOAK_TRIALS2 /
+    ZD_SOAK_SIZES (e.g. "2048,1536,1792": BASELINE C3's size through the fused Z stage against the reference's arrays)."""
     seed = int(os.environ.get("ZD_SOAK_SEED", "1"))
     trials = int(os.environ.get("ZD_SOAK_TRIALS2", "24"))
     rng = np.random.default_rng(1000 + seed)
     failed = []
     for trial in range(trials):
-        n = int(rng.choice([512, 512, 1024, 1024, 768, 640, 896, 1280]))
+        n = int(rng.choice([int(v) for v in os.environ.get("ZD_SOAK_SIZES", "512,512,1024,1024,768,640,896,1280").split(",")]))
         comp = n & (n - 1) != 0
         plt = bool(rng.integers(0, 2))
         kw = dict(seed=int(rng.integers(1, 2 ** 31 - 1)), k_cutoff=float(rng.choice([1.0, 1.0, 1.0, 1.5, 2.0, 4.0])),
