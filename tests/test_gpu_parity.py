@@ -1265,6 +1265,11 @@ def test_fft_lines_any_length(zd, n, kind):
     (50, dict(stream_factor=5)),                                # a stream factor that is not a power of two: z lines of 10
     (90, dict(stream_factor=3, fmt="RVZel")),                   # 2 * 3^2 * 5, three residue passes
     (100, dict(stream_factor=25)),                              # z lines of 4
+    # several GPUs (round 5): the convolution kernels run on one rank, so the GPUs share such a job as pass groups — the library picks a
+    # divisor of PPD that deals its passes out over them (zd_choose_pass_groups, convolution_job)
+    (100, dict(ngpu=2, pass_groups=0, fmt="RVZel")),           # R = 2: one pass per GPU
+    (90, dict(ngpu=2, pass_groups=0, qdensity=1)),             # 2 * 3^2 * 5
+    (96, dict(ngpu=4, pass_groups=0, corner_modes=1, k_cutoff=2.0)),  # a composite size whose option needs the reference arrays
 ])
 def test_any_even_ppd_vs_oracle(zd, oracle, ps, opk, n, kw):
     """PPD with prime factors other than 2 and 3 (the reference plans any length with FFTW, src/zeldovich.cpp:61-66; its only

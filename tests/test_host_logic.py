@@ -81,6 +81,27 @@ def test_stream_factor_for_any_even_ppd(zd):
     assert R(8640, 250 * GB) == 80 and R(8640, 250 * GB, qPLT=1) == -1   # 64 * 135: z lines of 108 = 4 * 27; beyond 8192 only the ZA field store
 
 
+
+def test_pass_groups_for_jobs_on_the_convolution_kernels(zd):
+    """a job that one rank runs as convolutions (PPD neither 2^a nor a composite size with the options the composite kernels have)
+    is shared by several GPUs as pass groups only: the library picks a divisor of PPD that deals its passes out over them — up to four
+    times the passes one GPU would need, or two per GPU — and refuses where no divisor does (it used to refuse all of them)"""
+    L = zd.load_library()
+    GB = 1 << 30
+
+    def G(n, ngpu, budget=250 * GB, **kw):
+        g, R = C.c_int32(), C.c_int32()
+        rc = L.zd_choose_pass_groups(C.byref(zd.make_params(n, **kw)), ngpu, int(budget), C.byref(g), C.byref(R))
+        return (g.value, R.value) if rc == 0 else None
+
+    assert G(1000, 8) == (8, 8) and G(1000, 2) == (2, 2) and G(3000, 8) == (8, 8)
+    assert G(5000, 8) == (8, 40)       # one GPU needs R = 20 (z lines of 250): 40 passes, five per GPU
+    assert G(100, 2) == (2, 2) and G(100, 4) == (4, 4) and G(50, 2) == (2, 2)
+    assert G(1250, 4) is None          # 2 * 5^4 has no divisor that is a multiple of 4
+    assert G(192, 4, k_cutoff=2.0, corner_modes=1) == (4, 4)     # a composite size whose option needs the reference arrays
+    assert G(192, 4, k_cutoff=2.0, corner_modes=1, stream_factor=2) == (1, 2)  # a given factor is kept (plan creation then says that this store runs on one rank)
+    assert G(3456, 8) == (1, 2) and G(4096, 8) == (8, 16)        # the composite / power-of-two choices are what they were
+
 def test_params_from_file(zd, tmp_path):
     par = _write(tmp_path, EXAMPLE % dict(out=tmp_path / "ic", eig="./eigmodes128", pk=WMAP, plt=1))
     p, s = zd.params_from_file(par)

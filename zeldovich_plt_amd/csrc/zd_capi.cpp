@@ -502,6 +502,14 @@ static int choose_stream_factor_one(const zd_params *p, int nranks, int64_t budg
     return np2 ? any_factor() : -1;
 }
 
+// a job that one rank runs as convolutions on the power-of-two engine (zd_kernels_any.hip: PPD neither 2^a nor a composite size
+// whose options the composite kernels have).  Its R is any divisor of PPD; several GPUs share it as pass groups only.
+static bool convolution_job(const zd_params *p) {
+    const int64_t N = p->ppd;
+    if (is_pow2(N) || plt_dens_split(p, 1)) return false;
+    return p->f_NL != 0. || !zd::pack_is_fields(pack_mode(p, 2)) || !zd::np2_supported_ppd((int) N) || (N / 2) % zd::FIELD_RB;
+}
+
 // planes a store plane delivers for (p, R) on `nranks` ranks: 2 with the ZA packings (plan_create_ex's choice of store)
 static int plan_plane_step(const zd_params *p, int R, int nranks) {
     const int64_t N = p->ppd;
@@ -539,6 +547,13 @@ int zd_choose_pass_groups(const zd_params *p_in, int ngpu, int64_t budget_bytes,
             // one pass per GPU, 0.36-0.38 s predicted against 0.30-0.33 s for the all-to-all — within the
             // uncertainty of the link rate, and independent of it.  More than one doubling is not worth the generations.
             const int Rmax = q.stream_factor > 0 ? R1 : 2 * R1;
+            if (convolution_job(p) && p->f_NL == 0.) {  // any divisor of PPD is a stream factor there; up to four times the passes it needs
+                for (int R2 = R1; R2 <= (q.stream_factor > 0 ? R1 : std::max(4 * R1, 2 * ngpu)) && p->ppd / R2 >= 3; R2++)
+                    if (p->ppd % R2 == 0 && R2 % ngpu == 0) {
+                        g = ngpu;
+                        break;
+                    }
+            } else
             for (int R2 = R1; R2 <= Rmax; R2 = is_pow2(p->ppd) ? R2 * 2 : R2 + 2) {
                 const bool len_ok = is_pow2(p->ppd) ? (p->ppd % R2 == 0 && p->ppd / R2 >= 32) : np2_stream_factor_ok(p->ppd, R2);
                 if (!len_ok) {
@@ -571,6 +586,10 @@ int zd_choose_pass_groups(const zd_params *p_in, int ngpu, int64_t budget_bytes,
         if (is_pow2(p->ppd)) {
             R *= 2;
             if (p->ppd % R || p->ppd / R < 32 || (p->ppd / R) % gsz) return 1;
+        } else if (gsz == 1 && convolution_job(p)) {  // convolution kernels: the next divisor of PPD
+            do R++;
+            while (p->ppd / R >= 3 && p->ppd % R);
+            if (p->ppd / R < 3) return 1;
         } else {  // composite PPD: the next even factor the composite kernels take
             do R += 2;
             while (p->ppd / R >= 12 && !(np2_stream_factor_ok(p->ppd, R) && (p->ppd / R) % gsz == 0));
