@@ -46,8 +46,9 @@ def _draw(rng, oracle):
                                         sgn() * int(rng.integers(1, h // 3 + 1))])
     # reference arrays (the only store of these options) exist on several ranks for the powers of two only: a composite grid then
     # runs as convolutions on one rank, and says so
-    ref_arrays = kw["store_mode"] == "reference" or (kw["corner_modes"] and kw["k_cutoff"] != 1.0) or (kw["k_cutoff"] < 1.0)
-    if rng.integers(0, 4) == 0 and n >= 128 and not (comp and (ref_arrays or (plt and kw.get("qdensity") == 1))):
+    ref_arrays = (kw["store_mode"] == "reference" or (kw["corner_modes"] and kw["k_cutoff"] != 1.0) or (kw["k_cutoff"] < 1.0)
+                  or (comp and kw["store_mode"] == "packed"))  # (the composite kernels exist for the field stores only)
+    if rng.integers(0, 3) == 0 and n >= 128 and not (comp and (ref_arrays or (plt and kw.get("qdensity") == 1))):
         ng = int(rng.choice([2, 4]))
         if (n // R) % ng == 0 and (n // 2) % (8 * ng) == 0:
             kw["ngpu"] = ng
@@ -56,6 +57,8 @@ def _draw(rng, oracle):
             passes = R if (plt or (kw.get("qdensity") and not comp) or ref_arrays or R < 2) else R // 2
             if rng.integers(0, 2) and passes % ng == 0:
                 kw["pass_groups"] = ng
+            elif rng.integers(0, 2):
+                kw["loopback"] = True  # one group of ranks on the RCCL branch of the exchange (in-process emulation of its calls: the -DZD_TESTING library)
     if rng.integers(0, 6) == 0:  # ZD_Version = 1: mt19937 streams, PPD / NumBlock of them, dealt over the ranks
         if (n // 2) % kw.get("ngpu", 1) == 0 and kw["k_cutoff"] in (1.0, 2.0, 4.0):  # (NumBlock 2 x k_cutoff must divide PPD: parameters.cpp:129-141)
             kw["version"] = 1
