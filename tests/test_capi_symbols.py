@@ -173,9 +173,9 @@ def test_choose_pass_groups_policy():
     assert choose(4096, 8, stream_factor=8)[0] == 1      # a given stream factor is kept: 4 passes -> one group
     assert choose(2048, 8)[0] == 1 and choose(2048, 2) == (2, 4)  # (two GPUs would exchange over a single link)
     assert choose(4096, 8, qPLT=1, qPLTrescale=1) == (8, 16)  # 16 passes, two per GPU
-    # composite grid: any even stream factor with a composite z length.  PPD = 6912 ZA: R = 36 (18 passes) on one GPU, two GPUs take
-    # nine passes each, eight GPUs R = 48 (24 passes, three each)
-    assert choose(6912, 1) == (1, 36) and choose(6912, 2) == (2, 36)
+    # composite grid: any even stream factor with a composite z length.  PPD = 6912 ZA: R = 32 (16 passes of two residues, z lines of
+    # 216 = 8 * 27 — round 5; before: R = 36, 18 passes) on one GPU, two GPUs take eight passes each, eight GPUs two each
+    assert choose(6912, 1) == (1, 32) and choose(6912, 2) == (2, 32) and choose(6912, 8) == (8, 32)
     g, R = choose(6912, 8)
     assert g == 8 and 6912 % R == 0 and (R // 2) % 8 == 0 and R <= 72, (g, R)
 

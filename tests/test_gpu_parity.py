@@ -880,6 +880,7 @@ def test_density_only_on_composite_grids_vs_oracle(zd, oracle, ps, opk, n, kw):
 
 @pytest.mark.parametrize("n,kw", [
     (96, dict(stream_factor=1)),                                   # 32 * 3: z lines of 96, the density half at 2 x 48
+    (96, dict(stream_factor=2)),                                   # z lines of 48, the density half at 4 x 24 (= 8 * 3)
     pytest.param(160, dict(stream_factor=1, qPLTrescale=1), marks=pytest.mark.slow),  # 32 * 5
     pytest.param(224, dict(stream_factor=1), marks=pytest.mark.slow),                 # 32 * 7
     (192, dict(stream_factor=2, qPLTrescale=1)),                   # two passes, each with its own density-only pass (R = 4) in front
@@ -1125,6 +1126,38 @@ def test_non_power_of_two_short_z_lines(zd, oracle, ps):
                        lambda z, rec: hi.__setitem__(z // 2, rec["d"][::2, ::2].copy()) if (z % 2 == 0 and z // 2 in zs) else None)
     for z in zs:
         assert np.abs(hi[z] - lo[z]).max() < 1e-12 * np.abs(lo[z]).max(), z
+
+
+@pytest.mark.parametrize("n,R,plt", [(96, 4, False), (160, 4, False), (224, 4, True)])
+def test_z_lines_of_eight_times_q_vs_oracle(zd, oracle, ps, opk, n, R, plt):
+    """z lines of 8 * Q (round 5: 24, 40, 56 here — one thread per 8-point sub-line in the z transform, `k_zfft_fq<8, 8, Q, NC>`;
+    the generator walks 4 z rows per thread) against the oracle, ZA (two residues per pass) and PLT"""
+    eig = oracle.synthetic_eigenmodes(24) if plt else None
+    kw = dict(qPLT=1, qPLTrescale=1, PLT_target_z=5.0, f_cluster=0.97) if plt else {}
+    plan = zd.Plan(zd.make_params(n, stream_factor=R, **kw), ps, eig=eig)
+    assert plan.store_mode == "fields" and plan.R == R
+    plan.close()
+    got, _ = _compare(zd, oracle, ps, opk, n, eig=eig, stream_factor=R, **kw)
+    assert sorted(got["planes_seen"]) == list(range(n))
+
+
+@pytest.mark.parametrize("n,R", [(288, 4), (480, 4), (800, 4), (864, 4)])
+def test_z_lines_of_eight_times_q_vs_longer_lines(zd, oracle, ps, n, R):
+    """z lines of 72, 120, 200, 216 = 8 * {9, 15, 25, 27} (beyond the oracle's plain DFT in the time of a test): stream factor R
+    against R = 2 (lines of 16 * 2^k * Q) on sample planes, ZA with a density (six fields) and PLT"""
+    zs = (1, n // 2 + 3, n - 2)
+    eig = oracle.synthetic_eigenmodes(32)
+    for kw, e in ((dict(icformat="RVdoubleZel", qdensity=1), None),
+                  (dict(icformat="RVdoubleZel", qPLT=1, qPLTrescale=1, PLT_target_z=5.0, f_cluster=0.97), eig)):
+        a, b = {}, {}
+        sa = zd.generate_planes(zd.make_params(n, stream_factor=2, **kw), ps, lambda z, rec: a.__setitem__(z, rec.copy()) if z in zs else None, eig=e)
+        sb = zd.generate_planes(zd.make_params(n, stream_factor=R, **kw), ps, lambda z, rec: b.__setitem__(z, rec.copy()) if z in zs else None, eig=e)
+        assert sb["stream_factor"] == R and sorted(a) == sorted(b) == sorted(zs)
+        for z in zs:
+            for f in ("d", "v"):
+                assert np.abs(a[z][f]).max() > 0
+                assert np.abs(a[z][f] - b[z][f]).max() <= 1e-12 * np.abs(a[z][f]).max(), (kw, z, f)
+        assert abs(sa["density_variance"] - sb["density_variance"]) <= 1e-12 * sa["density_variance"]
 
 
 @pytest.mark.parametrize("n,Rs,plt", [(864, (6, 18), False), (864, (6,), True), (960, (10, 12, 20), False)])

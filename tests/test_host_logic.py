@@ -68,9 +68,9 @@ def test_stream_factor_for_any_even_ppd(zd):
     # with a density since round 4, density only since round 5: the six-field store) ...
     assert R(96, 250 * GB, qdensity=2, qPLT=1) == 2  # ... density only ignores ZD_qPLT, as the reference does (zeldovich.cpp:303,440)
     # PLT with ZD_qdensity = 1: a density-only pass at 2R in front of every PLT pass (plt_dens_split) — R and 2R must both be z lengths
-    # the composite kernels transform (96 / 1 = 96, 96 / 2 = 48; 24 is not one), and the density planes of a pass need room
+    # the composite kernels transform, and the density planes of a pass need room
     assert R(96, 250 * GB, qdensity=1, qPLT=1) == 1
-    assert R(3456, 270 * GB, qPLT=1) == 6 and R(3456, 270 * GB, qdensity=1, qPLT=1) == 12  # 8 has no 2R = 16 (z lines of 216 = 8 * 27)
+    assert R(3456, 270 * GB, qPLT=1) == 6 and R(3456, 270 * GB, qdensity=1, qPLT=1) == 8  # 6: no room beside the 260 GB store; 8 with 2R = 16: z lines of 216 = 8 * 27
     assert R(3456, 270 * GB, qdensity=1, qPLT=1, nranks=2) == -1  # several ranks of one group: no composite path, and the convolution path is one rank
     assert R(1000, 250 * GB, f_NL=1.0, n_s=0.96, Omega_M=0.3) == 1
     # radix-7 composite grids (round 4): 7168 = 1024 * 7 with z lines of 112 = 16 * 7; 3584 = 512 * 7, z lines of 448; 4320 = 32 * 135
@@ -78,7 +78,7 @@ def test_stream_factor_for_any_even_ppd(zd):
     assert R(7168, 250 * GB) == 64 and R(3584, 250 * GB) == 8 and R(2688, 250 * GB) == 2 and R(4320, 250 * GB) == 10
     assert R(7168, 250 * GB, nranks=8) == 8 and R(6272, 250 * GB, qPLT=1) == 56
     assert R(8192, 250 * GB, qPLT=1, k_cutoff=2.0) > 0 and R(8192, 250 * GB, qPLT=1, qdensity=1) == -1   # four reference arrays at 8192: a row of the x pass is 2048 threads
-    assert R(8640, 250 * GB) == 80 and R(8640, 250 * GB, qPLT=1) == -1   # 64 * 135: z lines of 108 = 4 * 27; beyond 8192 only the ZA field store
+    assert R(8640, 250 * GB) == 72 and R(8640, 250 * GB, qPLT=1) == -1   # 64 * 135: z lines of 120 = 8 * 15 (round 4: R = 80, lines of 108 = 4 * 27); beyond 8192 only the ZA field store
 
 
 

@@ -124,6 +124,14 @@ EXPECTED = [
     ("reference arrays PLT", "launch_xfft_t", "NA = 4"),
     ("f_NL", "launch_fnl_t", ""),
     ("version 1", "launch_v1_draw", ""),
+    # z lines of 8 * Q (round 5): one thread per 8-point sub-line
+    ("composite z lines 8 * Q", "launch_zfft_fq_t", "P = 8, E = 8, Q = 3, NC = 4"),
+    ("composite z lines 8 * Q", "launch_zfft_fq_t", "P = 8, E = 8, Q = 5, NC = 4"),
+    ("composite z lines 8 * Q", "launch_zfft_fq_t", "P = 8, E = 8, Q = 7, NC = 4"),
+    ("composite z lines 8 * Q", "launch_zfft_fq_t", "P = 8, E = 8, Q = 9, NC = 4"),
+    ("composite z lines 8 * Q", "launch_zfft_fq_t", "P = 8, E = 8, Q = 15, NC = 4"),
+    ("composite z lines 8 * Q", "launch_zfft_fq_t", "P = 8, E = 8, Q = 25, NC = 2"),
+    ("composite z lines 8 * Q", "launch_zfft_fq_t", "P = 8, E = 8, Q = 27, NC = 2"),
 ]
 
 

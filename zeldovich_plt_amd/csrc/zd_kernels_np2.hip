@@ -544,14 +544,26 @@ int launch_zfft_fields_np2(int L, const FieldLayout &F, const StoreLayout &S, in
     if (L == 180) return launch_zfft_fq_t<4, 4, 45, 2>(F, S, ky0, kyloc0, nky, Y, (const cplx *) tw, out, st);
     if (L == 100) return launch_zfft_fq_t<4, 4, 25, 4>(F, S, ky0, kyloc0, nky, Y, (const cplx *) tw, out, st);
     if (L == 60) return launch_zfft_fq_t<4, 4, 15, 4>(F, S, ky0, kyloc0, nky, Y, (const cplx *) tw, out, st);
-    fprintf(stderr, "zeldovich_hip: no z transform of length %d (16*2^k * {3, 9, 27, 5, 15, 25, 45, 75, 125, 7, 21, 35, 49})\n", L);
+    // 8 * Q (round 5): eight elements per thread, one thread per sub-line — the half-length lines of the density-only passes that
+    // precede the PLT passes of a PLT + ZD_qdensity = 1 run (zd_capi.cpp plt_dens_split: stream factors R and 2R; PPD = 3456 at R = 8 needs
+    // 216 = 8 * 27), and more stream factors to choose from in general
+    if (L == 24) return launch_zfft_fq_t<8, 8, 3, 4>(F, S, ky0, kyloc0, nky, Y, (const cplx *) tw, out, st);
+    if (L == 40) return launch_zfft_fq_t<8, 8, 5, 4>(F, S, ky0, kyloc0, nky, Y, (const cplx *) tw, out, st);
+    if (L == 56) return launch_zfft_fq_t<8, 8, 7, 4>(F, S, ky0, kyloc0, nky, Y, (const cplx *) tw, out, st);
+    if (L == 72) return launch_zfft_fq_t<8, 8, 9, 4>(F, S, ky0, kyloc0, nky, Y, (const cplx *) tw, out, st);
+    if (L == 120) return launch_zfft_fq_t<8, 8, 15, 4>(F, S, ky0, kyloc0, nky, Y, (const cplx *) tw, out, st);
+    if (L == 200) return launch_zfft_fq_t<8, 8, 25, 2>(F, S, ky0, kyloc0, nky, Y, (const cplx *) tw, out, st);
+    if (L == 216) return launch_zfft_fq_t<8, 8, 27, 2>(F, S, ky0, kyloc0, nky, Y, (const cplx *) tw, out, st);
+    fprintf(stderr, "zeldovich_hip: no z transform of length %d (16*2^k * {3, 9, 27, 5, 15, 25, 45, 75, 125, 7, 21, 35, 49}, or one of the short 4 * Q / 8 * Q lengths)\n", L);
     return 2;
 }
 // columns per z-FFT workgroup (the generator prunes by it) = the NC of the table above
 int zfft_fields_np2_columns(int L) {
     switch (L) {
         case 48: case 96: case 192: case 144: case 80: case 160: case 240: case 100: case 60: case 112: case 224: case 448: case 336: return 4;
+        case 24: case 40: case 56: case 72: case 120: return 4;  // 8 * Q
         case 384: case 288: case 432: case 108: case 320: case 480: case 400: case 180: case 896: case 672: case 560: case 784: return 2;
+        case 200: case 216: return 2;  // 8 * Q
         default: return 1;
     }
 }
@@ -676,6 +688,7 @@ bool np2_supported_ppd(int N) {
 bool np2_supported_zlen(int L) {
     int P, Q;
     if (L == 108 || L == 500 || L == 300 || L == 180 || L == 100 || L == 60) return true;  // 4 * Q (launch_zfft_fields_np2)
+    if (L == 24 || L == 40 || L == 56 || L == 72 || L == 120 || L == 200 || L == 216) return true;  // 8 * Q
     if (!np2_split(L, &P, &Q) || P < 16) return false;
     return (Q == 3 && P <= 512) || (Q == 9 && P <= 128) || (Q == 27 && P <= 64) || (Q == 5 && P <= 256) || (Q == 15 && P <= 128)
            || (Q == 25 && P <= 64) || (Q == 45 && P <= 32) || (Q == 75 && P <= 16) || (Q == 125 && P <= 16)
