@@ -1128,7 +1128,7 @@ def test_non_power_of_two_short_z_lines(zd, oracle, ps):
         assert np.abs(hi[z] - lo[z]).max() < 1e-12 * np.abs(lo[z]).max(), z
 
 
-@pytest.mark.parametrize("n,R,plt", [(96, 4, False), (160, 4, False), (224, 4, True)])
+@pytest.mark.parametrize("n,R,plt", [(96, 4, True), (160, 4, False), (224, 4, False)])
 def test_z_lines_of_eight_times_q_vs_oracle(zd, oracle, ps, opk, n, R, plt):
     """z lines of 8 * Q (round 5: 24, 40, 56 here — one thread per 8-point sub-line in the z transform, `k_zfft_fq<8, 8, Q, NC>`;
     the generator walks 4 z rows per thread) against the oracle, ZA (two residues per pass) and PLT"""
@@ -1141,14 +1141,14 @@ def test_z_lines_of_eight_times_q_vs_oracle(zd, oracle, ps, opk, n, R, plt):
     assert sorted(got["planes_seen"]) == list(range(n))
 
 
-@pytest.mark.parametrize("n,R", [(288, 4), (480, 4), (800, 4), (864, 4)])
-def test_z_lines_of_eight_times_q_vs_longer_lines(zd, oracle, ps, n, R):
+@pytest.mark.parametrize("n,R,plt", [(288, 4, False), (480, 4, True), (800, 4, False), (864, 4, True), pytest.param(864, 4, False, marks=pytest.mark.slow)])
+def test_z_lines_of_eight_times_q_vs_longer_lines(zd, oracle, ps, n, R, plt):
     """z lines of 72, 120, 200, 216 = 8 * {9, 15, 25, 27} (beyond the oracle's plain DFT in the time of a test): stream factor R
-    against R = 2 (lines of 16 * 2^k * Q) on sample planes, ZA with a density (six fields) and PLT"""
+    against R = 2 (lines of 16 * 2^k * Q) on sample planes, ZA with a density (six fields) or PLT"""
     zs = (1, n // 2 + 3, n - 2)
     eig = oracle.synthetic_eigenmodes(32)
-    for kw, e in ((dict(icformat="RVdoubleZel", qdensity=1), None),
-                  (dict(icformat="RVdoubleZel", qPLT=1, qPLTrescale=1, PLT_target_z=5.0, f_cluster=0.97), eig)):
+    for kw, e in (((dict(icformat="RVdoubleZel", qPLT=1, qPLTrescale=1, PLT_target_z=5.0, f_cluster=0.97), eig),) if plt else
+                  ((dict(icformat="RVdoubleZel", qdensity=1), None),)):
         a, b = {}, {}
         sa = zd.generate_planes(zd.make_params(n, stream_factor=2, **kw), ps, lambda z, rec: a.__setitem__(z, rec.copy()) if z in zs else None, eig=e)
         sb = zd.generate_planes(zd.make_params(n, stream_factor=R, **kw), ps, lambda z, rec: b.__setitem__(z, rec.copy()) if z in zs else None, eig=e)
