@@ -131,7 +131,7 @@ EXPECTED = [
     ("composite z lines 8 * Q", "launch_zfft_fq_t", "P = 8, E = 8, Q = 9, NC = 4"),
     ("composite z lines 8 * Q", "launch_zfft_fq_t", "P = 8, E = 8, Q = 15, NC = 4"),
     ("composite z lines 8 * Q", "launch_zfft_fq_t", "P = 8, E = 8, Q = 25, NC = 2"),
-    ("composite z lines 8 * Q", "launch_zfft_fq_t", "P = 8, E = 8, Q = 27, NC = 2"),
+    ("composite z lines 8 * Q", "launch_zfft_fq_t", "P = 8, E = 8, Q = 27, NC = 1"),
 ]
 
 

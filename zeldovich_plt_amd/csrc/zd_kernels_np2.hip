@@ -553,7 +553,10 @@ int launch_zfft_fields_np2(int L, const FieldLayout &F, const StoreLayout &S, in
     if (L == 72) return launch_zfft_fq_t<8, 8, 9, 4>(F, S, ky0, kyloc0, nky, Y, (const cplx *) tw, out, st);
     if (L == 120) return launch_zfft_fq_t<8, 8, 15, 4>(F, S, ky0, kyloc0, nky, Y, (const cplx *) tw, out, st);
     if (L == 200) return launch_zfft_fq_t<8, 8, 25, 2>(F, S, ky0, kyloc0, nky, Y, (const cplx *) tw, out, st);
-    if (L == 216) return launch_zfft_fq_t<8, 8, 27, 2>(F, S, ky0, kyloc0, nky, Y, (const cplx *) tw, out, st);
+    // (216 = PPD=6912 ZA at R = 32: ONE column per workgroup — 216 threads = one wave per SIMD, which fits beside the generator's three
+    // workgroups of 128 registers on a CU; with two columns, 432 threads, the z FFT only ran when a generator launch drained: Z stage
+    // 10.16 -> 9.42 s, profiles/r05_6912_z_stage.txt)
+    if (L == 216) return launch_zfft_fq_t<8, 8, 27, 1>(F, S, ky0, kyloc0, nky, Y, (const cplx *) tw, out, st);
     fprintf(stderr, "zeldovich_hip: no z transform of length %d (16*2^k * {3, 9, 27, 5, 15, 25, 45, 75, 125, 7, 21, 35, 49}, or one of the short 4 * Q / 8 * Q lengths)\n", L);
     return 2;
 }
@@ -563,7 +566,7 @@ int zfft_fields_np2_columns(int L) {
         case 48: case 96: case 192: case 144: case 80: case 160: case 240: case 100: case 60: case 112: case 224: case 448: case 336: return 4;
         case 24: case 40: case 56: case 72: case 120: return 4;  // 8 * Q
         case 384: case 288: case 432: case 108: case 320: case 480: case 400: case 180: case 896: case 672: case 560: case 784: return 2;
-        case 200: case 216: return 2;  // 8 * Q
+        case 200: return 2;  // 8 * Q (216: one column, see launch_zfft_fields_np2)
         default: return 1;
     }
 }
