@@ -27,7 +27,7 @@ def _draw(rng, oracle):
               boxsize=float(rng.choice([720.0, 720.0, 90.0, 2000.0])))
     if comp:
         R = int(rng.choice([1, 2, 2, 4])) if plt else int(rng.choice([2, 2, 4]))
-        if n // R < 48 or n % R or (n // R) % 16:  # z lines the composite kernels transform: 16 * 2^k * Q
+        if n // R < 24 or n % R or (n // R) % 8:  # z lines the composite kernels transform: 16 * 2^k * Q, and 8 * Q
             R = 1 if plt else 2
     else:
         R = int(rng.choice([1, 2, 4]))
